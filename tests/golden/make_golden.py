@@ -1,0 +1,335 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE (read-only at /root/reference) on CPU.
+
+Runs only in the build container (the reference does not travel to the GPU box). It
+  1. stubs the two absent third-party imports of dpt_models/renderer.py:6-7 (mcubes, icecream),
+  2. builds the reference's own SDFNetwork / RenderingNetwork / NeRF / SingleVarianceNetwork /
+     NeuSRenderer at the shipped config shapes and loads this repo's deterministic synthetic
+     weights (vdn_train.synth) through load_state_dict,
+  3. replaces torch.rand by a queue of injected jitter tensors for the duration of render(),
+  4. writes inputs + reference outputs as small .npz fixtures (weights are NOT stored: they are
+     regenerated from (seed, name) by vdn_train.synth),
+  5. cross-checks the oracle (oracle/neus_oracle.py) against the reference and prints the errors.
+
+Usage:  python tests/golden/make_golden.py [--check-only]
+"""
+import argparse
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "vdn-nerf_amd"))
+sys.path.insert(0, ROOT)
+warnings.filterwarnings("ignore")
+
+
+def import_reference():
+    sys.modules.setdefault("mcubes", types.ModuleType("mcubes"))
+    ic = types.ModuleType("icecream")
+    ic.ic = lambda *a, **k: None
+    sys.modules.setdefault("icecream", ic)
+    sys.path.insert(0, "/root/reference")
+    import importlib
+    fields = importlib.import_module("dpt_models.fields")
+    renderer = importlib.import_module("dpt_models.renderer")
+    embedder = importlib.import_module("dpt_models.embedder")
+    sys.path.remove("/root/reference")
+    return fields, renderer, embedder
+
+
+def build_reference(fields, renderer, states, wdepth, dtype, n_importance=64, n_outside=32):
+    tt = lambda d: {k: torch.tensor(v, dtype=dtype) for k, v in d.items()}
+    nerf = fields.NeRF(D=8, d_in=4, d_in_view=3, W=256, multires=10, multires_view=4, output_ch=4, skips=[4],
+                       rgb_dims=3, use_viewdirs=True, gen_depth_feats=wdepth, dpt_dim=96).to(dtype)
+    sdf = fields.SDFNetwork(d_out=257, d_in=3, d_hidden=256, n_layers=8, skip_in=[4], multires=6, bias=0.5,
+                            scale=1.0, geometric_init=True, weight_norm=True).to(dtype)
+    var = fields.SingleVarianceNetwork(init_val=0.3).to(dtype)
+    col = fields.RenderingNetwork(d_feature=256, mode="idr", d_in=9, d_out=3, d_hidden=256, n_layers=4,
+                                  weight_norm=True, multires_view=4, squeeze_out=True).to(dtype)
+    vdn = None
+    if wdepth:
+        vdn = fields.RenderingNetwork(d_feature=256, mode="idr", d_in=9, d_out=96, d_hidden=256, n_layers=4,
+                                      weight_norm=True, multires_view=4, squeeze_out=True).to(dtype)
+        vdn.load_state_dict(tt(states["depth_network_fine"]))
+    nerf.load_state_dict(tt(states["nerf"]))
+    sdf.load_state_dict(tt(states["sdf_network_fine"]))
+    var.load_state_dict(tt(states["variance_network_fine"]))
+    col.load_state_dict(tt(states["color_network_fine"]))
+    rend = renderer.NeuSRenderer(nerf, sdf, var, col, vdn, n_samples=64, n_importance=n_importance,
+                                 n_outside=n_outside, up_sample_steps=4, perturb=1.0)
+    return rend
+
+
+class RandQueue:
+    """Context manager: torch.rand(shape) pops the next injected tensor (renderer.py:348,355)."""
+
+    def __init__(self, tensors):
+        self.q = list(tensors)
+
+    def __enter__(self):
+        self.orig = torch.rand
+
+        def fake(shape, *a, **k):
+            t = self.q.pop(0)
+            assert list(t.shape) == list(shape), (t.shape, shape)
+            return t
+        torch.rand = fake
+        return self
+
+    def __exit__(self, *a):
+        torch.rand = self.orig
+
+
+def make_rays(seed, B, center_crop=520):
+    from vdn_train import synth
+    cams = synth.make_cameras(seed)
+    px = np.floor(synth.uniform(seed, "gold/x", (B,)) * center_crop) + (synth.W_IMG - center_crop) // 2
+    py = np.floor(synth.uniform(seed, "gold/y", (B,)) * center_crop) + (synth.H - center_crop) // 2
+    o, d = synth.pixel_rays(cams[seed % len(cams)], px, py)
+    near, far = synth.near_far_from_sphere(o, d)
+    return o, d, near, far
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def run_case(fields, renderer, name, seed, B, wdepth, variance, cos_anneal, perturb, dtype=torch.float32,
+             n_importance=64, with_grads=True, white=True, depth_before_color=False):
+    from vdn_train import synth
+    import oracle.neus_oracle as orc
+    torch.set_default_dtype(dtype)
+    states = synth.make_all_states(seed, wdepth=wdepth, variance=variance)
+    rend = build_reference(fields, renderer, states, wdepth, dtype, n_importance=n_importance)
+    o, d, near, far = make_rays(seed, B)
+    t_rand, t_rand_out = synth.jitter(seed, 0, B)
+    tt = lambda x: torch.tensor(x, dtype=dtype)
+    bg_rgb = torch.ones(1, 3, dtype=dtype) if white else None
+    q = [tt(t_rand), tt(t_rand_out)] if perturb > 0 else []
+    captured = {}
+    orig_core = rend.render_core
+
+    def spy_core(rays_o_, rays_d_, z_vals_, *a, **k):      # records the reference's own inside z_vals
+        captured["z"] = z_vals_.detach().clone()
+        return orig_core(rays_o_, rays_d_, z_vals_, *a, **k)
+    rend.render_core = spy_core
+    with RandQueue(q):
+        out = rend.render(tt(o), tt(d), tt(near), tt(far), perturb_overwrite=(-1 if perturb > 0 else 0),
+                          background_rgb=bg_rgb, cos_anneal_ratio=cos_anneal,
+                          depth_before_color=depth_before_color)
+    true_rgb = tt(synth.target_colors(o, d))
+    gt_feats = tt(synth.uniform(seed, "gold/feats", (B, 96)).astype(np.float32)) if wdepth else None
+    # loss exactly as dpt_runner.py:208-243 (use_mask False, mask_weight 0, igr 0.1, depth ramp 0.7)
+    mask = torch.ones(B, 1, dtype=dtype)
+    mask_sum = mask.sum() + 1e-5
+    color_err = (out["color_fine"] - true_rgb) * mask
+    loss = torch.nn.functional.l1_loss(color_err, torch.zeros_like(color_err), reduction="sum") / mask_sum
+    loss = loss + out["gradient_error"] * 0.1
+    if wdepth:
+        derr = (out["render_feats"] - gt_feats) * mask
+        loss = loss + torch.nn.functional.l1_loss(derr, torch.zeros_like(derr), reduction="sum") / mask_sum * 0.7
+    psnr = 20.0 * torch.log10(1.0 / (((out["color_fine"] - true_rgb) ** 2 * mask).sum() / (mask_sum * 3.0)).sqrt())
+    fx = {
+        "seed": seed, "B": B, "wdepth": wdepth, "variance": variance, "cos_anneal": cos_anneal,
+        "perturb": perturb, "n_importance": n_importance, "white": white,
+        "rays_o": o, "rays_d": d, "near": near, "far": far, "t_rand": t_rand, "t_rand_out": t_rand_out,
+        "true_rgb": true_rgb.numpy(), "loss": loss.item(), "psnr": psnr.item(),
+    }
+    if wdepth:
+        fx["gt_feats"] = gt_feats.numpy()
+    for k, v in out.items():
+        if v is not None:
+            fx["out_" + k] = v.detach().numpy()
+    if with_grads:
+        mods = [("nerf", rend.nerf), ("sdf", rend.sdf_network), ("variance", rend.deviation_network),
+                ("color", rend.color_network)] + ([("vdn", rend.depth_network)] if wdepth else [])
+        params = [(mn + "." + pn if mn != "variance" else "variance", p) for mn, m in mods for pn, p in m.named_parameters()]
+        grads = torch.autograd.grad(loss, [p for _, p in params], allow_unused=True)
+        for (n, p), g in zip(params, grads):
+            g = torch.zeros_like(p) if g is None else g
+            gf = g.detach().reshape(-1)
+            fx["grad_norm/" + n] = float(gf.norm())
+            fx["grad_sum/" + n] = float(gf.sum())
+            idx = np.unique(np.linspace(0, gf.numel() - 1, 16).astype(np.int64))
+            fx["grad_idx/" + n] = idx
+            fx["grad_val/" + n] = gf[idx].numpy()
+    # ---- oracle cross-check
+    nets = orc.nets_from_numpy(states, dtype=dtype, requires_grad=with_grads)
+    conf = orc.RendererConf(n_importance=n_importance)
+    rec = {}
+    oo = orc.render(nets, tt(o), tt(d), tt(near), tt(far), conf, perturb_overwrite=(-1 if perturb > 0 else 0),
+                    background_rgb=bg_rgb, cos_anneal_ratio=cos_anneal, depth_before_color=depth_before_color,
+                    t_rand=tt(t_rand), t_rand_out=tt(t_rand_out), record=rec)
+    errs = {k: rel(oo[k].detach().numpy(), out[k].detach().numpy()) for k in out if out[k] is not None}
+    fx["z_vals_inside"] = captured["z"].numpy()          # the REFERENCE's inside z (input of render_core)
+    errs["z_inside"] = rel(rec["z_vals_inside"].numpy(), fx["z_vals_inside"])
+    oi = orc.render(nets, tt(o), tt(d), tt(near), tt(far), conf, perturb_overwrite=(-1 if perturb > 0 else 0),
+                    background_rgb=bg_rgb, cos_anneal_ratio=cos_anneal, depth_before_color=depth_before_color,
+                    t_rand=tt(t_rand), t_rand_out=tt(t_rand_out), z_vals_inject=captured["z"])
+    for k in ("weights", "cdf_fine", "gradients", "color_fine"):
+        errs["inj_" + k] = rel(oi[k].detach().numpy(), out[k].detach().numpy())
+    if "coarse_sdf" in rec:
+        fx["coarse_sdf"] = rec["coarse_sdf"].numpy()
+        for i in range(4):
+            fx["z_round%d" % i] = rec["z_round%d" % i].numpy()
+    if with_grads:
+        # gradients are compared with the reference's own z injected: the sampler is a no-grad,
+        # ill-conditioned stage and would otherwise dominate the difference
+        lo = orc.loss_from_render(oi, true_rgb, gt_feats=gt_feats, depth_ramp=0.7 if wdepth else None)
+        errs["loss"] = abs(lo["loss"].item() - loss.item()) / abs(loss.item())
+        named = orc.all_params(nets)
+        og = torch.autograd.grad(lo["loss"], [p for _, p in named], allow_unused=True)
+        worst = 0.0
+        for (n, p), g in zip(named, og):
+            g = torch.zeros_like(p) if g is None else g
+            gf = g.detach().reshape(-1)
+            ref_n = fx["grad_norm/" + n]
+            e = float(np.abs(gf[fx["grad_idx/" + n]].numpy() - fx["grad_val/" + n]).max() / (np.abs(fx["grad_val/" + n]).max() + 1e-30))
+            en = abs(float(gf.norm()) - ref_n) / (ref_n + 1e-30)
+            worst = max(worst, e if ref_n > 0 else 0.0, en if ref_n > 0 else 0.0)
+        errs["param_grads(worst)"] = worst
+    print("[%s] oracle vs reference:" % name, {k: "%.2e" % v for k, v in errs.items()})
+    torch.set_default_dtype(torch.float32)
+    return fx, errs
+
+
+def stage_fixture(fields, renderer, embedder, seed=3):
+    """Per-stage known-answer vectors from the reference modules (fp32)."""
+    from vdn_train import synth
+    import oracle.neus_oracle as orc
+    torch.set_default_dtype(torch.float32)
+    states = synth.make_all_states(seed, wdepth=True, variance=0.3)
+    rend = build_reference(fields, renderer, states, True, torch.float32)
+    P = 96
+    pts = torch.tensor(((synth.uniform(seed, "st/pts", (P, 3)) * 2 - 1) * 0.9).astype(np.float32))
+    dirs = synth.normal(seed, "st/dirs", (P, 3))
+    dirs = torch.tensor((dirs / np.linalg.norm(dirs, axis=-1, keepdims=True)).astype(np.float32))
+    fx = {"seed": seed, "pts": pts.numpy(), "dirs": dirs.numpy()}
+    for (L, dd) in ((6, 3), (10, 4), (4, 3)):
+        fn, od = embedder.get_embedder(L, input_dims=dd)
+        x = pts if dd == 3 else torch.cat([pts, pts[:, :1] * 0.5], -1)
+        fx["pe_%d_%d" % (L, dd)] = fn(x).numpy()
+    out = rend.sdf_network(pts)
+    fx["sdf_out"] = out.detach().numpy()
+    g = rend.sdf_network.gradient(pts.clone()).squeeze(1)
+    fx["sdf_grad"] = g.detach().numpy()
+    feat = out[:, 1:].detach()
+    fx["color"] = rend.color_network(pts, g.detach(), dirs, feat).detach().numpy()
+    fx["vdn"] = rend.depth_network(pts, g.detach(), dirs, feat).detach().numpy()
+    pts4 = torch.cat([pts, torch.tensor(synth.uniform(seed, "st/w", (P, 1)).astype(np.float32))], -1)
+    a, rgb, ft = rend.nerf(pts4, dirs)
+    fx["pts4"] = pts4.numpy()
+    fx["nerf_alpha"], fx["nerf_rgb"], fx["nerf_feat"] = a.detach().numpy(), rgb.detach().numpy(), ft.detach().numpy()
+    # sample_pdf known-answer
+    B, M = 8, 80
+    bins = np.sort(synth.uniform(seed, "st/bins", (B, M)) * 2 + 1, -1).astype(np.float32)
+    w = (synth.uniform(seed, "st/w2", (B, M - 1)) ** 8).astype(np.float32)
+    w[0, :] = 0.0                      # flat-CDF row: exercises the denom<1e-5 branch (renderer.py:70)
+    w[1, 10:] = 0.0
+    fx["spdf_bins"], fx["spdf_w"] = bins, w
+    fx["spdf_out"] = renderer.sample_pdf(torch.tensor(bins), torch.tensor(w), 16, det=True).numpy()
+    # SDF lattice (renderer.py:10-30) at resolution 20 (non multiple of 64 -> single ragged block)
+    u = renderer.extract_fields(torch.tensor([-0.8, -0.7, -0.6]), torch.tensor([0.7, 0.8, 0.9]), 20,
+                                lambda p: -rend.sdf_network.sdf(p))
+    fx["lattice"] = u
+    # oracle check
+    nets = orc.nets_from_numpy(states)
+    oo, og = orc.sdf_forward(nets.sdf, pts, nets.sdf_conf, with_gradient=True)
+    e = {"sdf_out": rel(oo.numpy(), fx["sdf_out"]), "sdf_grad": rel(og.numpy(), fx["sdf_grad"]),
+         "color": rel(orc.rendering_forward(nets.color, pts, g.detach(), dirs, feat, nets.color_conf).numpy(), fx["color"]),
+         "vdn": rel(orc.rendering_forward(nets.vdn, pts, g.detach(), dirs, feat, nets.vdn_conf).numpy(), fx["vdn"]),
+         "spdf": rel(orc.sample_pdf_det(torch.tensor(bins), torch.tensor(w), 16).numpy(), fx["spdf_out"]),
+         "lattice": rel(orc.extract_fields(nets, [-0.8, -0.7, -0.6], [0.7, 0.8, 0.9], 20).numpy(), u)}
+    na, nr, nf = orc.nerf_forward(nets.nerf, pts4, dirs, nets.nerf_conf)
+    e["nerf"] = max(rel(na.numpy(), fx["nerf_alpha"]), rel(nr.numpy(), fx["nerf_rgb"]), rel(nf.numpy(), fx["nerf_feat"]))
+    print("[stages] oracle vs reference:", {k: "%.2e" % v for k, v in e.items()})
+    return fx, e
+
+
+def adam_fixture(fields, renderer, seed=5, B=12, steps=3):
+    """Params after 3 Adam steps of the a-R loop (dpt_runner.py:228-257, 310-319), fp32."""
+    from vdn_train import synth
+    torch.set_default_dtype(torch.float32)
+    states = synth.make_all_states(seed, wdepth=False, variance=0.3)
+    rend = build_reference(fields, renderer, states, False, torch.float32)
+    mods = [rend.nerf, rend.sdf_network, rend.deviation_network, rend.color_network]
+    params = [p for m in mods for p in m.parameters()]
+    opt = torch.optim.Adam(params, lr=5e-4)
+    o, d, near, far = make_rays(seed, B)
+    tt = torch.tensor
+    true_rgb = tt(synth.target_colors(o, d))
+    fx = {"seed": seed, "B": B, "steps": steps, "rays_o": o, "rays_d": d, "near": near, "far": far,
+          "true_rgb": true_rgb.numpy()}
+    losses = []
+    for it in range(steps):
+        lr_factor = (it + 100) / 5000.0            # warm-up branch of dpt_runner.py:311-312 at iter_step = it+100
+        for gq in opt.param_groups:
+            gq["lr"] = 5e-4 * lr_factor
+        t1, t2 = synth.jitter(seed, it, B)
+        with RandQueue([tt(t1), tt(t2)]):
+            out = rend.render(tt(o), tt(d), tt(near), tt(far), background_rgb=torch.ones(1, 3),
+                              cos_anneal_ratio=min(1.0, (it + 100) / 50000.0))
+        mask_sum = B + 1e-5
+        loss = (out["color_fine"] - true_rgb).abs().sum() / mask_sum + out["gradient_error"] * 0.1
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    fx["losses"] = np.asarray(losses)
+    names = ["nerf", "sdf", "variance", "color"]
+    for mn, m in zip(names, mods):
+        for pn, p in m.named_parameters():
+            key = mn + "." + pn if mn != "variance" else "variance"
+            pf = p.detach().reshape(-1)
+            idx = np.unique(np.linspace(0, pf.numel() - 1, 8).astype(np.int64))
+            fx["p_idx/" + key] = idx
+            fx["p_val/" + key] = pf[idx].numpy()
+            fx["p_norm/" + key] = float(pf.norm())
+    print("[adam] reference losses:", losses)
+    return fx
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check-only", action="store_true")
+    args = ap.parse_args()
+    fields, renderer, embedder = import_reference()
+    torch.manual_seed(0)
+    out = {}
+    out["stages"], _ = stage_fixture(fields, renderer, embedder)
+    cases = [
+        # name, seed, B, wdepth, variance, cos_anneal, perturb, kwargs
+        ("white_v03_c0", 1, 24, False, 0.3, 0.0, 1.0, {}),
+        ("white_v03_c05_det", 2, 24, False, 0.3, 0.5, 0.0, {}),
+        ("white_v065_c1", 4, 24, False, 0.65, 1.0, 1.0, {}),
+        ("wdepth_v03_c05", 6, 16, True, 0.3, 0.5, 1.0, {}),
+        ("wdepth_v065_c1", 7, 16, True, 0.65, 1.0, 1.0, {}),
+        ("white_n64_v03", 8, 24, False, 0.3, 0.3, 1.0, {"n_importance": 0}),
+        ("black_v03", 9, 16, False, 0.3, 1.0, 1.0, {"white": False, "with_grads": False}),
+    ]
+    for (name, seed, B, wd, var, ca, pt, kw) in cases:
+        out[name], _ = run_case(fields, renderer, name, seed, B, wd, var, ca, pt, **kw)
+        if name in ("white_v03_c0", "white_v065_c1", "wdepth_v065_c1"):
+            # fp64 companion: calibrates tolerances (SURVEY.md 4 noise floor)
+            fx64, _ = run_case(fields, renderer, name + "_f64", seed, B, wd, var, ca, pt, dtype=torch.float64, **kw)
+            keep = {k: v for k, v in fx64.items() if k.startswith("out_") or k.startswith("grad_") or
+                    k in ("loss", "psnr", "z_vals_inside")}
+            out[name + "_f64"] = keep
+    out["adam3"] = adam_fixture(fields, renderer)
+    if not args.check_only:
+        for name, fx in out.items():
+            path = os.path.join(HERE, name + ".npz")
+            np.savez_compressed(path, **{k.replace("/", "__"): np.asarray(v) for k, v in fx.items()})
+            print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__":
+    main()
