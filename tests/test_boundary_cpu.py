@@ -1,0 +1,104 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol the
+header declares, the module API / state_dict schema matches the reference, and the
+product path refuses to run without the GPU (no silent fallback)."""
+import ctypes
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from vdn_hip import images, lib
+from vdn_train import synth, factory
+
+
+def test_library_exports_every_declared_symbol():
+    l = lib.load()
+    text = open(lib.HEADER).read()
+    declared = re.findall(r"\bint\s+(vdn_\w+)\s*\(", text)
+    assert len(declared) >= 10
+    for name in declared:
+        assert hasattr(l, name), name
+    assert l.vdn_abi_version() == 1
+
+
+def test_struct_layouts_are_c_layouts():
+    assert ctypes.sizeof(lib.VdnChunkDesc) == 72 and lib.struct_dtype("VdnChunkDesc").itemsize == 72
+    assert ctypes.sizeof(lib.VdnWeightNormDesc) == 40
+
+
+def test_argument_errors_are_reported_not_ignored():
+    a = lib.VdnSdfArgs()
+    with pytest.raises(lib.VdnError):
+        lib.call("vdn_sdf_mlp_fwd_f32", 0, a, None)       # P == 0 / null blob -> status < 0, never reaches the GPU
+    with pytest.raises(lib.VdnError):
+        lib.call("vdn_merge_sorted", lib.VdnMergeArgs(), None)
+
+
+def test_state_dict_schema_and_param_counts():
+    rend = factory.build_renderer(wdepth=True, device="cpu")
+    sd = rend.sdf_network.state_dict()
+    assert list(sd)[:3] == ["lin0.bias", "lin0.weight_g", "lin0.weight_v"]
+    assert sd["lin3.weight_v"].shape == (217, 256) and sd["lin4.weight_v"].shape == (256, 256)
+    assert sd["lin8.weight_g"].shape == (257, 1) and sd["lin0.weight_v"].shape == (256, 39)
+    count = lambda m: sum(p.numel() for p in m.parameters())
+    assert count(rend.sdf_network) == 529076 and count(rend.color_network) == 273414
+    assert count(rend.depth_network) == 297408 and count(rend.nerf) == 618980
+    assert list(rend.deviation_network.state_dict()) == ["variance"]
+    nk = list(rend.nerf.state_dict())
+    assert nk[:2] == ["pts_linears.0.weight", "pts_linears.0.bias"] and "dpt_linear.weight" in nk
+    assert rend.nerf.state_dict()["pts_linears.5.weight"].shape == (256, 340)
+    total = sum(count(m) for m in (rend.nerf, rend.sdf_network, rend.deviation_network, rend.color_network))
+    assert total - 12384 == 1409087          # SURVEY.md 8e all-reduce payload (womsk_white has no dpt head)
+
+
+def test_synth_states_load_into_modules_and_roundtrip():
+    st = synth.make_all_states(0, wdepth=True)
+    rend = factory.build_renderer(wdepth=True, device="cpu", states=st)
+    for k, v in st["sdf_network_fine"].items():
+        assert np.array_equal(rend.sdf_network.state_dict()[k].numpy(), v)
+    rend.nerf.load_state_dict({k: torch.as_tensor(v) for k, v in synth.make_nerf_state(0).items()}, strict=False)
+
+
+def test_geometric_init_matches_reference_statistics():
+    torch.manual_seed(0)
+    from dpt_models.fields import SDFNetwork
+    net = SDFNetwork(**factory.CONF["sdf_network"])
+    sd = net.state_dict()
+    assert torch.all(sd["lin8.bias"] == -0.5) and torch.all(sd["lin0.weight_v"][:, 3:] == 0)
+    assert abs(sd["lin8.weight_v"].mean().item() - np.sqrt(np.pi) / 16) < 1e-4
+    assert torch.all(sd["lin4.weight_v"][:, -36:] == 0)
+    assert torch.allclose(sd["lin2.weight_g"][:, 0], sd["lin2.weight_v"].norm(dim=1))
+
+
+def test_no_cpu_fallback():
+    rend = factory.build_renderer(wdepth=False, device="cpu")
+    with pytest.raises(RuntimeError):
+        rend.sdf_network.sdf(torch.zeros(4, 3))
+    with pytest.raises(RuntimeError):
+        rend.render(torch.zeros(2, 3), torch.zeros(2, 3), torch.zeros(2, 1), torch.ones(2, 1))
+
+
+def test_unsupported_shapes_raise():
+    from dpt_models.fields import SDFNetwork, RenderingNetwork
+    with pytest.raises(ValueError):
+        images.sdf_streams(3, 257, 128, 8, (4,), 6)
+    with pytest.raises(ValueError):
+        images.rendering_streams(256, "no_view_dir", 9, 3, 256, 4, 4)
+    with pytest.raises(ValueError):
+        factory.build_renderer(device="cpu", n_importance=62)
+
+
+def test_stream_plans_are_consistent():
+    """Chunk streams: every layer's contraction width matches the previous layer's padded output."""
+    s = images.sdf_streams(3, 257, 256, 8, (4,), 6)
+    assert [L.kt for L in s["sdf"]] == [2, 8, 8, 8, 9, 8, 8, 8, 8]
+    assert [len(L.chunks) for L in s["sdf"]] == [8, 8, 8, 7, 8, 8, 8, 8, 1]
+    full = s["full"]
+    assert [len(L.chunks) for L in full[9:]] == [8, 8, 8, 9, 8, 8, 8, 2]      # sweep: W7^T .. W0^T
+    assert [L.kt for L in full[9:]] == [8, 8, 8, 8, 7, 8, 8, 8]
+    n = images.nerf_streams(8, 256, 4, 3, 10, 4, (4,), 3, True, 96)["fwd"]
+    assert [L.kt for L in n] == [3, 8, 8, 8, 8, 11, 8, 8, 8, 9, 4]
+    assert [len(L.chunks) for L in n] == [8, 8, 8, 8, 8, 8, 8, 8, 9, 4, 4]
+    r = images.rendering_streams(256, "idr", 9, 96, 256, 4, 4)["fwd"]
+    assert [L.kt for L in r] == [10, 8, 8, 8, 8] and len(r[-1].chunks) == 3

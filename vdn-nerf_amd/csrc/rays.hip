@@ -1,0 +1,456 @@
+// Per-ray kernels of the NeuS renderer on gfx950: one 64-lane wavefront per ray, wave-level scans
+// (shuffle based) for the exclusive transmittance product and the CDF, LDS only as a per-wave
+// scratch line. Replaces the elementwise / cumprod / cumsum / searchsorted / sort / gather op chains of
+// reference dpt_models/renderer.py: render 334-359 (coarse + outside z), up_sample 147-191 with
+// sample_pdf 44-74, cat_z_vals 193-207, the section set-up of render_core 228-230 /
+// render_core_outside 107-109, and render_core's alpha + compositing 262-315.
+//
+// Numerics follow the reference's CPU path: ATen's CPU cumprod / cumsum accumulate float32 inputs in
+// double and round every prefix to float, so the scans here run in double too. Built with
+// -ffp-contract=off so that mul/add pairs round like the reference's separate aten ops.
+#include "vdn_common.h"
+#include "vdn_kernels.h"
+
+namespace vdn {
+
+constexpr int kRayWaves = 4;      // rays per workgroup
+constexpr int kMaxT = 256;        // max samples per ray handled (4 per lane)
+constexpr int kEPL = 4;
+
+VDN_DEV double wave_incl_scan_mul(double v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double t = __shfl_up(v, off);
+        if (lane >= off) v *= t;
+    }
+    return v;
+}
+VDN_DEV double wave_incl_scan_add(double v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double t = __shfl_up(v, off);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+VDN_DEV double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+VDN_DEV float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+// exclusive product scan over a ray: in f[e] (lane owns elements kEPL*lane+e), out T[e] = prod_{k<i} f_k
+// rounded to float per element (what alpha * cumprod([1, f...])[:-1] multiplies with).
+VDN_DEV void ray_excl_cumprod(const float (&f)[kEPL], float (&T)[kEPL], int lane) {
+    double loc = 1.0;
+#pragma unroll
+    for (int e = 0; e < kEPL; ++e) loc *= (double)f[e];
+    const double incl = wave_incl_scan_mul(loc, lane);
+    double run = __shfl_up(incl, 1);
+    if (lane == 0) run = 1.0;
+#pragma unroll
+    for (int e = 0; e < kEPL; ++e) {
+        T[e] = (float)run;
+        run *= (double)f[e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// coarse z + outside z  (renderer.py:334-359)
+// ------------------------------------------------------------------------------------------
+__global__ void coarse_z_kernel(CoarseArgs a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = a.n_samples + a.n_outside;
+    if (idx >= a.B * per) return;
+    const int r = idx / per, j = idx % per;
+    const float nearv = a.near[r], farv = a.far[r];
+    if (j < a.n_samples) {
+        float z = nearv + (farv - nearv) * a.lin_samples[j];
+        if (a.t_rand != nullptr) z = z + (a.t_rand[r] - 0.5f) * 2.0f / (float)a.n_samples;
+        a.z[(long)r * a.z_ld + j] = z;
+    } else {
+        // z_out[k] = far / flip(zo)[k] + 1/n_samples, zo = lower + (upper-lower)*t (stratified) or the linspace itself
+        const int k = j - a.n_samples;
+        const int kk = a.n_outside - 1 - k;
+        float zo;
+        if (a.t_rand_out != nullptr)
+            zo = a.out_lower[kk] + (a.out_upper[kk] - a.out_lower[kk]) * a.t_rand_out[(long)r * a.n_outside + kk];
+        else
+            zo = a.lin_outside[kk];
+        a.z_out[(long)r * a.n_outside + k] = farv / zo + 1.0f / (float)a.n_samples;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// one up-sampling round: z[M], sdf[M] -> n_imp new z per ray  (renderer.py:147-191, 44-74)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kRayWaves * 64) void upsample_kernel(UpsampleArgs a) {
+    __shared__ float s_z[kRayWaves][kMaxT], s_sdf[kRayWaves][kMaxT], s_cdf[kRayWaves][kMaxT];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * kRayWaves + wave;
+    if (r >= a.B) return;            // whole wave exits together; no block-level barrier is used
+    const int M = a.M;
+    float* z = s_z[wave];
+    float* sd = s_sdf[wave];
+    float* cdf = s_cdf[wave];
+    for (int i = lane; i < M; i += 64) {
+        z[i] = a.z[(long)r * a.ld + i];
+        sd[i] = a.sdf[(long)r * a.ld + i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    float o[3], d[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        o[k] = a.rays_o[r * 3 + k];
+        d[k] = a.rays_d[r * 3 + k];
+    }
+    auto radius = [&](float zz) {
+        const float x = o[0] + d[0] * zz, y = o[1] + d[1] * zz, w = o[2] + d[2] * zz;
+        return sqrtf(x * x + y * y + w * w);
+    };
+    float alpha[kEPL], f[kEPL], T[kEPL];
+#pragma unroll
+    for (int e = 0; e < kEPL; ++e) {
+        const int i = kEPL * lane + e;
+        alpha[e] = 0.0f;
+        f[e] = 1.0f;
+        if (i < M - 1) {
+            const float z0 = z[i], z1 = z[i + 1], s0 = sd[i], s1 = sd[i + 1];
+            const bool inside = (radius(z0) < 1.0f) | (radius(z1) < 1.0f);
+            const float mid_sdf = (s0 + s1) * 0.5f;
+            float cosv = (s1 - s0) / (z1 - z0 + 1e-5f);
+            const float prev_cos = (i == 0) ? 0.0f : (s0 - sd[i - 1]) / (z0 - z[i - 1] + 1e-5f);
+            cosv = fminf(prev_cos, cosv);
+            cosv = fminf(fmaxf(cosv, -1e3f), 0.0f) * (inside ? 1.0f : 0.0f);
+            const float dist = z1 - z0;
+            const float prev_esti = mid_sdf - cosv * dist * 0.5f;
+            const float next_esti = mid_sdf + cosv * dist * 0.5f;
+            const float prev_cdf = sigmoidf_(prev_esti * a.inv_s);
+            const float next_cdf = sigmoidf_(next_esti * a.inv_s);
+            alpha[e] = (prev_cdf - next_cdf + 1e-5f) / (prev_cdf + 1e-5f);
+            f[e] = 1.0f - alpha[e] + 1e-7f;
+        }
+    }
+    ray_excl_cumprod(f, T, lane);
+    // sample_pdf (det=True)
+    float w[kEPL];
+    double wsum = 0.0;
+#pragma unroll
+    for (int e = 0; e < kEPL; ++e) {
+        const int i = kEPL * lane + e;
+        w[e] = (i < M - 1) ? (alpha[e] * T[e] + 1e-5f) : 0.0f;
+        wsum += (double)w[e];
+    }
+    const float tot = (float)wave_sum(wsum);
+    double loc = 0.0;
+    float pdf[kEPL];
+#pragma unroll
+    for (int e = 0; e < kEPL; ++e) {
+        const int i = kEPL * lane + e;
+        pdf[e] = (i < M - 1) ? w[e] / tot : 0.0f;
+        loc += (double)pdf[e];
+    }
+    const double incl = wave_incl_scan_add(loc, lane);
+    double run = __shfl_up(incl, 1);
+    if (lane == 0) run = 0.0;
+    if (lane == 0) cdf[0] = 0.0f;
+#pragma unroll
+    for (int e = 0; e < kEPL; ++e) {
+        const int i = kEPL * lane + e;
+        run += (double)pdf[e];
+        if (i < M - 1) cdf[i + 1] = (float)run;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < a.n_imp) {
+        const float u = a.u[lane];
+        int lo = 0, hi = M;                       // searchsorted(cdf, u, right=True): first idx with cdf[idx] > u
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+        }
+        const int below = max(lo - 1, 0), above = min(lo, M - 1);
+        float denom = cdf[above] - cdf[below];
+        denom = denom < 1e-5f ? 1.0f : denom;
+        const float t = (u - cdf[below]) / denom;
+        a.new_z[(long)r * a.n_imp + lane] = z[below] + t * (z[above] - z[below]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// merge the new samples into the sorted ray (cat + sort + permuted sdf, renderer.py:197-205)
+// also used for z_feed = sort(cat(z_vals, z_vals_outside)) (renderer.py:390-391), sdf pointers NULL
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kRayWaves * 64) void merge_kernel(MergeArgs a) {
+    __shared__ float s_a[kRayWaves][kMaxT], s_b[kRayWaves][kMaxT];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * kRayWaves + wave;
+    if (r >= a.B) return;
+    const int M = a.M, K = a.K;
+    float* za = s_a[wave];
+    float* zb = s_b[wave];
+    for (int i = lane; i < M; i += 64) za[i] = a.z[(long)r * a.ld + i];
+    for (int j = lane; j < K; j += 64) zb[j] = a.new_z[(long)r * a.K + j];
+    __builtin_amdgcn_wave_barrier();
+    const bool has_sdf = a.sdf != nullptr;
+    // stable ranks: old elements precede equal new ones (position in the concatenation decides ties)
+    float oz[kEPL], os[kEPL];
+    int opos[kEPL];
+#pragma unroll
+    for (int e = 0; e < kEPL; ++e) {
+        const int i = lane + 64 * e;
+        opos[e] = -1;
+        if (i < M) {
+            const float v = za[i];
+            int cnt = 0;
+            for (int k = 0; k < M; ++k) cnt += (za[k] < v) | ((za[k] == v) & (k < i));
+            for (int j = 0; j < K; ++j) cnt += zb[j] < v;
+            opos[e] = cnt;
+            oz[e] = v;
+            os[e] = has_sdf ? a.sdf[(long)r * a.ld + i] : 0.0f;
+        }
+    }
+    float nz = 0.0f, ns = 0.0f;
+    int npos = -1;
+    if (lane < K) {
+        const float v = zb[lane];
+        int cnt = 0;
+        for (int k = 0; k < M; ++k) cnt += za[k] <= v;
+        for (int j = 0; j < K; ++j) cnt += (zb[j] < v) | ((zb[j] == v) & (j < lane));
+        npos = cnt;
+        nz = v;
+        ns = has_sdf ? a.new_sdf[(long)r * a.K + lane] : 0.0f;
+    }
+    __builtin_amdgcn_wave_barrier();   // all reads of the old row are done before it is overwritten in place
+#pragma unroll
+    for (int e = 0; e < kEPL; ++e) {
+        if (opos[e] >= 0) {
+            a.z_out[(long)r * a.ld_out + opos[e]] = oz[e];
+            if (has_sdf) a.sdf_out[(long)r * a.ld_out + opos[e]] = os[e];
+        }
+    }
+    if (npos >= 0) {
+        a.z_out[(long)r * a.ld_out + npos] = nz;
+        if (has_sdf) a.sdf_out[(long)r * a.ld_out + npos] = ns;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// section lengths and mid-points (renderer.py:228-230 and 107-109): dists, mid_z for a sorted row
+// ------------------------------------------------------------------------------------------
+__global__ void sections_kernel(SectionArgs a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.B * a.n) return;
+    const int r = idx / a.n, i = idx % a.n;
+    const float z0 = a.z[(long)r * a.ld + i];
+    const float dist = (i + 1 < a.n) ? a.z[(long)r * a.ld + i + 1] - z0 : a.sample_dist;
+    a.dists[(long)r * a.n + i] = dist;
+    a.mid_z[(long)r * a.n + i] = z0 + dist * 0.5f;
+}
+
+// ------------------------------------------------------------------------------------------
+// NeuS alpha from (sdf, normal), inside/outside blend with the background pass, transmittance
+// scan and weighted sums (renderer.py:262-315). One wave per ray, T = N + n_outside <= 256.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kRayWaves * 64) void composite_kernel(CompositeArgs a) {
+    __shared__ float s_w[kRayWaves][kMaxT], s_in[kRayWaves][kMaxT];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * kRayWaves + wave;
+    if (r >= a.B) return;
+    const int N = a.N, T = a.T;
+    const bool has_bg = a.bg_density != nullptr;
+    float o[3], d[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        o[k] = a.rays_o[r * 3 + k];
+        d[k] = a.rays_d[r * 3 + k];
+    }
+    float inv_s = expf(a.variance[0] * 10.0f);                     // fields.py:364
+    inv_s = fminf(fmaxf(inv_s, 1e-6f), 1e6f);                      // renderer.py:262
+    const float car = a.cos_anneal_ratio;
+
+    float alpha[kEPL], f[kEPL], Tr[kEPL], wgt[kEPL], col[kEPL][3], ins[kEPL];
+    double eik_num = 0.0, eik_den = 0.0;
+#pragma unroll
+    for (int e = 0; e < kEPL; ++e) {
+        const int i = kEPL * lane + e;
+        alpha[e] = 0.0f;
+        f[e] = 1.0f;
+        ins[e] = 0.0f;
+        col[e][0] = col[e][1] = col[e][2] = 0.0f;
+        if (i < T) {
+            float bg_a = 0.0f;
+            if (has_bg) {
+                const long q = (long)r * T + i;
+                bg_a = 1.0f - expf(-softplus1(a.bg_density[q]) * a.bg_dists[q]);   // renderer.py:124
+            }
+            if (i < N) {
+                const long q = (long)r * N + i;
+                const float sdf = a.sdf[q], dist = a.dists[q];
+                const float g0 = a.normals[q * 3], g1 = a.normals[q * 3 + 1], g2 = a.normals[q * 3 + 2];
+                const float true_cos = d[0] * g0 + d[1] * g1 + d[2] * g2;
+                const float iter_cos = -(fmaxf(-true_cos * 0.5f + 0.5f, 0.0f) * (1.0f - car) + fmaxf(-true_cos, 0.0f) * car);
+                const float est_next = sdf + iter_cos * dist * 0.5f;
+                const float est_prev = sdf - iter_cos * dist * 0.5f;
+                const float prev_cdf = sigmoidf_(est_prev * inv_s);
+                const float next_cdf = sigmoidf_(est_next * inv_s);
+                float al = ((prev_cdf - next_cdf) + 1e-5f) / (prev_cdf + 1e-5f);
+                al = fminf(fmaxf(al, 0.0f), 1.0f);
+                const float mz = a.mid_z[q];
+                const float x = o[0] + d[0] * mz, y = o[1] + d[1] * mz, w = o[2] + d[2] * mz;
+                const float pn = sqrtf(x * x + y * y + w * w);
+                const float inside = pn < 1.0f ? 1.0f : 0.0f;
+                const float relax = pn < 1.2f ? 1.0f : 0.0f;
+                const float gn = sqrtf(g0 * g0 + g1 * g1 + g2 * g2) - 1.0f;
+                eik_num += (double)(relax * (gn * gn));
+                eik_den += (double)relax;
+                a.cdf[q] = prev_cdf;
+                a.inside_sphere[q] = inside;
+                ins[e] = inside;
+                float c0 = a.color[q * 3], c1 = a.color[q * 3 + 1], c2 = a.color[q * 3 + 2];
+                if (has_bg) {
+                    const long qb = (long)r * T + i;
+                    al = al * inside + bg_a * (1.0f - inside);                     // renderer.py:290
+                    c0 = c0 * inside + a.bg_rgb[qb * 3] * (1.0f - inside);
+                    c1 = c1 * inside + a.bg_rgb[qb * 3 + 1] * (1.0f - inside);
+                    c2 = c2 * inside + a.bg_rgb[qb * 3 + 2] * (1.0f - inside);
+                }
+                alpha[e] = al;
+                col[e][0] = c0; col[e][1] = c1; col[e][2] = c2;
+            } else {
+                const long qb = (long)r * T + i;
+                alpha[e] = bg_a;
+                col[e][0] = a.bg_rgb[qb * 3]; col[e][1] = a.bg_rgb[qb * 3 + 1]; col[e][2] = a.bg_rgb[qb * 3 + 2];
+            }
+            f[e] = 1.0f - alpha[e] + 1e-7f;
+        }
+    }
+    ray_excl_cumprod(f, Tr, lane);
+    double ws = 0.0, c0 = 0.0, c1 = 0.0, c2 = 0.0;
+    float wmax = 0.0f;
+#pragma unroll
+    for (int e = 0; e < kEPL; ++e) {
+        const int i = kEPL * lane + e;
+        wgt[e] = 0.0f;
+        if (i < T) {
+            wgt[e] = alpha[e] * Tr[e];
+            a.weights[(long)r * T + i] = wgt[e];
+            if (a.alpha_out != nullptr) a.alpha_out[(long)r * T + i] = alpha[e];
+            s_w[wave][i] = wgt[e];
+            s_in[wave][i] = ins[e];
+            ws += (double)wgt[e];
+            c0 += (double)(col[e][0] * wgt[e]);
+            c1 += (double)(col[e][1] * wgt[e]);
+            c2 += (double)(col[e][2] * wgt[e]);
+            wmax = fmaxf(wmax, wgt[e]);
+        }
+    }
+    const float wsum = (float)wave_sum(ws);
+    float cr = (float)wave_sum(c0), cg = (float)wave_sum(c1), cb = (float)wave_sum(c2);
+    wmax = wave_max(wmax);
+    eik_num = wave_sum(eik_num);
+    eik_den = wave_sum(eik_den);
+    if (a.background_rgb != nullptr) {                                              // renderer.py:309-310
+        cr = cr + a.background_rgb[0] * (1.0f - wsum);
+        cg = cg + a.background_rgb[1] * (1.0f - wsum);
+        cb = cb + a.background_rgb[2] * (1.0f - wsum);
+    }
+    if (lane == 0) {
+        a.color_out[r * 3] = cr; a.color_out[r * 3 + 1] = cg; a.color_out[r * 3 + 2] = cb;
+        a.weight_sum[r] = wsum;
+        a.weight_max[r] = wmax;
+        if (a.s_val != nullptr) a.s_val[r] = 1.0f / inv_s;
+        a.eik_partial[r * 2] = (float)eik_num;
+        a.eik_partial[r * 2 + 1] = (float)eik_den;
+    }
+    // 96-channel VDN features: lanes over channels, samples streamed (weights / inside from LDS)
+    if (a.feat_out != nullptr) {
+        __builtin_amdgcn_wave_barrier();
+        const int C = a.feat_ch;
+        for (int ch = lane; ch < C; ch += 64) {
+            double acc = 0.0;
+            for (int i = 0; i < T; ++i) {
+                float fv;
+                if (i < N) {
+                    fv = a.feat[((long)r * N + i) * C + ch];
+                    if (has_bg) {
+                        const float inside = s_in[wave][i];
+                        fv = fv * inside + a.bg_feat[((long)r * T + i) * C + ch] * (1.0f - inside);   // renderer.py:297-298
+                    }
+                } else {
+                    fv = a.bg_feat[((long)r * T + i) * C + ch];
+                }
+                acc += (double)(fv * s_w[wave][i]);
+            }
+            a.feat_out[(long)r * C + ch] = (float)acc;
+        }
+    }
+}
+
+// gradient_error = sum(num) / (sum(den) + 1e-5)  (renderer.py:313-315); also exports (num, den) for
+// the data-parallel all-reduce of the two scalars.
+__global__ void eikonal_reduce_kernel(const float* partial, int B, float* out3) {
+    double n = 0.0, dn = 0.0;
+    for (int i = threadIdx.x; i < B; i += 64) {
+        n += (double)partial[2 * i];
+        dn += (double)partial[2 * i + 1];
+    }
+    n = wave_sum(n);
+    dn = wave_sum(dn);
+    if (threadIdx.x == 0) {
+        out3[0] = (float)n / ((float)dn + 1e-5f);
+        out3[1] = (float)n;
+        out3[2] = (float)dn;
+    }
+}
+
+}  // namespace vdn
+
+using namespace vdn;
+
+extern "C" int vdn_coarse_z(const VdnCoarseArgs* a, void* stream) {
+    if (!a || a->B <= 0 || !a->near || !a->far || !a->z || !a->lin_samples) return -1;
+    if (a->n_outside > 0 && (!a->z_out || !a->lin_outside)) return -2;
+    if (a->t_rand_out && (!a->out_lower || !a->out_upper)) return -3;
+    const int n = a->B * (a->n_samples + a->n_outside);
+    hipLaunchKernelGGL(coarse_z_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int vdn_upsample_round(const VdnUpsampleArgs* a, void* stream) {
+    if (!a || a->B <= 0 || !a->z || !a->sdf || !a->new_z || !a->u || !a->rays_o || !a->rays_d) return -1;
+    if (a->M < 2 || a->M > kMaxT || a->n_imp < 1 || a->n_imp > 64 || a->ld < a->M) return -2;
+    hipLaunchKernelGGL(upsample_kernel, dim3((a->B + kRayWaves - 1) / kRayWaves), dim3(kRayWaves * 64), 0, (hipStream_t)stream, *a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int vdn_merge_sorted(const VdnMergeArgs* a, void* stream) {
+    if (!a || a->B <= 0 || !a->z || !a->new_z || !a->z_out) return -1;
+    if (a->M < 1 || a->K < 1 || a->K > 64 || a->M + a->K > kMaxT || a->ld < a->M || a->ld_out < a->M + a->K) return -2;
+    if (a->sdf && (!a->new_sdf || !a->sdf_out)) return -3;
+    hipLaunchKernelGGL(merge_kernel, dim3((a->B + kRayWaves - 1) / kRayWaves), dim3(kRayWaves * 64), 0, (hipStream_t)stream, *a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int vdn_sections(const VdnSectionArgs* a, void* stream) {
+    if (!a || a->B <= 0 || a->n <= 0 || !a->z || !a->dists || !a->mid_z || a->ld < a->n) return -1;
+    const int n = a->B * a->n;
+    hipLaunchKernelGGL(sections_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int vdn_alpha_composite_fwd(const VdnCompositeArgs* a, void* stream) {
+    if (!a || a->B <= 0 || a->N <= 0 || a->T < a->N || a->T > kMaxT) return -1;
+    if (!a->rays_o || !a->rays_d || !a->sdf || !a->normals || !a->dists || !a->mid_z || !a->color || !a->variance) return -2;
+    if (!a->weights || !a->cdf || !a->inside_sphere || !a->color_out || !a->weight_sum || !a->weight_max ||
+        !a->eik_partial || !a->eik_out) return -3;
+    if (a->T > a->N && (!a->bg_density || !a->bg_rgb || !a->bg_dists)) return -4;
+    if (a->feat_out && (!a->feat || a->feat_ch <= 0 || (a->T > a->N && !a->bg_feat))) return -5;
+    hipLaunchKernelGGL(composite_kernel, dim3((a->B + kRayWaves - 1) / kRayWaves), dim3(kRayWaves * 64), 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(eikonal_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a->eik_partial, a->B, a->eik_out);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,115 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) NeuS render kernels.
+//
+// Register layout used by every MLP kernel ("activation tile"): one wave owns 32 points; a tile of
+// 32 features x 32 points lives in 16 f32 registers per lane exactly as an MFMA 32x32 accumulator:
+//   lane = c + 32*h  (c = point column 0..31, h = lane half)
+//   reg t (0..15) holds feature  rho(t,h) = (t&3) + 8*(t>>2) + 4*h  of point c.
+// A layer is  Y[out x pts] = W[out x in] . X[in x pts]: weights are the MFMA A operand (streamed
+// through LDS), activations the B operand, so a layer's accumulators are directly the next layer's
+// B operands and activations never leave registers between layers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+#include <utility>
+
+#define VDN_DEV __device__ __forceinline__
+
+namespace vdn {
+
+constexpr int kWave = 64;
+
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [0, N) - independent of the
+// optimizer's unroll heuristics, so register arrays indexed by I never fall to scratch.
+template <class F, int... Is>
+VDN_DEV void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+VDN_DEV void static_for(F&& f) {
+    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+VDN_DEV int rho(int t, int h) { return (t & 3) + 8 * (t >> 2) + 4 * h; }
+
+// async global -> LDS copy of 16 B per lane; LDS destination = wave-uniform base + lane*16.
+VDN_DEV void glds16(const void* gsrc_lane, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+VDN_DEV float softplus100(float a) {
+    // torch.nn.Softplus(beta=100), threshold 20  (reference fields.py:70)
+    const float z = a * 100.0f;
+    return z > 20.0f ? a : log1pf(expf(z)) * 0.01f;
+}
+VDN_DEV float softplus100_grad(float a) {
+    // d/da, the form ATen's backward uses: z/(z+1), 1 past the threshold
+    const float z = a * 100.0f;
+    const float e = expf(z);
+    return z > 20.0f ? 1.0f : e / (e + 1.0f);
+}
+VDN_DEV float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+VDN_DEV float softplus1(float x) {
+    // F.softplus default: beta 1, threshold 20 (reference renderer.py:124)
+    return x > 20.0f ? x : log1pf(expf(x));
+}
+
+// Scatter a per-point vector vals[NF] (compile-time indexed, identical on both lane halves) into
+// NT activation tiles: X[tile*16+t] = vals[32*tile + rho(t,h)], zero beyond NF.
+template <int NF, int NT>
+VDN_DEV void vals_to_tiles(const float (&vals)[NF], int h, float* X) {
+#pragma unroll
+    for (int tile = 0; tile < NT; ++tile) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int f0 = 32 * tile + (t & 3) + 8 * (t >> 2);
+            const int f1 = f0 + 4;
+            const float a = f0 < NF ? vals[f0 < NF ? f0 : 0] : 0.0f;
+            const float b = f1 < NF ? vals[f1 < NF ? f1 : 0] : 0.0f;
+            X[tile * 16 + t] = h ? b : a;
+        }
+    }
+}
+
+// Inverse: gather NT tiles into a full per-point vector (every lane gets all values of its point).
+template <int NF, int NT>
+VDN_DEV void tiles_to_vals(const float* X, int h, float (&vals)[NF]) {
+#pragma unroll
+    for (int tile = 0; tile < NT; ++tile) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int f0 = 32 * tile + (t & 3) + 8 * (t >> 2);
+            const int f1 = f0 + 4;
+            const float mine = X[tile * 16 + t];
+            const float other = __shfl_xor(mine, 32);
+            if (f0 < NF) vals[f0 < NF ? f0 : 0] = h ? other : mine;
+            if (f1 < NF) vals[f1 < NF ? f1 : 0] = h ? mine : other;
+        }
+    }
+}
+
+// Positional encoding of a D-vector with L log-spaced octaves, reference order
+// [x, sin(2^0 x), cos(2^0 x), sin(2^1 x), ...] (embedder.py:27-36).
+template <int D, int L>
+VDN_DEV void posenc(const float (&v)[D], float (&pe)[D * (1 + 2 * L)]) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) pe[d] = v[d];
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        const float f = (float)(1 << k);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            float s, c;
+            sincosf(v[d] * f, &s, &c);
+            pe[D + 2 * D * k + d] = s;
+            pe[D + 2 * D * k + D + d] = c;
+        }
+    }
+}
+
+}  // namespace vdn

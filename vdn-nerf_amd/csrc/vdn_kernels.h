@@ -1,0 +1,23 @@
+// Internal: maps the C-ABI structs of include/vdn_render.h into namespace vdn.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/vdn_render.h"
+
+namespace vdn {
+using SdfArgs = ::VdnSdfArgs;
+using WeightNormDesc = ::VdnWeightNormDesc;
+using ChunkDesc = ::VdnChunkDesc;
+using RenderNetArgs = ::VdnRenderNetArgs;
+using NerfArgs = ::VdnNerfArgs;
+using CoarseArgs = ::VdnCoarseArgs;
+using UpsampleArgs = ::VdnUpsampleArgs;
+using MergeArgs = ::VdnMergeArgs;
+using SectionArgs = ::VdnSectionArgs;
+using CompositeArgs = ::VdnCompositeArgs;
+
+// Kernels needing more than 64 KiB of dynamic LDS opt in once per process.
+template <class K>
+inline void allow_big_lds(K kernel, size_t bytes) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+}  // namespace vdn

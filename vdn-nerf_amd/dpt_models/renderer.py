@@ -1,0 +1,249 @@
+"""Drop-in for the reference's dpt_models/renderer.py on MI355X.
+
+NeuSRenderer keeps the reference's constructor and render()/extract_geometry() signatures and the
+exact output dict of renderer.py:426-439; the work is done by the gfx950 kernels of
+libvdn_render.so: vdn_coarse_z, vdn_upsample_round, vdn_merge_sorted, vdn_sections (sampling,
+renderer.py:334-391), the fused MLP kernels (fields.py), and vdn_alpha_composite_fwd
+(renderer.py:262-315). No eager/CPU path exists.
+
+Extra, optional keyword arguments (not in the reference): `t_rand` [B,1] and `t_rand_out`
+[B,n_outside] inject the two uniform draws of renderer.py:348,355; `z_vals_inject` [B,N] skips the
+hierarchical sampler. They exist for parity tests (hard part 6).
+"""
+import numpy as np
+import torch
+
+from vdn_hip import lib
+from dpt_models.fields import _require_gpu, _stream
+
+
+def extract_fields(bound_min, bound_max, resolution, query_func, device=None):
+    """SDF lattice in 64^3 blocks (renderer.py:10-30); `query_func` maps [P,3] device points -> values."""
+    N = 64
+    device = device or (bound_min.device if torch.is_tensor(bound_min) and bound_min.is_cuda else torch.device("cuda"))
+    lo = [float(v) for v in bound_min]
+    hi = [float(v) for v in bound_max]
+    X = torch.linspace(lo[0], hi[0], resolution).split(N)
+    Y = torch.linspace(lo[1], hi[1], resolution).split(N)
+    Z = torch.linspace(lo[2], hi[2], resolution).split(N)
+    u = np.zeros([resolution, resolution, resolution], dtype=np.float32)
+    with torch.no_grad():
+        for xi, xs in enumerate(X):
+            for yi, ys in enumerate(Y):
+                for zi, zs in enumerate(Z):
+                    xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
+                    pts = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], dim=-1).to(device)
+                    val = query_func(pts).reshape(len(xs), len(ys), len(zs)).cpu().numpy()
+                    u[xi * N: xi * N + len(xs), yi * N: yi * N + len(ys), zi * N: zi * N + len(zs)] = val
+    return u
+
+
+def extract_geometry(bound_min, bound_max, resolution, threshold, query_func):
+    """renderer.py:33-41. Marching cubes itself is the third-party PyMCubes (not part of this path)."""
+    u = extract_fields(bound_min, bound_max, resolution, query_func)
+    try:
+        import mcubes
+    except ImportError as e:
+        raise RuntimeError("extract_geometry needs PyMCubes for marching cubes (as the reference does); "
+                           "use extract_fields() for the SDF lattice alone") from e
+    vertices, triangles = mcubes.marching_cubes(u, threshold)
+    b_max_np = np.asarray([float(v) for v in bound_max])
+    b_min_np = np.asarray([float(v) for v in bound_min])
+    vertices = vertices / (resolution - 1.0) * (b_max_np - b_min_np)[None, :] + b_min_np[None, :]
+    return vertices, triangles
+
+
+class NeuSRenderer:
+    def __init__(self, nerf, sdf_network, deviation_network, color_network, depth_network, n_samples, n_importance,
+                 n_outside, up_sample_steps, perturb):
+        self.nerf = nerf
+        self.sdf_network = sdf_network
+        self.deviation_network = deviation_network
+        self.color_network = color_network
+        self.depth_network = depth_network
+        self.n_samples = n_samples
+        self.n_importance = n_importance
+        self.n_outside = n_outside
+        self.up_sample_steps = up_sample_steps
+        self.perturb = perturb
+        if n_importance > 0 and (n_importance % up_sample_steps != 0 or n_importance // up_sample_steps > 64):
+            raise ValueError("n_importance must be a multiple of up_sample_steps with at most 64 samples per round")
+        if n_samples + n_importance + n_outside > 256 or n_outside > 64:
+            raise ValueError("the per-ray kernels handle up to 256 samples per ray and n_outside <= 64")
+        self._const_cache = {}
+
+    # constant vectors whose rounding must be torch.linspace's (renderer.py:335,340,352-354; 53)
+    def _consts(self, dev):
+        c = self._const_cache.get(dev)
+        if c is None:
+            c = {"lin_samples": torch.linspace(0.0, 1.0, self.n_samples).to(dev)}
+            if self.n_outside > 0:
+                zo = torch.linspace(1e-3, 1.0 - 1.0 / (self.n_outside + 1.0), self.n_outside)
+                mids = .5 * (zo[1:] + zo[:-1])
+                c["lin_outside"] = zo.to(dev)
+                c["out_upper"] = torch.cat([mids, zo[-1:]], -1).to(dev)
+                c["out_lower"] = torch.cat([zo[:1], mids], -1).to(dev)
+            if self.n_importance > 0:
+                n = self.n_importance // self.up_sample_steps
+                c["u"] = torch.linspace(0.5 / n, 1.0 - 0.5 / n, steps=n).to(dev)
+            self._const_cache[dev] = c
+        return c
+
+    # -------------------------------------------------------------------------------------
+    def _sample(self, rays_o, rays_d, near, far, perturb, t_rand, t_rand_out, z_vals_inject):
+        """renderer.py:334-386 -> z [B,N] (sorted inside samples), z_out [B,O] or None."""
+        B, dev = rays_o.shape[0], rays_o.device
+        S, I, O = self.n_samples, self.n_importance, self.n_outside
+        N = S + I
+        c = self._consts(dev)
+        st = _stream()
+        z = torch.empty(B, N, dtype=torch.float32, device=dev)
+        z_out = torch.empty(B, O, dtype=torch.float32, device=dev) if O > 0 else None
+        a = lib.VdnCoarseArgs()
+        a.near, a.far, a.lin_samples = near.data_ptr(), far.data_ptr(), c["lin_samples"].data_ptr()
+        a.z, a.B, a.n_samples, a.n_outside, a.z_ld = z.data_ptr(), B, S, O, N
+        if O > 0:
+            a.lin_outside, a.out_lower, a.out_upper = (c[k].data_ptr() for k in ("lin_outside", "out_lower", "out_upper"))
+            a.z_out = z_out.data_ptr()
+        if perturb > 0:
+            if t_rand is None:
+                t_rand = torch.rand([B, 1], device=dev)                  # renderer.py:348
+            a.t_rand = t_rand.data_ptr()
+            if O > 0:
+                if t_rand_out is None:
+                    t_rand_out = torch.rand([B, O], device=dev)          # renderer.py:355
+                a.t_rand_out = t_rand_out.data_ptr()
+        lib.call("vdn_coarse_z", a, st)
+        if I > 0:
+            if z_vals_inject is not None:
+                z = z_vals_inject.contiguous()
+            else:
+                sdf = torch.empty(B, N, dtype=torch.float32, device=dev)
+                self.sdf_network._run(0, rays=(rays_o, rays_d, z[:, :S]), sdf_out=sdf[:, :S])   # renderer.py:369-370
+                n_imp = I // self.up_sample_steps
+                new_z = torch.empty(B, n_imp, dtype=torch.float32, device=dev)
+                new_sdf = torch.empty(B, n_imp, dtype=torch.float32, device=dev)
+                M = S
+                for i in range(self.up_sample_steps):
+                    u = lib.VdnUpsampleArgs()
+                    u.rays_o, u.rays_d, u.z, u.sdf, u.u = (t.data_ptr() for t in (rays_o, rays_d, z, sdf, c["u"]))
+                    u.new_z, u.inv_s, u.B, u.M, u.ld, u.n_imp = new_z.data_ptr(), float(64 * 2 ** i), B, M, N, n_imp
+                    lib.call("vdn_upsample_round", u, st)
+                    last = (i + 1 == self.up_sample_steps)
+                    m = lib.VdnMergeArgs()
+                    m.z, m.new_z, m.z_out = z.data_ptr(), new_z.data_ptr(), z.data_ptr()
+                    m.B, m.M, m.K, m.ld, m.ld_out = B, M, n_imp, N, N
+                    if not last:
+                        self.sdf_network._run(0, rays=(rays_o, rays_d, new_z), sdf_out=new_sdf)         # renderer.py:201
+                        m.sdf, m.new_sdf, m.sdf_out = sdf.data_ptr(), new_sdf.data_ptr(), sdf.data_ptr()
+                    lib.call("vdn_merge_sorted", m, st)
+                    M += n_imp
+        else:
+            z = z[:, :S] if N == S else z
+        return z, z_out
+
+    def _sections(self, z, n, sample_dist):
+        B, dev = z.shape[0], z.device
+        dists = torch.empty(B, n, dtype=torch.float32, device=dev)
+        mid = torch.empty(B, n, dtype=torch.float32, device=dev)
+        a = lib.VdnSectionArgs()
+        a.z, a.dists, a.mid_z, a.sample_dist, a.B, a.n, a.ld = z.data_ptr(), dists.data_ptr(), mid.data_ptr(), sample_dist, B, n, z.stride(0)
+        lib.call("vdn_sections", a, _stream())
+        return dists, mid
+
+    def render(self, rays_o, rays_d, near, far, perturb_overwrite=-1, background_rgb=None, cos_anneal_ratio=0.0,
+               depth_before_color=False, t_rand=None, t_rand_out=None, z_vals_inject=None):
+        for t, n in ((rays_o, "rays_o"), (rays_d, "rays_d"), (near, "near"), (far, "far")):
+            _require_gpu(t, "NeuSRenderer.render " + n)
+        if depth_before_color:
+            raise ValueError("depth_before_color=True (352-wide colour-net feature) is not used by any shipped "
+                             "configuration and has no kernel")
+        if rays_o.dim() != 2 or rays_o.shape[1] != 3 or rays_d.shape != rays_o.shape:
+            raise ValueError("rays_o / rays_d must be [B,3]")
+        B, dev = rays_o.shape[0], rays_o.device
+        if near.numel() != B or far.numel() != B:
+            raise ValueError("near / far must hold one value per ray")
+        rays_o = rays_o.detach().contiguous()
+        rays_d = rays_d.detach().contiguous()
+        near = near.detach().reshape(B).contiguous()
+        far = far.detach().reshape(B).contiguous()
+        S, I, O = self.n_samples, self.n_importance, self.n_outside
+        N = S + I
+        T = N + O
+        sample_dist = 2.0 / S                                                    # renderer.py:334
+        perturb = self.perturb if perturb_overwrite < 0 else perturb_overwrite
+        if B == 0:
+            raise ValueError("empty ray batch")
+        st = _stream()
+
+        z, z_out = self._sample(rays_o, rays_d, near, far, perturb, t_rand, t_rand_out, z_vals_inject)
+        dists, mid_z = self._sections(z, N, sample_dist)
+
+        bg_density = bg_rgb = bg_feat = bg_dists = bg_mid = None
+        if O > 0:                                                                # renderer.py:389-397
+            z_feed = torch.empty(B, T, dtype=torch.float32, device=dev)
+            m = lib.VdnMergeArgs()
+            m.z, m.new_z, m.z_out = z.data_ptr(), z_out.data_ptr(), z_feed.data_ptr()
+            m.B, m.M, m.K, m.ld, m.ld_out = B, N, O, z.stride(0), T
+            lib.call("vdn_merge_sorted", m, st)
+            bg_dists, bg_mid = self._sections(z_feed, T, sample_dist)
+            bg_density, bg_rgb, bg_feat = self.nerf._run(rays=(rays_o, rays_d, bg_mid))
+
+        ws = {}
+        sdf, feat, normals = self.sdf_network._run(1, rays=(rays_o, rays_d, mid_z), workspace=ws)   # renderer.py:239-243
+        sampled_feat = None
+        if self.depth_network is not None:                                       # renderer.py:245-249
+            sampled_feat = self.depth_network._run(normals, feat, rays=(rays_o, rays_d, mid_z))
+        sampled_color = self.color_network._run(normals, feat, rays=(rays_o, rays_d, mid_z))        # renderer.py:251
+
+        a = lib.VdnCompositeArgs()
+        f32 = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        weights, alpha, cdf, inside = f32(B, T), f32(B, T), f32(B, N), f32(B, N)
+        color, wsum, wmax, s_val = f32(B, 3), f32(B, 1), f32(B, 1), f32(B, 1)
+        eik_partial, eik = f32(B, 2), f32(3)
+        feat_out = f32(B, 96) if sampled_feat is not None else None
+        a.rays_o, a.rays_d, a.sdf, a.normals = rays_o.data_ptr(), rays_d.data_ptr(), sdf.data_ptr(), normals.data_ptr()
+        a.dists, a.mid_z, a.color = dists.data_ptr(), mid_z.data_ptr(), sampled_color.data_ptr()
+        a.variance = self.deviation_network.variance.data_ptr()
+        if sampled_feat is not None:
+            a.feat, a.feat_out, a.feat_ch = sampled_feat.data_ptr(), feat_out.data_ptr(), 96
+        if O > 0:
+            a.bg_density, a.bg_rgb, a.bg_dists = bg_density.data_ptr(), bg_rgb.data_ptr(), bg_dists.data_ptr()
+            if sampled_feat is not None:
+                if bg_feat is None:
+                    raise ValueError("depth_network is set but the NeRF was built with gen_depth_feats=False")
+                a.bg_feat = bg_feat.data_ptr()
+        bgc = None
+        if background_rgb is not None:
+            bgc = background_rgb.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+            if bgc.numel() != 3:
+                raise ValueError("background_rgb must have 3 values")
+            a.background_rgb = bgc.data_ptr()
+        a.cos_anneal_ratio = float(cos_anneal_ratio)
+        a.B, a.N, a.T = B, N, T
+        a.weights, a.alpha_out, a.cdf, a.inside_sphere = weights.data_ptr(), alpha.data_ptr(), cdf.data_ptr(), inside.data_ptr()
+        a.color_out, a.weight_sum, a.weight_max, a.s_val = color.data_ptr(), wsum.data_ptr(), wmax.data_ptr(), s_val.data_ptr()
+        a.eik_partial, a.eik_out = eik_partial.data_ptr(), eik.data_ptr()
+        lib.call("vdn_alpha_composite_fwd", a, st)
+
+        self.last_eikonal_terms = eik[1:3]      # (numerator, denominator) for the data-parallel reduction
+        return {
+            "render_feats": feat_out,
+            "color_fine": color,
+            "s_val": s_val,
+            "cdf_fine": cdf,
+            "weight_sum": wsum,
+            "weight_max": wmax,
+            "gradients": normals.view(B, N, 3),
+            "weights": weights,
+            "z_vals": bg_mid if O > 0 else mid_z,                                # renderer.py:421-424
+            "gradient_error": eik[0],
+            "inside_sphere": inside,
+        }
+
+    def extract_fields(self, bound_min, bound_max, resolution):
+        return extract_fields(bound_min, bound_max, resolution, lambda pts: -self.sdf_network.sdf(pts))
+
+    def extract_geometry(self, bound_min, bound_max, resolution, threshold=0.0):
+        return extract_geometry(bound_min, bound_max, resolution=resolution, threshold=threshold,
+                                query_func=lambda pts: -self.sdf_network.sdf(pts))

@@ -1,0 +1,76 @@
+"""Build libvdn_render.so (gfx950) from csrc/*.hip with hipcc, in-tree.
+
+hipcc cross-compiles without a GPU. Objects are rebuilt only when a source or header is newer.
+Usage: python -m vdn_hip.build [--force] [-j N]
+"""
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+CSRC = os.path.join(PKG, "csrc")
+INCLUDE = os.path.join(os.path.dirname(PKG), "include")
+OBJDIR = os.path.join(HERE, "_build")
+LIB = os.path.join(HERE, "libvdn_render.so")
+ARCH = "gfx950"
+BASE_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC]
+PER_FILE_FLAGS = {"rays.hip": ["-ffp-contract=off"], "train_rays.hip": ["-ffp-contract=off"]}
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _headers_mtime():
+    m = 0.0
+    for d in (CSRC, INCLUDE):
+        for f in os.listdir(d):
+            if f.endswith(".h"):
+                m = max(m, os.path.getmtime(os.path.join(d, f)))
+    return m
+
+
+def _compile(src, force, hm):
+    obj = os.path.join(OBJDIR, src[:-4] + ".o")
+    sp = os.path.join(CSRC, src)
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(sp), hm):
+        return src, 0.0, ""
+    t = time.time()
+    cmd = ["hipcc"] + BASE_FLAGS + PER_FILE_FLAGS.get(src, []) + ["-c", sp, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))
+    return src, time.time() - t, r.stderr
+
+
+def build(force=False, jobs=None, verbose=True):
+    os.makedirs(OBJDIR, exist_ok=True)
+    srcs = _sources()
+    hm = _headers_mtime()
+    jobs = jobs or min(len(srcs), max(1, (os.cpu_count() or 2) - 1))
+    rebuilt = False
+    with cf.ThreadPoolExecutor(jobs) as ex:
+        for src, dt, _ in ex.map(lambda s: _compile(s, force, hm), srcs):
+            if dt > 0:
+                rebuilt = True
+                if verbose:
+                    print("[vdn_hip.build] %-24s %.1fs" % (src, dt), flush=True)
+    objs = [os.path.join(OBJDIR, s[:-4] + ".o") for s in srcs]
+    if rebuilt or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+        cmd = ["hipcc", "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stderr[-4000:])
+        if verbose:
+            print("[vdn_hip.build] linked", LIB, flush=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    j = None
+    if "-j" in sys.argv:
+        j = int(sys.argv[sys.argv.index("-j") + 1])
+    build(force="--force" in sys.argv, jobs=j)

@@ -1,0 +1,243 @@
+"""Weight-image plans: how each network's effective weights are re-tiled into the MFMA chunk
+streams the kernels consume (csrc/mlp_engine_f32.h), and the device tables that drive
+vdn_weightnorm_materialize / vdn_build_images.
+
+A *stream* is the exact sequence of 32-row chunks one kernel walks through; a layer of a stream is
+described by a padded input map (kmap: padded k -> source column, -1 = zero), and per chunk a
+source matrix, a bias vector and a 32-entry output-row map. Transposed layers (reverse sweeps,
+backward chains) swap the strides, nothing else.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import lib
+
+FMT_F32, FMT_BF16 = 0, 1
+
+
+def chunk_bytes(kt, fmt=FMT_F32):
+    return kt * 4096 + 1024 if fmt == FMT_F32 else kt * 2048 + 1024
+
+
+def _pad32(n):
+    return (n + 31) // 32 * 32
+
+
+def ident_map(n, pad=None):
+    pad = _pad32(n) if pad is None else pad
+    m = np.full(pad, -1, np.int32)
+    m[:n] = np.arange(n)
+    return m
+
+
+class Layer:
+    """One GEMM layer of a stream. chunks: list of (matrix_name, use_bias, rowmap32[int32 x32])."""
+
+    def __init__(self, kmap, chunks, scale=1.0, transposed=False):
+        self.kmap = np.asarray(kmap, np.int32)
+        assert len(self.kmap) % 32 == 0
+        self.chunks = chunks
+        self.scale = float(scale)
+        self.transposed = transposed
+
+    @property
+    def kt(self):
+        return len(self.kmap) // 32
+
+
+def dense_layer(name, kmap, nmap, bias=True, scale=1.0):
+    """Forward layer reading matrix `name` [rows, cols]: padded out row n <- source row nmap[n]."""
+    nmap = np.asarray(nmap, np.int32)
+    assert len(nmap) % 32 == 0
+    return Layer(kmap, [(name, bias, nmap[i:i + 32]) for i in range(0, len(nmap), 32)], scale)
+
+
+def transposed_layer(name, fwd_kmap, fwd_nmap, scale=1.0):
+    """W^T layer of a forward layer (kmap, nmap): image rows follow the forward layer's padded INPUT
+    order, the contraction runs over its padded OUTPUT order."""
+    fwd_kmap = np.asarray(fwd_kmap, np.int32)
+    return Layer(np.asarray(fwd_nmap, np.int32),
+                 [(name, False, fwd_kmap[i:i + 32]) for i in range(0, len(fwd_kmap), 32)], scale, transposed=True)
+
+
+class NetImages:
+    """Device-side state of one network: effective weights + chunk-stream blobs.
+
+    matrices: ordered {name: (g or None, v, bias or None)} of torch Parameters.
+    streams:  {stream_name: [Layer, ...]}.
+    """
+
+    def __init__(self, matrices, streams, device, fmt=FMT_F32):
+        self.device = device
+        self.fmt = fmt
+        self.matrices = matrices
+        self.streams = streams
+        self._key = None
+        names = list(matrices)
+        self.names = names
+        sizes = [matrices[n][1].numel() for n in names]
+        rows = [matrices[n][1].shape[0] for n in names]
+        self.w_off = dict(zip(names, np.concatenate([[0], np.cumsum(sizes)[:-1]]).tolist()))
+        self.r_off = dict(zip(names, np.concatenate([[0], np.cumsum(rows)[:-1]]).tolist()))
+        self.weff = torch.empty(int(sum(sizes)), dtype=torch.float32, device=device)
+        self.inv_norm = torch.empty(int(sum(rows)), dtype=torch.float32, device=device)
+        self.max_rows = max(rows)
+        # blobs
+        self.blobs, self.blob_off = {}, {}
+        maps, map_off = [], 0
+        chunk_rows = []
+        for sname, layers in streams.items():
+            total = sum(chunk_bytes(L.kt, fmt) * len(L.chunks) for L in layers)
+            self.blobs[sname] = torch.zeros(total, dtype=torch.uint8, device=device)
+            off = 0
+            for L in layers:
+                k_off = map_off
+                maps.append(L.kmap)
+                map_off += len(L.kmap)
+                for (mname, use_bias, rowmap) in L.chunks:
+                    n_off = map_off
+                    maps.append(np.asarray(rowmap, np.int32))
+                    map_off += 32
+                    chunk_rows.append((sname, off, mname, use_bias, k_off, n_off, L))
+                    off += chunk_bytes(L.kt, fmt)
+        self.maps = torch.from_numpy(np.concatenate(maps)).to(device)
+        self._chunk_rows = chunk_rows
+        self._tables_key = None
+        self.wn_table = None
+        self.chunk_table = None
+
+    def weff_view(self, name):
+        v = self.matrices[name][1]
+        o = self.w_off[name]
+        return self.weff[o:o + v.numel()].view(v.shape)
+
+    def _build_tables(self):
+        wn = np.zeros(len(self.names), dtype=lib.struct_dtype("VdnWeightNormDesc"))
+        for i, n in enumerate(self.names):
+            g, v, b = self.matrices[n]
+            wn[i]["g"] = 0 if g is None else g.data_ptr()
+            wn[i]["v"] = v.data_ptr()
+            wn[i]["w_eff"] = self.weff.data_ptr() + 4 * self.w_off[n]
+            wn[i]["inv_norm"] = self.inv_norm.data_ptr() + 4 * self.r_off[n]
+            wn[i]["rows"], wn[i]["cols"] = v.shape
+        ch = np.zeros(len(self._chunk_rows), dtype=lib.struct_dtype("VdnChunkDesc"))
+        mp = self.maps.data_ptr()
+        for i, (sname, off, mname, use_bias, k_off, n_off, L) in enumerate(self._chunk_rows):
+            g, v, b = self.matrices[mname]
+            rows, cols = v.shape
+            ch[i]["src"] = self.weff.data_ptr() + 4 * self.w_off[mname]
+            ch[i]["bias"] = b.data_ptr() if (use_bias and b is not None) else 0
+            ch[i]["kmap"] = mp + 4 * k_off
+            ch[i]["nmap"] = mp + 4 * n_off
+            ch[i]["dst"] = self.blobs[sname].data_ptr() + off
+            if L.transposed:      # image row index -> source COLUMN, k index -> source ROW
+                ch[i]["row_stride"], ch[i]["col_stride"] = 1, cols
+            else:
+                ch[i]["row_stride"], ch[i]["col_stride"] = cols, 1
+            ch[i]["n0"] = 0
+            ch[i]["k_pad"] = len(L.kmap)
+            ch[i]["scale"] = L.scale
+            ch[i]["fmt"] = self.fmt
+        self.wn_table = torch.from_numpy(wn.view(np.uint8)).to(self.device)
+        self.chunk_table = torch.from_numpy(ch.view(np.uint8)).to(self.device)
+        self._n_wn, self._n_ch = len(wn), len(ch)
+
+    def refresh(self, stream):
+        """Re-materialise W_eff and all chunk images if any parameter changed (in place or rebound)."""
+        params = [t for n in self.names for t in self.matrices[n] if t is not None]
+        ptr_key = tuple(t.data_ptr() for t in params)
+        if ptr_key != self._tables_key:
+            self._build_tables()
+            self._tables_key = ptr_key
+            self._key = None
+        key = tuple(t._version for t in params)
+        if key == self._key:
+            return False
+        lib.call("vdn_weightnorm_materialize", lib.ptr(self.wn_table), self._n_wn, self.max_rows, stream)
+        lib.call("vdn_build_images", lib.ptr(self.chunk_table), self._n_ch, stream)
+        self._key = key
+        return True
+
+
+# ---------------------------------------------------------------------------------------------
+# plans for the shipped shape family
+# ---------------------------------------------------------------------------------------------
+
+def sdf_streams(d_in, d_out, d_hidden, n_layers, skip_in, multires):
+    """Streams of csrc/sdf_f32.hip: 'sdf' (mode 0) and 'full' (mode 1: forward + reverse sweep)."""
+    if not (d_in == 3 and d_hidden == 256 and n_layers == 8 and tuple(skip_in) == (4,) and multires == 6 and d_out == 257):
+        raise ValueError("SDFNetwork: the HIP kernels implement the shipped shape family only "
+                         "(d_in=3, d_out=257, d_hidden=256, n_layers=8, skip_in=(4,), multires=6); got "
+                         "d_in=%d d_out=%d d_hidden=%d n_layers=%d skip_in=%s multires=%d"
+                         % (d_in, d_out, d_hidden, n_layers, tuple(skip_in), multires))
+    d0 = 39
+    fwd = []   # (name, kmap, nmap, scale) per layer 0..7
+    for l in range(8):
+        name = "lin%d" % l
+        if l == 0:
+            km, nm, sc = ident_map(d0, 64), ident_map(256), 1.0
+        elif l == 3:
+            km, nm, sc = ident_map(256), ident_map(256 - d0, 224), 1.0
+        elif l == 4:
+            km = np.full(288, -1, np.int32)
+            km[:256 - d0] = np.arange(256 - d0)                    # h4 (217)
+            km[224:224 + d0] = (256 - d0) + np.arange(d0)          # PE (39)
+            nm, sc = ident_map(256), 1.0 / math.sqrt(2.0)
+        else:
+            km, nm, sc = ident_map(256), ident_map(256), 1.0
+        fwd.append((name, km, nm, sc))
+    hidden = [dense_layer(n, km, nm, True, sc) for (n, km, nm, sc) in fwd]
+    last_sdf = dense_layer("lin8", ident_map(256), ident_map(1, 32), True)
+    nm8 = np.full(288, -1, np.int32)
+    nm8[:256] = 1 + np.arange(256)      # feature rows
+    nm8[256] = 0                        # sdf row
+    last_full = dense_layer("lin8", ident_map(256), nm8, True)
+    sweep = [transposed_layer(n, km, nm, sc) for (n, km, nm, sc) in reversed(fwd[0:8])]
+    return {"sdf": hidden + [last_sdf], "full": hidden + [last_full] + sweep}
+
+
+def rendering_streams(d_feature, mode, d_in, d_out, d_hidden, n_layers, multires_view):
+    if not (d_feature == 256 and mode == "idr" and d_in == 9 and d_hidden == 256 and n_layers == 4 and
+            multires_view == 4 and (d_out == 96 or 1 <= d_out <= 4)):
+        raise ValueError("RenderingNetwork: the HIP kernels implement mode='idr', d_feature=256, d_in=9, "
+                         "d_hidden=256, n_layers=4, multires_view=4, d_out in {1..4, 96} only")
+    km0 = np.full(320, -1, np.int32)
+    km0[:256] = 33 + np.arange(256)      # feature vector columns
+    km0[256:289] = np.arange(33)         # points(3), PE(view)(27), normals(3)
+    layers = [dense_layer("lin0", km0, ident_map(256))]
+    for l in (1, 2, 3):
+        layers.append(dense_layer("lin%d" % l, ident_map(256), ident_map(256)))
+    layers.append(dense_layer("lin4", ident_map(256), ident_map(d_out, 96 if d_out == 96 else 32)))
+    return {"fwd": layers}
+
+
+def nerf_streams(D, W, d_in, d_in_view, multires, multires_view, skips, rgb_dims, gen_depth_feats, dpt_dim):
+    if not (D == 8 and W == 256 and d_in == 4 and d_in_view == 3 and multires == 10 and multires_view == 4 and
+            tuple(skips) == (4,) and rgb_dims == 3 and (not gen_depth_feats or dpt_dim == 96)):
+        raise ValueError("NeRF: the HIP kernels implement D=8, W=256, d_in=4, d_in_view=3, multires=10, "
+                         "multires_view=4, skips=[4], rgb_dims=3, dpt_dim=96 only")
+    ch = 84
+    layers = [dense_layer("pts_linears.0", ident_map(ch, 96), ident_map(256))]
+    for i in (1, 2, 3, 4):
+        layers.append(dense_layer("pts_linears.%d" % i, ident_map(256), ident_map(256)))
+    km5 = np.full(352, -1, np.int32)
+    km5[:ch] = np.arange(ch)
+    km5[96:352] = ch + np.arange(256)
+    layers.append(dense_layer("pts_linears.5", km5, ident_map(256)))
+    for i in (6, 7):
+        layers.append(dense_layer("pts_linears.%d" % i, ident_map(256), ident_map(256)))
+    head = dense_layer("feature_linear", ident_map(256), ident_map(256))
+    head.chunks.append(("alpha_linear", True, ident_map(1, 32)))
+    layers.append(head)
+    kmv = np.full(288, -1, np.int32)
+    kmv[:256] = np.arange(256)
+    kmv[256:283] = 256 + np.arange(27)
+    layers.append(dense_layer("views_linears.0", kmv, ident_map(128)))
+    out = dense_layer("rgb_linear", ident_map(128), ident_map(3, 32))
+    if gen_depth_feats:
+        nm = ident_map(96)
+        out.chunks += [("dpt_linear", True, nm[i:i + 32]) for i in (0, 32, 64)]
+    layers.append(out)
+    return {"fwd": layers}

@@ -1,0 +1,102 @@
+"""ctypes binding of libvdn_render.so, generated from include/vdn_render.h at import time.
+
+The header is the single source of truth: struct layouts and entry points are parsed from it, so
+the Python mirror cannot drift from the C ABI. There is no fallback: if the shared library is
+missing or does not load, every kernel entry point raises.
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+HEADER = os.path.join(os.path.dirname(PKG), "include", "vdn_render.h")
+LIB_PATH = os.path.join(HERE, "libvdn_render.so")
+
+_SCALARS = {"int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "int": ctypes.c_int}
+
+
+def _strip_comments(text):
+    return re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+
+
+def parse_header(path=HEADER):
+    """-> (structs: {name: [(field, ctype)]}, functions: {name: n_args})"""
+    text = _strip_comments(open(path).read())
+    structs = {}
+    for m in re.finditer(r"typedef\s+struct\s*\{(.*?)\}\s*(\w+)\s*;", text, flags=re.S):
+        fields = []
+        for decl in m.group(1).split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            mm = re.match(r"(const\s+)?(\w+)\s*(\*?)\s*(.+)$", decl)
+            base, ptr, names = mm.group(2), mm.group(3), mm.group(4)
+            for nm in names.split(","):
+                nm = nm.strip()
+                is_ptr = bool(ptr) or nm.startswith("*")
+                nm = nm.lstrip("* ")
+                fields.append((nm, ctypes.c_void_p if is_ptr else _SCALARS[base]))
+        structs[m.group(2)] = fields
+    funcs = {}
+    for m in re.finditer(r"\bint\s+(vdn_\w+)\s*\((.*?)\)\s*;", text, flags=re.S):
+        args = m.group(2).strip()
+        funcs[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
+    return structs, funcs
+
+
+_STRUCT_FIELDS, FUNCTIONS = parse_header()
+
+
+def _make_struct(name, fields):
+    return type(name, (ctypes.Structure,), {"_fields_": fields})
+
+
+STRUCTS = {n: _make_struct(n, f) for n, f in _STRUCT_FIELDS.items()}
+globals().update(STRUCTS)
+
+
+def struct_dtype(name):
+    """numpy dtype with the C layout of struct `name` (for device-side descriptor tables)."""
+    return np.dtype(STRUCTS[name])
+
+
+class VdnError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the kernel library, failing loudly when it is absent (no CPU / eager fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VdnError("HIP kernel library %s not built. Run `python -m vdn_hip.build` (or "
+                       "__graft_entry__.build()); there is no fallback path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for fn in FUNCTIONS:
+        f = getattr(lib, fn)       # AttributeError here = header/library mismatch
+        f.restype = ctypes.c_int
+    if lib.vdn_abi_version() != int(re.search(r"#define\s+VDN_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1)):
+        raise VdnError("libvdn_render.so ABI version does not match include/vdn_render.h; rebuild")
+    _lib = lib
+    return lib
+
+
+def call(fn_name, *args):
+    """Invoke an entry point; struct args are passed by reference; raises on a non-zero status."""
+    lib = load()
+    cargs = [ctypes.byref(a) if isinstance(a, ctypes.Structure) else a for a in args]
+    rc = getattr(lib, fn_name)(*cargs)
+    if rc != 0:
+        raise VdnError("%s failed with status %d (%s)" % (fn_name, rc, "argument error" if rc < 0 else "hipError_t"))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
