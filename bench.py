@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rays/sec of the NeuS render hot path, 512 rays x 128 samples (+32 outside)
+per GPU per step (BASELINE.json metric), synthetic 800x800 scene, random-init weights of the
+shipped architecture.
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+One JSON line on rank 0 with the driver's contract plus `roofline` (dominant kernel, timed live with
+HIP events) and `cpu_baseline` (the oracle = CPU restatement of the reference, timed on this host).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "vdn-nerf_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+# algorithmic FLOPs (2 per MAC, GEMM work only) - SURVEY.md 8d
+F_SDF, F_SDF1, F_GRAD, F_COL, F_VDN, F_NERF, F_NERF_DPT = 1049088, 918016, 918016, 542720, 590336, 1208320, 1232896
+FLOP_PER_RAY_FWD = 112 * F_SDF1 + 128 * (F_SDF + F_GRAD) + 128 * F_COL + 160 * F_NERF          # 617 406 464
+PEAK = {"f32": 157.3e12, "bf16": 2.5e15}     # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def time_kernel(fn, iters=10):
+    """Average device time of fn() (which launches on torch's current stream) via HIP events."""
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0 = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
+    e1 = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
+    for i in range(iters):
+        e0[i].record()
+        fn()
+        e1[i].record()
+    torch.cuda.synchronize()
+    return float(np.mean([a.elapsed_time(b) for a, b in zip(e0, e1)])) * 1e-3
+
+
+def cpu_baseline(B, seed, max_seconds=30.0):
+    """The oracle's render() forward on the host cores, same workload, bounded sample."""
+    import oracle.neus_oracle as orc
+    from vdn_train import synth
+    st = synth.make_all_states(seed, wdepth=False)
+    nets = orc.nets_from_numpy(st)
+    cams = synth.make_cameras(seed)
+    o, d = synth.random_pixel_batch(seed, 0, 0, B, cams=cams)
+    near, far = synth.near_far_from_sphere(o, d)
+    t1, t2 = synth.jitter(seed, 0, B)
+    tt = torch.tensor
+    args = (nets, tt(o), tt(d), tt(near), tt(far))
+    kw = dict(background_rgb=torch.ones(1, 3), cos_anneal_ratio=0.5, t_rand=tt(t1), t_rand_out=tt(t2))
+    cores = torch.get_num_threads()
+    t0 = time.time()
+    with torch.no_grad():
+        pass
+    orc.render(*args, **kw)                     # warm-up (first call pays allocator / thread-pool start)
+    warm = time.time() - t0
+    times = []
+    while len(times) < 5 and (sum(times) + warm) < max_seconds:
+        t = time.time()
+        orc.render(*args, **kw)
+        times.append(time.time() - t)
+    med = float(np.median(times)) if times else warm
+    return {"value": B / med, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": "%d x render() forward of %d rays (64+64+32 samples), oracle fp32 on %d threads, median" % (max(len(times), 1), B, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from vdn_train import synth, factory
+    seed, B = 0, args.batch
+    st = synth.make_all_states(seed, wdepth=False)
+    rend = factory.build_renderer(wdepth=False, device=dev, states=st)
+    cams = synth.make_cameras(seed)
+    perm = np.argsort(synth.uniform(seed, "perm", (len(cams),)))
+    bg = torch.ones(1, 3, device=dev)
+    g = lambda x: torch.tensor(x).to(dev)
+
+    def batch(step):
+        o, d = synth.random_pixel_batch(seed, step, int(perm[step % len(perm)]), B, rank=rank, cams=cams)
+        near, far = synth.near_far_from_sphere(o, d)
+        return g(o), g(d), g(near), g(far)
+
+    batches = [batch(s) for s in range(args.warmup + args.steps)]     # resident in HBM before the timed region
+
+    def step(i):
+        o, d, near, far = batches[i]
+        return rend.render(o, d, near, far, background_rgb=bg, cos_anneal_ratio=0.5)
+
+    for i in range(args.warmup):
+        step(i)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    fence()
+    t0 = time.time()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+    fence()
+    dt = time.time() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        rays = world * B * args.steps
+        value = rays / dt
+        # dominant kernel: fused PE -> SDF MLP -> feature + analytic gradient sweep, 65 536 points
+        o, d, near, far = batches[0]
+        z, _ = rend._sample(o, d, near.reshape(-1), far.reshape(-1), 0.0, None, None, None)
+        _, mid = rend._sections(z, z.shape[1], 2.0 / rend.n_samples)
+        tk = time_kernel(lambda: rend.sdf_network._run(1, rays=(o, d, mid)))
+        flops = (F_SDF + F_GRAD) * mid.numel()
+        dtype = "f32"
+        line = {
+            "metric": "rays/sec (512-ray batch, 128 samples/ray)", "value": value, "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": "NeuSRenderer.render forward, womsk_white shapes (SDF 8x256 + colour 4x256 + NeRF 8x256), "
+                                   "512 rays x (64 coarse + 64 importance + 32 outside) per GPU per step, hierarchical sampling on",
+                       "rays_per_gpu": B, "samples_per_ray": 128, "outside_samples": 32, "parallelism": "dp%d" % world,
+                       "flop_per_ray": FLOP_PER_RAY_FWD},
+            "model_flops_per_s": value * FLOP_PER_RAY_FWD,
+            "roofline": {"bound": "mfma", "kernel": "sdf_f32_kernel<1> (PE + SDF MLP + gradient sweep, 65536 points)",
+                         "achieved": flops / tk / 1e12, "peak": PEAK[dtype] / 1e12, "unit": "TFLOP/s",
+                         "frac": flops / tk / PEAK[dtype], "traffic": None, "kernel_ms": tk * 1e3},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(B, seed)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

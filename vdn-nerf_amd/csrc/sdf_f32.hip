@@ -24,8 +24,14 @@ struct HiddenEpi {
         f32x16 s;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            Y[nt * 16 + t] = softplus100(acc[t]);
-            if constexpr (SAVE) s[t] = softplus100_grad(acc[t]);
+            if constexpr (SAVE) {
+                float hv, sv;
+                softplus100_both(acc[t], hv, sv);
+                Y[nt * 16 + t] = hv;
+                s[t] = sv;
+            } else {
+                Y[nt * 16 + t] = softplus100_fast(acc[t]);
+            }
         }
         if constexpr (SAVE) store_tile_rowmajor(S, row, 256, nt, h, s, ok);
     }

@@ -42,6 +42,27 @@ VDN_DEV void glds16(const void* gsrc_lane, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Hardware transcendental forms (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp each): what the MLP
+// epilogues use - the ocml expf/log1pf expansions cost more VALU time than the layer's MFMAs.
+VDN_DEV float hw_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+VDN_DEV float hw_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+
+// Softplus(beta=100, threshold=20) and its derivative sigmoid(100 a) from one exponential
+// (reference fields.py:70; derivative in the z/(z+1) form of ATen's backward).
+VDN_DEV void softplus100_both(float a, float& hval, float& sval) {
+    const float z = a * 100.0f;
+    const float e = hw_exp(fminf(z, 30.0f));
+    const float u = 1.0f + e;
+    const bool lin = z > 20.0f;
+    hval = lin ? a : hw_log(u) * 0.01f;
+    sval = lin ? 1.0f : e * __builtin_amdgcn_rcpf(u);
+}
+VDN_DEV float softplus100_fast(float a) {
+    const float z = a * 100.0f;
+    const float e = hw_exp(fminf(z, 30.0f));
+    return z > 20.0f ? a : hw_log(1.0f + e) * 0.01f;
+}
+
 VDN_DEV float softplus100(float a) {
     // torch.nn.Softplus(beta=100), threshold 20  (reference fields.py:70)
     const float z = a * 100.0f;
