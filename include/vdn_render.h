@@ -44,9 +44,13 @@ typedef struct {
     char* dst;               /* chunk destination inside the blob */
     int64_t row_stride, col_stride;
     int32_t n0;              /* first padded output row of this chunk */
-    int32_t k_pad;           /* padded input width (multiple of 32) */
+    int32_t k_pad;           /* padded input width of the whole chunk (multiple of 32) */
     float scale;
     int32_t fmt;             /* 0 = fp32 chunk, 1 = bf16 chunk */
+    int32_t kt_begin;        /* this descriptor fills k-tiles [kt_begin, kt_begin+kt_count) of the chunk; */
+    int32_t kt_count;        /* kmap is indexed from the start of that range. kt_count 0 = whole chunk    */
+    int32_t write_bias;      /* 1: also write the chunk's bias/pad block (exactly one descriptor per chunk) */
+    int32_t _pad;
 } VdnChunkDesc;
 int vdn_build_images(const VdnChunkDesc* descs_dev, int n_chunks, void* stream);
 
@@ -69,6 +73,10 @@ typedef struct {
     float* normals;            /* [P,3] out (mode 1) */
     float* S;                  /* [8,P,256] workspace: softplus'(pre-activation) per hidden layer (mode 1) */
     const float* w8row;        /* [256] row 0 of the last layer's effective weight (mode 1) */
+    /* training-mode saves (mode 1), all optional (NULL = not saved): */
+    float* H;                  /* [8,P,256] H[l] = softplus output of layer l (= input of layer l+1) */
+    float* V;                  /* [8,P,256] V[l] = sweep value v_l = u_{l+1} * softplus'(a_l) */
+    float* PE;                 /* [P,64] positional encoding of the point (39 valid) */
 } VdnSdfArgs;
 int vdn_sdf_mlp_fwd_f32(int mode, const VdnSdfArgs* args_host, void* stream);
 
@@ -84,6 +92,8 @@ typedef struct {
     const float* pts;          /* [P,3] explicit points (standalone RenderingNetwork.forward) or NULL */
     const float* dirs;         /* [P,3] explicit view dirs or NULL (then rays_d[r]) */
     float* out;                /* [P,d_out] */
+    float* save_h;             /* [4,P,256] post-ReLU hidden activations (training) or NULL */
+    float* save_small;         /* [P,64] the non-feature inputs [points, PE(view), normals] (33 valid) or NULL */
     int32_t n_per_ray;
     int32_t P;
     int32_t d_out;             /* 1..4 or 96 */
@@ -102,6 +112,12 @@ typedef struct {
     float* density;            /* [P] raw alpha_linear output (before softplus) */
     float* rgb;                /* [P,3] */
     float* feat;               /* [P,96] dpt_linear output, or NULL when gen_depth_feats is off */
+    /* training-mode saves, optional: */
+    float* save_h;             /* [8,P,256] post-ReLU outputs of pts_linears.0..7 */
+    float* save_pe;            /* [P,96] PE10(pts4) (84 valid) */
+    float* save_feature;       /* [P,256] feature_linear output */
+    float* save_vpe;           /* [P,32] PE4(view) (27 valid) */
+    float* save_hv;            /* [P,128] views_linears.0 output (post-ReLU) */
     int32_t n_per_ray;
     int32_t P;
 } VdnNerfArgs;
@@ -196,6 +212,153 @@ typedef struct {
     float* eik_out;            /* [3]: gradient_error, numerator, denominator */
 } VdnCompositeArgs;
 int vdn_alpha_composite_fwd(const VdnCompositeArgs* args_host, void* stream);
+
+/* ======================= training step: backward of the render path ============================
+ * The reference back-propagates with autograd (dpt_runner.py:253) through renderer.py:209-330 and,
+ * twice, through fields.py:97-108. Here the adjoint is hand-derived (DESIGN.md 'Backward'). */
+
+/* backward of RenderingNetwork (fields.py:148-176): delta chain through W^T with ReLU masks from the
+ * saved activations; emits per-layer deltas for the weight-gradient GEMM and d feature / d normals. */
+typedef struct {
+    const char* blob;          /* 'bwd' stream: W4^T, W3^T, W2^T, W1^T, W0^T */
+    const float* g_out;        /* [P,d_out] gradient wrt the network output */
+    const float* out;          /* [P,d_out] forward output (post sigmoid / relu) */
+    const float* save_h;       /* [4,P,256] from the forward */
+    float* delta_out;          /* [P,32] (d_out<=4) or [P,96]: delta of the last layer */
+    float* delta_h;            /* [4,P,256]: deltas of hidden layers 0..3 */
+    float* d_feat;             /* [P,256] d loss / d feature_vector */
+    float* d_normals;          /* [P,3] */
+    int32_t acc_feat;          /* 0: overwrite d_feat, 1: add into it */
+    int32_t acc_normals;       /* 0: overwrite d_normals, 1: add into it */
+    int32_t P;
+    int32_t d_out;
+    int32_t squeeze_out;
+} VdnRenderNetBwdArgs;
+int vdn_rendernet_bwd_f32(const VdnRenderNetBwdArgs* args_host, void* stream);
+
+/* backward of the background NeRF (fields.py:324-353). */
+typedef struct {
+    const char* blob;          /* 'bwd' stream: Wout^T, Wviews^T, Whead^T, W7^T .. W1^T */
+    const float* g_density;    /* [P] */
+    const float* g_rgb;        /* [P,3] */
+    const float* g_feat;       /* [P,96] or NULL */
+    const float* save_h;       /* [8,P,256] */
+    const float* save_hv;      /* [P,128] */
+    float* delta_o;            /* [P,128] ([P,32] without the dpt head): delta of [rgb | dpt] */
+    float* delta_v;            /* [P,128] delta of views_linears.0 */
+    float* delta_head;         /* [P,288] delta of [feature_linear (256) | alpha_linear (1)] */
+    float* delta_h;            /* [8,P,256] deltas of pts_linears.0..7 */
+    int32_t P;
+} VdnNerfBwdArgs;
+int vdn_nerf_mlp_bwd_f32(const VdnNerfBwdArgs* args_host, void* stream);
+
+/* backward of SDFNetwork.forward + .gradient (fields.py:72-108), i.e. including the double backward
+ * through the input-gradient. Two chains (DESIGN.md 'Backward'):
+ *   rbar: adjoint of the reverse sweep, ascending layers, uses the forward weight images;
+ *   fbar: adjoint of the forward pass, descending layers, uses the transposed images.
+ * Flat workspaces (row-major blocks, P rows each):
+ *   UB = [ub0: 64][ub1: 256][ub2: 256][ub3: 256][ub4: 288][ub5: 256][ub6: 256][ub7: 256][ub8: 256]  (2144 cols total)
+ *   EX = [8][P][256]   second-order term added to the forward adjoint of each hidden layer
+ *   AB = [ab8: 288][ab7: 256] ... [ab0: 256]                                                (2336 cols total) */
+typedef struct {
+    const char* blob;          /* forward stream of the SDF network (hidden layers 0..7 are used) */
+    const float* pts;          /* [P,3] or NULL -> rays */
+    const float* rays_o;
+    const float* rays_d;
+    const float* z;            /* [B,z_ld] */
+    int32_t n_per_ray;
+    int32_t z_ld;
+    int32_t P;
+    float scale;
+    const float* g_normals;    /* [P,3] d loss / d (d sdf/d x) */
+    const float* S;            /* [8,P,256] from the forward */
+    const float* V;            /* [8,P,256] from the forward */
+    float* UB;                 /* out, see above */
+    float* EX;                 /* out */
+} VdnSdfRbarArgs;
+int vdn_sdf_bwd_rbar_f32(const VdnSdfRbarArgs* args_host, void* stream);
+
+typedef struct {
+    const char* blob;          /* 'fbar' stream: W8^T, W7^T .. W1^T */
+    const float* g_sdf;        /* [P] */
+    const float* g_feat;       /* [P,256] */
+    const float* S;            /* [8,P,256] */
+    const float* EX;           /* [8,P,256] from rbar */
+    float* AB;                 /* out, see above */
+    int32_t P;
+    float scale;
+} VdnSdfFbarArgs;
+int vdn_sdf_bwd_fbar_f32(const VdnSdfFbarArgs* args_host, void* stream);
+
+/* ---- weight gradients: dW[m,n] = sum_p A[p,m] * B[p,n] over one or two (A,B) segments ----------
+ * (A = per-layer delta, B = the layer's input; the second segment carries the sweep term of the SDF
+ * net). K is split across workgroups; partial slabs are reduced and scattered by vdn_dw_finalize. */
+typedef struct {
+    const float* A1; const float* B1;     /* [P,lda1], [P,ldb1] */
+    const float* A2; const float* B2;     /* second segment or NULL */
+    int32_t lda1, ldb1, lda2, ldb2;
+    int32_t P;
+    int32_t m_tiles, n_tiles;             /* 32-wide column tiles of A (outputs) and B (inputs); n_tiles may be 0 */
+    int32_t splits;
+    int32_t wg_begin;                     /* prefix sum of workgroups over the descriptor list */
+    int32_t _pad;
+    float* slab;                          /* [splits, m_tiles*32, n_tiles*32] partial products */
+    float* colsum;                        /* [splits, m_tiles*32] partial column sums of A1, or NULL */
+} VdnDwDesc;
+int vdn_dw_gemm_f32(const VdnDwDesc* descs_dev, int n_desc, int total_wgs, void* stream);
+
+/* reduce the K-splits and scatter from image coordinates to the parameter's own layout:
+ * target[rmap[i]*t_stride + cmap[j]] (+)= scale * sum_s slab[s,i,j];  btarget[rmap[i]] (+)= bscale * sum_s colsum[s,i] */
+typedef struct {
+    const float* slab; const float* colsum;
+    const int32_t* rmap; const int32_t* cmap;
+    float* target; float* btarget;         /* either may be NULL */
+    int64_t t_stride;
+    int32_t splits, M, N;                  /* M = m_tiles*32, N = n_tiles*32 */
+    int32_t accumulate;                    /* 0: '=' (phase 0), 1: '+=' (phase 1) */
+    float scale, bscale;
+} VdnDwFinalizeDesc;
+int vdn_dw_finalize(const VdnDwFinalizeDesc* descs_dev, int n_desc, int max_M, int phase, void* stream);
+
+/* weight-norm backward: dg_r = <dW_r, v_r>/||v_r||;  dv_r = g_r/||v_r|| * (dW_r - <dW_r,v_r>/||v_r||^2 * v_r) */
+typedef struct {
+    const float* g; const float* v; const float* inv_norm; const float* dw_eff;
+    float* dg; float* dv;
+    int32_t rows, cols;
+} VdnWeightNormBwdDesc;
+int vdn_weightnorm_bwd(const VdnWeightNormBwdDesc* descs_dev, int n_layers, int max_rows, void* stream);
+
+/* ---- adjoint of vdn_alpha_composite_fwd (renderer.py:262-315) ---------------------------------- */
+typedef struct {
+    /* forward inputs */
+    const float* rays_o; const float* rays_d;
+    const float* sdf; const float* normals; const float* dists; const float* mid_z;
+    const float* color; const float* feat; const float* variance;
+    const float* bg_density; const float* bg_rgb; const float* bg_feat; const float* bg_dists;
+    const float* background_rgb;
+    float cos_anneal_ratio;
+    int32_t B, N, T, feat_ch;
+    /* saved forward results */
+    const float* alpha;        /* [B,T] blended alpha */
+    const float* weights;      /* [B,T] */
+    const float* eik;          /* [3] gradient_error, numerator, denominator */
+    /* upstream gradients (any may be NULL = zero) */
+    const float* g_color;      /* [B,3] */
+    const float* g_feat;       /* [B,C] */
+    const float* g_weights;    /* [B,T] */
+    const float* g_eik;        /* [1] d loss / d gradient_error */
+    /* outputs */
+    float* d_sdf;              /* [B*N] */
+    float* d_normals;          /* [B*N,3] alpha + eikonal parts */
+    float* d_color;            /* [B*N,3] wrt the colour head's output */
+    float* d_feat;             /* [B*N,C] wrt the VDN head's output, or NULL */
+    float* d_bg_density;       /* [B*T] */
+    float* d_bg_rgb;           /* [B*T,3] */
+    float* d_bg_feat;          /* [B*T,C] or NULL */
+    float* d_var_partial;      /* [B] per-ray d loss / d variance */
+    float* d_variance;         /* [1] */
+} VdnCompositeBwdArgs;
+int vdn_alpha_composite_bwd(const VdnCompositeBwdArgs* args_host, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,230 @@
+"""GPU parity of the hand-derived backward: d loss / d every parameter through NeuSRenderer.render
+(custom autograd node -> HIP kernels) against the oracle's autograd and the reference's own gradient
+samples in the golden fixtures. z is injected (the sampler is a no-grad stage). Tolerance: 1e-4 of the
+largest entry of each gradient tensor vs the fp64 oracle (BASELINE north-star; SURVEY.md 4 'backward')."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def g(x, dev):
+    return torch.as_tensor(np.asarray(x), dtype=torch.float32).to(dev)
+
+
+def _loss(out, true_rgb, gt_feats, wdepth, mask_weight=0.0):
+    B = true_rgb.shape[0]
+    mask_sum = B + 1e-5
+    loss = (out["color_fine"] - true_rgb).abs().sum() / mask_sum + out["gradient_error"] * 0.1
+    if wdepth:
+        loss = loss + (out["render_feats"] - gt_feats).abs().sum() / mask_sum * 0.7
+    if mask_weight:
+        loss = loss + torch.nn.functional.binary_cross_entropy(out["weight_sum"].clip(1e-3, 1.0 - 1e-3),
+                                                               torch.ones_like(out["weight_sum"])) * mask_weight
+    return loss
+
+
+def _gpu_grads(fx, dev, mask_weight=0.0, **kw):
+    from vdn_train import synth, factory
+    wdepth = bool(fx["wdepth"])
+    st = synth.make_all_states(int(fx["seed"]), wdepth=wdepth, variance=float(fx["variance"]))
+    rend = factory.build_renderer(wdepth=wdepth, device=dev, states=st, n_importance=int(fx["n_importance"]), **kw)
+    z_inj = g(fx["z_vals_inside"], dev) if fx["n_importance"] > 0 else None
+    out = rend.render(g(fx["rays_o"], dev), g(fx["rays_d"], dev), g(fx["near"], dev), g(fx["far"], dev),
+                      perturb_overwrite=(-1 if fx["perturb"] > 0 else 0),
+                      background_rgb=torch.ones(1, 3, device=dev) if fx["white"] else None,
+                      cos_anneal_ratio=float(fx["cos_anneal"]), t_rand=g(fx["t_rand"], dev), t_rand_out=g(fx["t_rand_out"], dev),
+                      z_vals_inject=z_inj)
+    loss = _loss(out, g(fx["true_rgb"], dev), g(fx["gt_feats"], dev) if wdepth else None, wdepth, mask_weight)
+    loss.backward()
+    named = []
+    for key, mod in (("nerf", rend.nerf), ("sdf", rend.sdf_network), ("variance", rend.deviation_network),
+                     ("color", rend.color_network), ("vdn", rend.depth_network)):
+        if mod is None:
+            continue
+        for n, p in mod.named_parameters():
+            named.append((key + "." + n if key != "variance" else "variance", p))
+    return loss.item(), named, out
+
+
+def _oracle_grads(fx, dtype, mask_weight=0.0):
+    import oracle.neus_oracle as orc
+    from vdn_train import synth
+    wdepth = bool(fx["wdepth"])
+    st = synth.make_all_states(int(fx["seed"]), wdepth=wdepth, variance=float(fx["variance"]))
+    nets = orc.nets_from_numpy(st, dtype=dtype, requires_grad=True)
+    tt = lambda x: torch.tensor(np.asarray(x), dtype=dtype)
+    out = orc.render(nets, tt(fx["rays_o"]), tt(fx["rays_d"]), tt(fx["near"]), tt(fx["far"]),
+                     orc.RendererConf(n_importance=int(fx["n_importance"])),
+                     perturb_overwrite=(-1 if fx["perturb"] > 0 else 0),
+                     background_rgb=torch.ones(1, 3, dtype=dtype) if fx["white"] else None,
+                     cos_anneal_ratio=float(fx["cos_anneal"]), t_rand=tt(fx["t_rand"]), t_rand_out=tt(fx["t_rand_out"]),
+                     z_vals_inject=tt(fx["z_vals_inside"]) if fx["n_importance"] > 0 else None)
+    loss = _loss(out, tt(fx["true_rgb"]), tt(fx["gt_feats"]) if wdepth else None, wdepth, mask_weight)
+    named = orc.all_params(nets)
+    gs = torch.autograd.grad(loss, [p for _, p in named], allow_unused=True)
+    return loss.item(), {n: (torch.zeros_like(p) if gr is None else gr).detach() for (n, p), gr in zip(named, gs)}
+
+
+def _compare(named, ref, tol, ref32=None):
+    """rel-to-max error of every gradient tensor vs the fp64 oracle. Where the fp32 oracle (= what the fp32
+    reference computes) is itself further than `tol` from fp64 - tiny, cancellation-dominated gradients such as
+    the background NeRF's first layers (|g| ~ 1e-5) - the bound is 3x that measured fp32 floor instead."""
+    #
+    # ReLU sign flips: a hidden unit whose pre-activation is within ~1e-7 of zero is 'on' in one fp32 evaluation
+    # and 'off' in another (or in fp64). With ~3e6 unit-points per evaluation a few such flips are inevitable; each
+    # moves one row of one weight gradient by one point's contribution, which is a visible fraction of the total
+    # only because the fixtures hold 16-24 rays. Such an isolated difference is accepted when the tensor's
+    # Frobenius-relative error is within tolerance and the max error stays below 1e-2;
+    # test_param_grads_larger_batch checks the plain max criterion where flips are diluted.
+    rows, bad = [], []
+    for n, p in named:
+        gg = p.grad
+        assert gg is not None, n
+        a, b = gg.detach().cpu().double().numpy(), ref[n].double().numpy()
+        assert a.shape == b.shape, n
+        scale = np.abs(b).max()
+        err = np.abs(a - b).max() / (scale + 1e-30) if scale > 0 else np.abs(a).max()
+        fro = np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30)
+        floor = floor_f = 0.0
+        if ref32 is not None and scale > 0:
+            c = ref32[n].double().numpy()
+            floor = np.abs(c - b).max() / scale
+            floor_f = np.linalg.norm(c - b) / (np.linalg.norm(b) + 1e-30)
+        rows.append((err, n, scale, floor))
+        ok = err < max(tol, 3 * floor) or (fro < max(tol, 3 * floor_f) and err < 1e-2)
+        if not ok:
+            bad.append(n)
+    rows.sort(reverse=True)
+    report = "\n".join("%-36s err %.2e  fp32-floor %.2e  |g|max %.2e" % (n, e, fl, s) for e, n, s, fl in rows[:12])
+    assert not bad, "gradient errors beyond max(%.0e, 3x fp32 floor) in %s\n%s" % (tol, bad, report)
+    return rows
+
+
+@pytest.mark.parametrize("name", ["white_v03_c0", "white_v03_c05_det", "wdepth_v03_c05", "white_n64_v03"])
+def test_param_grads_vs_oracle_fp64(golden, name):
+    dev = torch.device("cuda:0")
+    fx = golden(name)
+    loss, named, _ = _gpu_grads(fx, dev)
+    ref_loss, ref = _oracle_grads(fx, torch.float64)
+    _, ref32 = _oracle_grads(fx, torch.float32)
+    assert abs(loss - ref_loss) < 2e-5 * abs(ref_loss)
+    assert abs(loss - float(fx["loss"])) < 2e-5 * abs(float(fx["loss"]))      # the reference's own loss
+    rows = _compare(named, ref, 1e-4, ref32)
+    # the bulk of the parameters must be at 1e-4 outright (not only within the floor)
+    assert sum(1 for e, *_ in rows if e < 1e-4) >= 0.8 * len(rows)
+    # the reference's own gradients (fp32 CPU autograd; sampled entries + norms in the fixture)
+    floors = {n: fl for _, n, _, fl in rows}
+    for n, p in named:
+        rv = fx["grad_val/" + n]
+        gv = p.grad.detach().cpu().reshape(-1)[torch.as_tensor(fx["grad_idx/" + n])].numpy()
+        tol = max(3e-4, 6 * floors[n])
+        assert np.abs(gv - rv).max() <= tol * np.abs(ref[n].numpy()).max() + 1e-12, n
+        rn = float(fx["grad_norm/" + n])
+        assert abs(float(p.grad.norm()) - rn) <= max(1e-4, 3 * floors[n]) * rn + 1e-12, n
+
+
+def test_param_grads_with_mask_loss_and_high_inv_s(golden):
+    """weight_sum (BCE mask loss, dpt_runner.py:233) and the inv_s = 665 regime. At inv_s = 665 the fp32 reference
+    itself is 1e-2 away from fp64 on some SDF gradients (tests/golden/make_golden.py), so the comparison is
+    against the fp32 oracle with the noise floor measured between the fp32 and fp64 oracles."""
+    dev = torch.device("cuda:0")
+    fx = golden("white_v03_c0")
+    loss, named, _ = _gpu_grads(fx, dev, mask_weight=0.3)
+    ref_loss, ref = _oracle_grads(fx, torch.float64, mask_weight=0.3)
+    _, ref32 = _oracle_grads(fx, torch.float32, mask_weight=0.3)
+    assert abs(loss - ref_loss) < 2e-5 * abs(ref_loss)
+    _compare(named, ref, 1e-4, ref32)
+    fx = golden("white_v065_c1")
+    loss, named, _ = _gpu_grads(fx, dev)
+    _, ref64 = _oracle_grads(fx, torch.float64)
+    _, ref32 = _oracle_grads(fx, torch.float32)
+    _compare(named, ref64, 1e-4, ref32)
+
+
+def test_no_outside_samples_and_second_step(golden):
+    """n_outside = 0 (no background pass: NeRF gets no gradient) and two consecutive steps on one engine."""
+    import oracle.neus_oracle as orc
+    from vdn_train import synth, factory
+    dev = torch.device("cuda:0")
+    B = 8
+    st = synth.make_all_states(31, wdepth=False)
+    rend = factory.build_renderer(device=dev, states=st, n_outside=0)
+    nets = orc.nets_from_numpy(st, dtype=torch.float64, requires_grad=True)
+    cams = synth.make_cameras(31)
+    px = np.floor(synth.uniform(31, "no/x", (B,)) * 300) + 250
+    py = np.floor(synth.uniform(31, "no/y", (B,)) * 300) + 250
+    o, d = synth.pixel_rays(cams[1], px, py)
+    near, far = synth.near_far_from_sphere(o, d)
+    target = synth.target_colors(o, d)
+    for step in range(2):
+        out = rend.render(g(o, dev), g(d, dev), g(near, dev), g(far, dev), perturb_overwrite=0, cos_anneal_ratio=1.0)
+        z = None
+        loss = (out["color_fine"] - g(target, dev)).abs().sum() / B + 0.1 * out["gradient_error"]
+        for m in (rend.sdf_network, rend.color_network, rend.deviation_network, rend.nerf):
+            m.zero_grad(set_to_none=True)
+        loss.backward()
+    assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in rend.nerf.parameters())
+    t64 = lambda x: torch.tensor(x, dtype=torch.float64)
+    conf = orc.RendererConf(n_outside=0)
+    # same z as the GPU used: take the GPU's inside z through its sampler
+    zg, _ = rend._sample(g(o, dev), g(d, dev), g(near, dev).reshape(-1), g(far, dev).reshape(-1), 0.0, None, None, None)
+    ref = orc.render(nets, t64(o), t64(d), t64(near), t64(far), conf, perturb_overwrite=0, cos_anneal_ratio=1.0,
+                     z_vals_inject=zg.cpu().double())
+    rl = (ref["color_fine"] - t64(target)).abs().sum() / B + 0.1 * ref["gradient_error"]
+    named = [(n, p) for n, p in orc.all_params(nets) if not n.startswith("nerf.")]
+    gs = torch.autograd.grad(rl, [p for _, p in named])
+    refd = {n: gr for (n, _), gr in zip(named, gs)}
+    got = [("sdf." + n, p) for n, p in rend.sdf_network.named_parameters()] + [("variance", rend.deviation_network.variance)] + \
+          [("color." + n, p) for n, p in rend.color_network.named_parameters()]
+    _compare(got, refd, 1e-4)
+
+
+def test_param_grads_larger_batch():
+    """192 rays: single ReLU flips are diluted, so the plain criterion max|dg| / max|g| < max(1e-4, 3x fp32 floor)
+    is applied to every parameter tensor, against the fp64 oracle."""
+    import oracle.neus_oracle as orc
+    from vdn_train import synth, factory
+    dev = torch.device("cuda:0")
+    B, seed = 192, 41
+    st = synth.make_all_states(seed, wdepth=True)
+    rend = factory.build_renderer(wdepth=True, device=dev, states=st)
+    cams = synth.make_cameras(seed)
+    px = np.floor(synth.uniform(seed, "lb/x", (B,)) * 520) + 140
+    py = np.floor(synth.uniform(seed, "lb/y", (B,)) * 520) + 140
+    o, d = synth.pixel_rays(cams[3], px, py)
+    near, far = synth.near_far_from_sphere(o, d)
+    t1, t2 = synth.jitter(seed, 0, B)
+    target = synth.target_colors(o, d)
+    gtf = synth.uniform(seed, "lb/f", (B, 96)).astype(np.float32)
+    with torch.no_grad():
+        z, _ = rend._sample(g(o, dev), g(d, dev), g(near, dev).reshape(-1), g(far, dev).reshape(-1), 1.0, g(t1, dev), g(t2, dev), None)
+    out = rend.render(g(o, dev), g(d, dev), g(near, dev), g(far, dev), background_rgb=torch.ones(1, 3, device=dev),
+                      cos_anneal_ratio=0.4, t_rand=g(t1, dev), t_rand_out=g(t2, dev), z_vals_inject=z)
+    loss = _loss(out, g(target, dev), g(gtf, dev), True)
+    loss.backward()
+    named = []
+    for key, mod in (("nerf", rend.nerf), ("sdf", rend.sdf_network), ("variance", rend.deviation_network),
+                     ("color", rend.color_network), ("vdn", rend.depth_network)):
+        named += [(key + "." + n if key != "variance" else "variance", p) for n, p in mod.named_parameters()]
+    refs = {}
+    for dt in (torch.float64, torch.float32):
+        nets = orc.nets_from_numpy(st, dtype=dt, requires_grad=True)
+        tt = lambda x: torch.tensor(np.asarray(x), dtype=dt)
+        ro = orc.render(nets, tt(o), tt(d), tt(near), tt(far), background_rgb=torch.ones(1, 3, dtype=dt), cos_anneal_ratio=0.4,
+                        t_rand=tt(t1), t_rand_out=tt(t2), z_vals_inject=z.cpu().to(dt))
+        rl = _loss(ro, tt(target), tt(gtf), True)
+        nm = orc.all_params(nets)
+        gs = torch.autograd.grad(rl, [p for _, p in nm])
+        refs[dt] = ({n: gr for (n, _), gr in zip(nm, gs)}, rl.item())
+    assert abs(loss.item() - refs[torch.float64][1]) < 2e-5 * abs(refs[torch.float64][1])
+    bad = []
+    for n, p in named:
+        b = refs[torch.float64][0][n].double().numpy()
+        scale = np.abs(b).max()
+        err = np.abs(p.grad.cpu().double().numpy() - b).max() / scale
+        floor = np.abs(refs[torch.float32][0][n].double().numpy() - b).max() / scale
+        if err >= max(1e-4, 3 * floor):
+            bad.append((n, err, floor))
+    assert not bad, bad

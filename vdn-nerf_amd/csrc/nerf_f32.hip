@@ -14,11 +14,32 @@ using NfStream = WStream<kNfWaves, kNfSlot>;
 
 struct ReluIntoN {
     float* Y;
+    float* save;    // row-major slice [P,ld] or nullptr
+    int ld;
+    long row;
+    bool ok;
+    int h;
     VDN_DEV void operator()(int nt, const f32x16& acc, int) const {
+        f32x16 o;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) Y[nt * 16 + t] = fmaxf(acc[t], 0.0f);
+        for (int t = 0; t < 16; ++t) {
+            o[t] = fmaxf(acc[t], 0.0f);
+            Y[nt * 16 + t] = o[t];
+        }
+        if (save != nullptr) store_tile_rowmajor(save, row, ld, nt, h, o, ok);
     }
 };
+template <int NTILES>
+VDN_DEV void save_tiles(float* dst, int ld, const float* X, long row, int h, bool ok) {
+    if (dst == nullptr) return;
+#pragma unroll
+    for (int kt = 0; kt < NTILES; ++kt) {
+        f32x16 t16;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) t16[t] = X[kt * 16 + t];
+        store_tile_rowmajor(dst, row, ld, kt, h, t16, ok);
+    }
+}
 
 template <bool DPT>
 __global__ __launch_bounds__(kNfWaves * 64, 1) void nerf_f32_kernel(NerfArgs a) {
@@ -60,24 +81,28 @@ __global__ __launch_bounds__(kNfWaves * 64, 1) void nerf_f32_kernel(NerfArgs a) 
     constexpr int C3 = chunk_bytes_f32(3), C8 = chunk_bytes_f32(8), C9 = chunk_bytes_f32(9), C11 = chunk_bytes_f32(11),
                   C4 = chunk_bytes_f32(4);
     put_pe(X);
+    save_tiles<3>(a.save_pe, 96, X, p, h, ok);
+    const long PS = (long)a.P * 256;
+    auto sv = [&](int l) { return a.save_h ? a.save_h + l * PS : nullptr; };
     ws.start<C3>();
-    dense_f32<3, 8, C8, true>(ws, X, NoPre{}, ReluIntoN{Y});          // pts_linears.0
-    dense_f32<8, 8, C8, true>(ws, Y, NoPre{}, ReluIntoN{X});          // 1
-    dense_f32<8, 8, C8, true>(ws, X, NoPre{}, ReluIntoN{Y});          // 2
-    dense_f32<8, 8, C8, true>(ws, Y, NoPre{}, ReluIntoN{X});          // 3
-    dense_f32<8, 8, C11, true>(ws, X, NoPre{}, ReluIntoN{Y});         // 4
+    dense_f32<3, 8, C8, true>(ws, X, NoPre{}, ReluIntoN{Y, sv(0), 256, p, ok, h});          // pts_linears.0
+    dense_f32<8, 8, C8, true>(ws, Y, NoPre{}, ReluIntoN{X, sv(1), 256, p, ok, h});          // 1
+    dense_f32<8, 8, C8, true>(ws, X, NoPre{}, ReluIntoN{Y, sv(2), 256, p, ok, h});          // 2
+    dense_f32<8, 8, C8, true>(ws, Y, NoPre{}, ReluIntoN{X, sv(3), 256, p, ok, h});          // 3
+    dense_f32<8, 8, C11, true>(ws, X, NoPre{}, ReluIntoN{Y, sv(4), 256, p, ok, h});         // 4
     // skip (fields.py:334-335): h = cat([input_pts, h]) -> X = [PE (3 tiles) | h (8 tiles)]
 #pragma unroll
     for (int i = 0; i < 128; ++i) X[48 + i] = Y[i];
     put_pe(X);
-    dense_f32<11, 8, C8, true>(ws, X, NoPre{}, ReluIntoN{Y});         // 5
-    dense_f32<8, 8, C8, true>(ws, Y, NoPre{}, ReluIntoN{X});          // 6
-    dense_f32<8, 8, C8, true>(ws, X, NoPre{}, ReluIntoN{Y});          // 7
+    dense_f32<11, 8, C8, true>(ws, X, NoPre{}, ReluIntoN{Y, sv(5), 256, p, ok, h});         // 5
+    dense_f32<8, 8, C8, true>(ws, Y, NoPre{}, ReluIntoN{X, sv(6), 256, p, ok, h});          // 6
+    dense_f32<8, 8, C8, true>(ws, X, NoPre{}, ReluIntoN{Y, sv(7), 256, p, ok, h});          // 7
     // heads on h: image rows 0..255 feature_linear, row 256 alpha_linear
     dense_f32<8, 9, C9, true>(ws, Y, NoPre{}, [&](int nt, const f32x16& acc, int) {
         if (nt < 8) {
 #pragma unroll
             for (int t = 0; t < 16; ++t) X[nt * 16 + t] = acc[t];
+            if (a.save_feature != nullptr) store_tile_rowmajor(a.save_feature, p, 256, nt, h, acc, ok);
         } else {
             if (ok && h == 0) a.density[p] = acc[0];
         }
@@ -86,8 +111,9 @@ __global__ __launch_bounds__(kNfWaves * 64, 1) void nerf_f32_kernel(NerfArgs a) 
         float pe[27];
         posenc<3, 4>(dir, pe);
         vals_to_tiles<27, 1>(pe, h, X + 128);
+        save_tiles<1>(a.save_vpe, 32, X + 128, p, h, ok);
     }
-    dense_f32<9, 4, C4, true>(ws, X, NoPre{}, ReluIntoN{Y});
+    dense_f32<9, 4, C4, true>(ws, X, NoPre{}, ReluIntoN{Y, a.save_hv, 128, p, ok, h});
     // rgb_linear (image tile 0, rows 0..2) and dpt_linear (image tiles 1..3)
     dense_f32<4, DPT ? 4 : 1, 0, true>(ws, Y, NoPre{}, [&](int nt, const f32x16& acc, int) {
         if (nt == 0) {

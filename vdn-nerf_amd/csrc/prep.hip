@@ -38,6 +38,8 @@ __device__ inline unsigned short f32_to_bf16_rn(float f) {
 __global__ void build_images_kernel(const ChunkDesc* descs) {
     const ChunkDesc d = descs[blockIdx.x];
     const int kt = d.k_pad / 32;
+    const int kt0 = d.kt_count > 0 ? d.kt_begin : 0;
+    const int ktn = d.kt_count > 0 ? d.kt_count : kt;
     auto val = [&](int i, int k) -> float {
         const int r = d.nmap[d.n0 + i];
         const int c = d.kmap[k];
@@ -45,8 +47,8 @@ __global__ void build_images_kernel(const ChunkDesc* descs) {
     };
     if (d.fmt == 0) {
         // [kt*4 groups][64 lanes][4] f32, then 32 bias floats, zero pad to 1 KiB
-        float* out = reinterpret_cast<float*>(d.dst);
-        const int n4 = kt * 4 * 64;
+        float* out = reinterpret_cast<float*>(d.dst) + (long)kt0 * 1024;
+        const int n4 = ktn * 4 * 64;
         for (int idx = threadIdx.x; idx < n4; idx += blockDim.x) {
             const int g = idx >> 6, lane = idx & 63, i = lane & 31, h = lane >> 5;
             float4 o;
@@ -56,8 +58,8 @@ __global__ void build_images_kernel(const ChunkDesc* descs) {
             o.w = val(i, 8 * g + 4 * h + 3);
             reinterpret_cast<float4*>(out)[idx] = o;
         }
-        float* b = out + (long)kt * 1024;
-        for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        float* b = reinterpret_cast<float*>(d.dst) + (long)kt * 1024;
+        for (int i = threadIdx.x; i < 256 && d.write_bias; i += blockDim.x) {
             float bv = 0.0f;
             if (i < 32 && d.bias != nullptr) {
                 const int r = d.nmap[d.n0 + i];
@@ -68,8 +70,8 @@ __global__ void build_images_kernel(const ChunkDesc* descs) {
     } else {
         // bf16: [kt*2 k-steps][64 lanes][8 bf16] (lane (i,h), element j: k = 16s + 8(j>>2) + 4h + (j&3)),
         // then 32 f32 bias, zero pad to 1 KiB
-        unsigned short* out = reinterpret_cast<unsigned short*>(d.dst);
-        const int n8 = kt * 2 * 64;
+        unsigned short* out = reinterpret_cast<unsigned short*>(d.dst) + (long)kt0 * 1024;
+        const int n8 = ktn * 2 * 64;
         for (int idx = threadIdx.x; idx < n8; idx += blockDim.x) {
             const int s = idx >> 6, lane = idx & 63, i = lane & 31, h = lane >> 5;
             unsigned short o[8];
@@ -83,7 +85,7 @@ __global__ void build_images_kernel(const ChunkDesc* descs) {
             reinterpret_cast<uint4*>(out)[idx] = pk;
         }
         float* b = reinterpret_cast<float*>(d.dst + (long)kt * 2048);
-        for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        for (int i = threadIdx.x; i < 256 && d.write_bias; i += blockDim.x) {
             float bv = 0.0f;
             if (i < 32 && d.bias != nullptr) {
                 const int r = d.nmap[d.n0 + i];

@@ -14,9 +14,18 @@ using RnStream = WStream<kRnWaves, kRnSlot>;
 
 struct ReluInto {
     float* Y;
+    float* save;    // [P,256] slice or nullptr
+    long row;
+    bool ok;
+    int h;
     VDN_DEV void operator()(int nt, const f32x16& acc, int) const {
+        f32x16 o;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) Y[nt * 16 + t] = fmaxf(acc[t], 0.0f);
+        for (int t = 0; t < 16; ++t) {
+            o[t] = fmaxf(acc[t], 0.0f);
+            Y[nt * 16 + t] = o[t];
+        }
+        if (save != nullptr) store_tile_rowmajor(save, row, 256, nt, h, o, ok);
     }
 };
 
@@ -49,13 +58,24 @@ __global__ __launch_bounds__(kRnWaves * 64, 1) void rendernet_f32_kernel(RenderN
 #pragma unroll
         for (int i = 0; i < 27; ++i) small[3 + i] = pe[i];
         vals_to_tiles<33, 2>(small, h, X + 128);
+        if (a.save_small != nullptr) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                f32x16 t16;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) t16[t] = X[128 + kt * 16 + t];
+                store_tile_rowmajor(a.save_small, p, 64, kt, h, t16, ok);
+            }
+        }
     }
+    const long PS = (long)a.P * 256;
+    auto sv = [&](int l) { return a.save_h ? a.save_h + l * PS : nullptr; };
     constexpr int C10 = chunk_bytes_f32(10), C8 = chunk_bytes_f32(8);
     ws.start<C10>();
-    dense_f32<10, 8, C8, true>(ws, X, NoPre{}, ReluInto{Y});
-    dense_f32<8, 8, C8, true>(ws, Y, NoPre{}, ReluInto{X});
-    dense_f32<8, 8, C8, true>(ws, X, NoPre{}, ReluInto{Y});
-    dense_f32<8, 8, C8, true>(ws, Y, NoPre{}, ReluInto{X});
+    dense_f32<10, 8, C8, true>(ws, X, NoPre{}, ReluInto{Y, sv(0), p, ok, h});
+    dense_f32<8, 8, C8, true>(ws, Y, NoPre{}, ReluInto{X, sv(1), p, ok, h});
+    dense_f32<8, 8, C8, true>(ws, X, NoPre{}, ReluInto{Y, sv(2), p, ok, h});
+    dense_f32<8, 8, C8, true>(ws, Y, NoPre{}, ReluInto{X, sv(3), p, ok, h});
     dense_f32<8, NT_OUT, 0, true>(ws, X, NoPre{}, [&](int nt, const f32x16& acc, int) {
         f32x16 o;
 #pragma unroll

@@ -20,6 +20,7 @@ struct HiddenEpi {
     long row;
     bool ok;
     int h;
+    float* Hs;      // [P,256] slice to keep the activation itself (training) or nullptr
     VDN_DEV void operator()(int nt, const f32x16& acc, int) const {
         f32x16 s;
 #pragma unroll
@@ -33,7 +34,15 @@ struct HiddenEpi {
                 Y[nt * 16 + t] = softplus100_fast(acc[t]);
             }
         }
-        if constexpr (SAVE) store_tile_rowmajor(S, row, 256, nt, h, s, ok);
+        if constexpr (SAVE) {
+            store_tile_rowmajor(S, row, 256, nt, h, s, ok);
+            if (Hs != nullptr) {
+                f32x16 hv;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) hv[t] = Y[nt * 16 + t];
+                store_tile_rowmajor(Hs, row, 256, nt, h, hv, ok);
+            }
+        }
     }
 };
 
@@ -66,25 +75,36 @@ __global__ __launch_bounds__(kSdfWaves * 64, 1) void sdf_f32_kernel(SdfArgs a) {
         float pe[39];
         posenc<3, 6>(xin, pe);
         vals_to_tiles<39, 2>(pe, h, X);
+        if constexpr (MODE == 1) {
+            if (a.PE != nullptr) {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    f32x16 t16;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) t16[t] = X[kt * 16 + t];
+                    store_tile_rowmajor(a.PE, p, 64, kt, h, t16, ok);
+                }
+            }
+        }
     }
     constexpr int C2 = chunk_bytes_f32(2), C7 = chunk_bytes_f32(7), C8 = chunk_bytes_f32(8), C9 = chunk_bytes_f32(9);
     constexpr bool SV = (MODE == 1);
     float* S = a.S;
     const long PS = (long)a.P * 256;
     ws.start<C2>();
-    dense_f32<2, 8, C8, true>(ws, X, NoPre{}, HiddenEpi<SV>{Y, S + 0 * PS, p, ok, h});
-    dense_f32<8, 8, C8, true>(ws, Y, NoPre{}, HiddenEpi<SV>{X, S + 1 * PS, p, ok, h});
-    dense_f32<8, 8, C8, true>(ws, X, NoPre{}, HiddenEpi<SV>{Y, S + 2 * PS, p, ok, h});
-    dense_f32<8, 7, C9, true>(ws, Y, NoPre{}, HiddenEpi<SV>{X, S + 3 * PS, p, ok, h});
+    dense_f32<2, 8, C8, true>(ws, X, NoPre{}, HiddenEpi<SV>{Y, S + 0 * PS, p, ok, h, (SV && a.H) ? a.H + 0 * PS : nullptr});
+    dense_f32<8, 8, C8, true>(ws, Y, NoPre{}, HiddenEpi<SV>{X, S + 1 * PS, p, ok, h, (SV && a.H) ? a.H + 1 * PS : nullptr});
+    dense_f32<8, 8, C8, true>(ws, X, NoPre{}, HiddenEpi<SV>{Y, S + 2 * PS, p, ok, h, (SV && a.H) ? a.H + 2 * PS : nullptr});
+    dense_f32<8, 7, C9, true>(ws, Y, NoPre{}, HiddenEpi<SV>{X, S + 3 * PS, p, ok, h, (SV && a.H) ? a.H + 3 * PS : nullptr});
     {   // skip: layer-4 input = [h4 (217, padded to 7 tiles) | PE (39, 2 tiles)] / sqrt2 (1/sqrt2 is in the image)
         float pe[39];
         posenc<3, 6>(xin, pe);
         vals_to_tiles<39, 2>(pe, h, X + 112);
     }
-    dense_f32<9, 8, C8, true>(ws, X, NoPre{}, HiddenEpi<SV>{Y, S + 4 * PS, p, ok, h});
-    dense_f32<8, 8, C8, true>(ws, Y, NoPre{}, HiddenEpi<SV>{X, S + 5 * PS, p, ok, h});
-    dense_f32<8, 8, C8, true>(ws, X, NoPre{}, HiddenEpi<SV>{Y, S + 6 * PS, p, ok, h});
-    dense_f32<8, 8, C8, true>(ws, Y, NoPre{}, HiddenEpi<SV>{X, S + 7 * PS, p, ok, h});
+    dense_f32<9, 8, C8, true>(ws, X, NoPre{}, HiddenEpi<SV>{Y, S + 4 * PS, p, ok, h, (SV && a.H) ? a.H + 4 * PS : nullptr});
+    dense_f32<8, 8, C8, true>(ws, Y, NoPre{}, HiddenEpi<SV>{X, S + 5 * PS, p, ok, h, (SV && a.H) ? a.H + 5 * PS : nullptr});
+    dense_f32<8, 8, C8, true>(ws, X, NoPre{}, HiddenEpi<SV>{Y, S + 6 * PS, p, ok, h, (SV && a.H) ? a.H + 6 * PS : nullptr});
+    dense_f32<8, 8, C8, true>(ws, Y, NoPre{}, HiddenEpi<SV>{X, S + 7 * PS, p, ok, h, (SV && a.H) ? a.H + 7 * PS : nullptr});
 
     const float inv_scale = 1.0f / a.scale;
     if constexpr (MODE == 0) {
@@ -110,16 +130,26 @@ __global__ __launch_bounds__(kSdfWaves * 64, 1) void sdf_f32_kernel(SdfArgs a) {
         for (int kt = 0; kt < 8; ++kt) {
             const f32x16 w8 = load_tile_rowmajor_v(a.w8row, 0, 0, kt, h);
             const f32x16 s7 = load_tile_rowmajor_v(S + 7 * PS, p, 256, kt, h);
+            f32x16 v7;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) Y[kt * 16 + t] = w8[t] * inv_scale * s7[t];
+            for (int t = 0; t < 16; ++t) {
+                v7[t] = w8[t] * inv_scale * s7[t];
+                Y[kt * 16 + t] = v7[t];
+            }
+            if (a.V != nullptr) store_tile_rowmajor(a.V + 7 * PS, p, 256, kt, h, v7, ok);
         }
         auto loadS = [&](int layer) {
             return [=](int nt) { return load_tile_rowmajor_v(S + layer * PS, p, 256, nt, h); };
         };
-        auto mulInto = [](float* D) {
-            return [D](int nt, const f32x16& acc, const f32x16& sv) {
+        auto mulInto = [&](float* D, int layer) {     // D <- v_layer = u (.) s_layer; optionally kept for the backward
+            return [=](int nt, const f32x16& acc, const f32x16& sv) {
+                f32x16 v;
 #pragma unroll
-                for (int t = 0; t < 16; ++t) D[nt * 16 + t] = acc[t] * sv[t];
+                for (int t = 0; t < 16; ++t) {
+                    v[t] = acc[t] * sv[t];
+                    D[nt * 16 + t] = v[t];
+                }
+                if (a.V != nullptr) store_tile_rowmajor(a.V + layer * PS, p, 256, nt, h, v, ok);
             };
         };
         // d/dx through the positional encoding (transpose Jacobian), accumulated into n[]
@@ -140,25 +170,28 @@ __global__ __launch_bounds__(kSdfWaves * 64, 1) void sdf_f32_kernel(SdfArgs a) {
                 }
             }
         };
-        dense_f32<8, 8, C8, false>(ws, Y, loadS(6), mulInto(X));   // through W7^T
-        dense_f32<8, 8, C8, false>(ws, X, loadS(5), mulInto(Y));   // W6^T
-        dense_f32<8, 8, C8, false>(ws, Y, loadS(4), mulInto(X));   // W5^T
+        dense_f32<8, 8, C8, false>(ws, Y, loadS(6), mulInto(X, 6));   // through W7^T
+        dense_f32<8, 8, C8, false>(ws, X, loadS(5), mulInto(Y, 5));   // W6^T
+        dense_f32<8, 8, C8, false>(ws, Y, loadS(4), mulInto(X, 4));   // W5^T
         {   // W4^T: 9 output tiles = [h4 part (7 tiles) | PE part (2 tiles)]
             float UPE[32];
             dense_f32<8, 9, C7, false>(ws, X,
                 [&](int nt) { return nt < 7 ? load_tile_rowmajor_v(S + 3 * PS, p, 256, nt, h) : f32x16{}; },
                 [&](int nt, const f32x16& acc, const f32x16& sv) {
+                    f32x16 v;
 #pragma unroll
                     for (int t = 0; t < 16; ++t) {
-                        if (nt < 7) Y[nt * 16 + t] = acc[t] * sv[t];
+                        v[t] = acc[t] * sv[t];
+                        if (nt < 7) Y[nt * 16 + t] = v[t];
                         else UPE[(nt - 7) * 16 + t] = acc[t];
                     }
+                    if (nt < 7 && a.V != nullptr) store_tile_rowmajor(a.V + 3 * PS, p, 256, nt, h, v, ok);
                 });
             pe_backward(UPE);
         }
-        dense_f32<7, 8, C8, false>(ws, Y, loadS(2), mulInto(X));   // W3^T
-        dense_f32<8, 8, C8, false>(ws, X, loadS(1), mulInto(Y));   // W2^T
-        dense_f32<8, 8, C8, false>(ws, Y, loadS(0), mulInto(X));   // W1^T
+        dense_f32<7, 8, C8, false>(ws, Y, loadS(2), mulInto(X, 2));   // W3^T
+        dense_f32<8, 8, C8, false>(ws, X, loadS(1), mulInto(Y, 1));   // W2^T
+        dense_f32<8, 8, C8, false>(ws, Y, loadS(0), mulInto(X, 0));   // W1^T
         dense_f32<8, 2, 0, false>(ws, X, NoPre{}, [&](int nt, const f32x16& acc, int) {   // W0^T
 #pragma unroll
             for (int t = 0; t < 16; ++t) Y[nt * 16 + t] = acc[t];

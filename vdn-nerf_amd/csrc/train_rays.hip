@@ -1,0 +1,223 @@
+// Adjoint of the per-ray compositing kernel (rays.hip: composite_kernel), one wavefront per ray.
+// weights w_i = alpha_i T_i, T_i = prod_{k<i} (1 - alpha_k + 1e-7):
+//   dL/dalpha_i = Wb_i T_i - (sum_{j>i} Wb_j w_j) / (1 - alpha_i + 1e-7),   Wb_i = dL/dw_i
+// then through the inside/outside blend, the NeuS alpha (renderer.py:262-282), the background
+// alpha (renderer.py:124) and the eikonal term (renderer.py:313-315). Built with -ffp-contract=off.
+#include "vdn_common.h"
+#include "vdn_kernels.h"
+
+namespace vdn {
+
+constexpr int kRW = 4;
+constexpr int kMaxTB = 256;
+constexpr int kE = 4;
+
+VDN_DEV double wsum_d(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__global__ __launch_bounds__(kRW * 64) void composite_bwd_kernel(CompositeBwdArgs a) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * kRW + wave;
+    if (r >= a.B) return;
+    const int N = a.N, T = a.T, C = a.feat_ch;
+    const bool has_bg = a.bg_density != nullptr;
+    const bool has_feat = a.d_feat != nullptr && a.g_feat != nullptr;
+    float o[3], d[3], gc[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        o[k] = a.rays_o[r * 3 + k];
+        d[k] = a.rays_d[r * 3 + k];
+        if (a.g_color != nullptr) gc[k] = a.g_color[r * 3 + k];
+    }
+    const float var = a.variance[0];
+    const float inv_s_raw = expf(var * 10.0f);
+    const float inv_s = fminf(fmaxf(inv_s_raw, 1e-6f), 1e6f);
+    const bool s_unclipped = inv_s_raw >= 1e-6f && inv_s_raw <= 1e6f;
+    const float car = a.cos_anneal_ratio;
+    const float g_eik = a.g_eik != nullptr ? a.g_eik[0] : 0.0f;
+    const float eik_den = a.eik[2] + 1e-5f;
+    float bgc[3] = {0.0f, 0.0f, 0.0f};
+    if (a.background_rgb != nullptr) {
+        bgc[0] = a.background_rgb[0]; bgc[1] = a.background_rgb[1]; bgc[2] = a.background_rgb[2];
+    }
+
+    float alpha[kE], w[kE], f[kE], Tr[kE], Wb[kE], ins[kE];
+    // pass 1: dL/dw_i
+#pragma unroll
+    for (int e = 0; e < kE; ++e) {
+        const int i = kE * lane + e;
+        alpha[e] = 0.0f; w[e] = 0.0f; f[e] = 1.0f; Wb[e] = 0.0f; ins[e] = 0.0f;
+        if (i < T) {
+            const long qt = (long)r * T + i;
+            alpha[e] = a.alpha[qt];
+            w[e] = a.weights[qt];
+            f[e] = 1.0f - alpha[e] + 1e-7f;
+            float c0, c1, c2;
+            float inside = 0.0f;
+            if (i < N) {
+                const long q = (long)r * N + i;
+                const float mz = a.mid_z[q];
+                const float x = o[0] + d[0] * mz, y = o[1] + d[1] * mz, zz = o[2] + d[2] * mz;
+                inside = sqrtf(x * x + y * y + zz * zz) < 1.0f ? 1.0f : 0.0f;
+                c0 = a.color[q * 3]; c1 = a.color[q * 3 + 1]; c2 = a.color[q * 3 + 2];
+                if (has_bg) {
+                    c0 = c0 * inside + a.bg_rgb[qt * 3] * (1.0f - inside);
+                    c1 = c1 * inside + a.bg_rgb[qt * 3 + 1] * (1.0f - inside);
+                    c2 = c2 * inside + a.bg_rgb[qt * 3 + 2] * (1.0f - inside);
+                }
+            } else {
+                c0 = a.bg_rgb[qt * 3]; c1 = a.bg_rgb[qt * 3 + 1]; c2 = a.bg_rgb[qt * 3 + 2];
+            }
+            ins[e] = inside;
+            float wb = gc[0] * (c0 - bgc[0]) + gc[1] * (c1 - bgc[1]) + gc[2] * (c2 - bgc[2]);
+            if (a.g_weights != nullptr) wb += a.g_weights[qt];
+            if (has_feat) {
+                float acc = 0.0f;
+                for (int ch = 0; ch < C; ++ch) {
+                    float fv;
+                    if (i < N) {
+                        fv = a.feat[((long)r * N + i) * C + ch];
+                        if (has_bg) fv = fv * inside + a.bg_feat[qt * C + ch] * (1.0f - inside);
+                    } else {
+                        fv = a.bg_feat[qt * C + ch];
+                    }
+                    acc += a.g_feat[(long)r * C + ch] * fv;
+                }
+                wb += acc;
+            }
+            Wb[e] = wb;
+        }
+    }
+    // transmittance (exclusive product) and suffix sums S_i = sum_{j>i} Wb_j w_j
+    {
+        double loc = 1.0;
+#pragma unroll
+        for (int e = 0; e < kE; ++e) loc *= (double)f[e];
+        double incl = loc;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double t = __shfl_up(incl, off);
+            if (lane >= off) incl *= t;
+        }
+        double run = __shfl_up(incl, 1);
+        if (lane == 0) run = 1.0;
+#pragma unroll
+        for (int e = 0; e < kE; ++e) {
+            Tr[e] = (float)run;
+            run *= (double)f[e];
+        }
+    }
+    double suf[kE];
+    {
+        double loc = 0.0;
+#pragma unroll
+        for (int e = 0; e < kE; ++e) loc += (double)Wb[e] * (double)w[e];
+        double incl = loc;                       // inclusive suffix over lanes
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double t = __shfl_down(incl, off);
+            if (lane + off < 64) incl += t;
+        }
+        double run = __shfl_down(incl, 1);       // sum over higher lanes
+        if (lane == 63) run = 0.0;
+#pragma unroll
+        for (int e = kE - 1; e >= 0; --e) {
+            suf[e] = run;
+            run += (double)Wb[e] * (double)w[e];
+        }
+    }
+    double dvar = 0.0;
+#pragma unroll
+    for (int e = 0; e < kE; ++e) {
+        const int i = kE * lane + e;
+        if (i >= T) continue;
+        const long qt = (long)r * T + i;
+        const float dalpha = Wb[e] * Tr[e] - (float)(suf[e] / (double)f[e]);
+        const float wi = w[e];
+        float da_in = 0.0f, da_bg = dalpha;
+        if (i < N) {
+            const long q = (long)r * N + i;
+            const float inside = ins[e];
+            if (has_bg) {
+                da_in = dalpha * inside;
+                da_bg = dalpha * (1.0f - inside);
+            } else {
+                da_in = dalpha;
+                da_bg = 0.0f;
+            }
+            const float cs = has_bg ? inside : 1.0f;
+            a.d_color[q * 3] = wi * gc[0] * cs;
+            a.d_color[q * 3 + 1] = wi * gc[1] * cs;
+            a.d_color[q * 3 + 2] = wi * gc[2] * cs;
+            if (has_feat)
+                for (int ch = 0; ch < C; ++ch) a.d_feat[q * C + ch] = wi * a.g_feat[(long)r * C + ch] * cs;
+            // NeuS alpha backward
+            const float sdf = a.sdf[q], dist = a.dists[q];
+            const float g0 = a.normals[q * 3], g1 = a.normals[q * 3 + 1], g2 = a.normals[q * 3 + 2];
+            const float tc = d[0] * g0 + d[1] * g1 + d[2] * g2;
+            const float ra = -tc * 0.5f + 0.5f, rb = -tc;
+            const float ic = -(fmaxf(ra, 0.0f) * (1.0f - car) + fmaxf(rb, 0.0f) * car);
+            const float en = sdf + ic * dist * 0.5f, ep = sdf - ic * dist * 0.5f;
+            const float pc = sigmoidf_(ep * inv_s), nc = sigmoidf_(en * inv_s);
+            const float raw = ((pc - nc) + 1e-5f) / (pc + 1e-5f);
+            const float graw = (raw >= 0.0f && raw <= 1.0f) ? da_in : 0.0f;
+            const float dpc = graw * (nc / ((pc + 1e-5f) * (pc + 1e-5f)));
+            const float dnc = -graw / (pc + 1e-5f);
+            const float dzp = dpc * pc * (1.0f - pc), dzn = dnc * nc * (1.0f - nc);    // wrt ep*s, en*s
+            const float dep = dzp * inv_s, den = dzn * inv_s;
+            dvar += (double)(dzp * ep + dzn * en);
+            const float dic = (den - dep) * dist * 0.5f;
+            const float dtc = dic * ((ra > 0.0f ? 0.5f * (1.0f - car) : 0.0f) + (rb > 0.0f ? car : 0.0f));
+            a.d_sdf[q] = dep + den;
+            // eikonal: d/dn of relax*(|n|-1)^2 / (den+1e-5)
+            const float mz = a.mid_z[q];
+            const float x = o[0] + d[0] * mz, y = o[1] + d[1] * mz, zz = o[2] + d[2] * mz;
+            const float relax = sqrtf(x * x + y * y + zz * zz) < 1.2f ? 1.0f : 0.0f;
+            const float gn = sqrtf(g0 * g0 + g1 * g1 + g2 * g2);
+            const float ke = gn > 0.0f ? g_eik * relax * 2.0f * (gn - 1.0f) / (gn * eik_den) : 0.0f;
+            a.d_normals[q * 3] = dtc * d[0] + ke * g0;
+            a.d_normals[q * 3 + 1] = dtc * d[1] + ke * g1;
+            a.d_normals[q * 3 + 2] = dtc * d[2] + ke * g2;
+        }
+        if (has_bg) {
+            const float cs = (i < N) ? (1.0f - ins[e]) : 1.0f;
+            a.d_bg_rgb[qt * 3] = wi * gc[0] * cs;
+            a.d_bg_rgb[qt * 3 + 1] = wi * gc[1] * cs;
+            a.d_bg_rgb[qt * 3 + 2] = wi * gc[2] * cs;
+            if (has_feat && a.d_bg_feat != nullptr)
+                for (int ch = 0; ch < C; ++ch) a.d_bg_feat[qt * C + ch] = wi * a.g_feat[(long)r * C + ch] * cs;
+            // alpha_bg = 1 - exp(-softplus(rho) * dist)
+            const float rho_ = a.bg_density[qt], dist = a.bg_dists[qt];
+            const float sp = softplus1(rho_);
+            const float dsp = rho_ > 20.0f ? 1.0f : sigmoidf_(rho_);
+            a.d_bg_density[qt] = da_bg * expf(-sp * dist) * dist * dsp;
+        }
+    }
+    dvar = wsum_d(dvar);
+    if (lane == 0) a.d_var_partial[r] = s_unclipped ? (float)(dvar * 10.0 * (double)inv_s) : 0.0f;
+}
+
+__global__ void variance_reduce_kernel(const float* partial, int B, float* out) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < B; i += 64) s += (double)partial[i];
+    s = wsum_d(s);
+    if (threadIdx.x == 0) out[0] = (float)s;
+}
+
+}  // namespace vdn
+
+extern "C" int vdn_alpha_composite_bwd(const VdnCompositeBwdArgs* a, void* stream) {
+    using namespace vdn;
+    if (!a || a->B <= 0 || a->N <= 0 || a->T < a->N || a->T > kMaxTB) return -1;
+    if (!a->rays_o || !a->rays_d || !a->sdf || !a->normals || !a->dists || !a->mid_z || !a->color || !a->variance ||
+        !a->alpha || !a->weights || !a->eik) return -2;
+    if (!a->d_sdf || !a->d_normals || !a->d_color || !a->d_var_partial || !a->d_variance) return -3;
+    if (a->T > a->N && (!a->bg_density || !a->bg_rgb || !a->bg_dists || !a->d_bg_density || !a->d_bg_rgb)) return -4;
+    if (a->d_feat && (!a->feat || a->feat_ch <= 0)) return -5;
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3((a->B + kRW - 1) / kRW), dim3(kRW * 64), 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(variance_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a->d_var_partial, a->B, a->d_variance);
+    return (int)hipGetLastError();
+}

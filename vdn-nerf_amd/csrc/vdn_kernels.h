@@ -14,6 +14,14 @@ using UpsampleArgs = ::VdnUpsampleArgs;
 using MergeArgs = ::VdnMergeArgs;
 using SectionArgs = ::VdnSectionArgs;
 using CompositeArgs = ::VdnCompositeArgs;
+using RenderNetBwdArgs = ::VdnRenderNetBwdArgs;
+using NerfBwdArgs = ::VdnNerfBwdArgs;
+using SdfRbarArgs = ::VdnSdfRbarArgs;
+using SdfFbarArgs = ::VdnSdfFbarArgs;
+using DwDesc = ::VdnDwDesc;
+using DwFinalizeDesc = ::VdnDwFinalizeDesc;
+using WeightNormBwdDesc = ::VdnWeightNormBwdDesc;
+using CompositeBwdArgs = ::VdnCompositeBwdArgs;
 
 // Kernels needing more than 64 KiB of dynamic LDS opt in once per process.
 template <class K>

@@ -53,6 +53,45 @@ def extract_geometry(bound_min, bound_max, resolution, threshold, query_func):
     return vertices, triangles
 
 
+class _RenderCoreFn(torch.autograd.Function):
+    """Differentiable part of render() (render_core_outside + render_core at detached z) as one autograd
+    node: forward and backward are the hand-written kernels driven by vdn_hip.train.TrainEngine."""
+
+    @staticmethod
+    def forward(ctx, engine, rays_o, rays_d, z, z_out, bgc, car, *params):
+        w = engine.forward(rays_o, rays_d, z, z_out, bgc, car)
+        ctx.engine, ctx.generation, ctx.n_params = engine, engine.generation, len(params)
+        color, weights, eik = w["color"].clone(), w["weights"].clone(), w["eik"][0].clone()
+        feats = w["feat_out"].clone() if w["feat_out"] is not None else color.new_zeros(0)
+        aux = (w["cdf"].clone(), w["inside"].clone(), w["normals"].view(engine.B, engine.N, 3).clone(), w["s_val"].clone(),
+               (w["bg_mid"] if engine.r.n_outside > 0 else w["mid_z"]).clone(), w["eik"][1:3].clone())
+        ctx.mark_non_differentiable(*aux)
+        return (color, feats, weights, eik) + aux
+
+    @staticmethod
+    def backward(ctx, g_color, g_feats, g_weights, g_eik, *unused):
+        eng = ctx.engine
+        if eng.generation != ctx.generation:
+            raise RuntimeError("NeuSRenderer.render was called again before this result's backward(): the training "
+                               "engine keeps the activations of the latest forward only")
+        g_feats = g_feats if (g_feats is not None and g_feats.numel() > 0) else None
+        grads = eng.backward(g_color, g_feats, g_weights, g_eik)
+        r = eng.r
+        flat = []
+        for key, mod in (("nerf", r.nerf), ("sdf", r.sdf_network), ("variance", r.deviation_network),
+                         ("color", r.color_network), ("vdn", r.depth_network)):
+            if mod is None:
+                continue
+            if key == "variance":
+                flat.append(grads["variance"])
+            elif key in grads:
+                flat += grads[key]
+            else:
+                flat += [None] * len(list(mod.parameters()))      # network not on the path (n_outside == 0)
+        assert len(flat) == ctx.n_params
+        return (None,) * 7 + tuple(flat)
+
+
 class NeuSRenderer:
     def __init__(self, nerf, sdf_network, deviation_network, color_network, depth_network, n_samples, n_importance,
                  n_outside, up_sample_steps, perturb):
@@ -177,6 +216,9 @@ class NeuSRenderer:
         st = _stream()
 
         z, z_out = self._sample(rays_o, rays_d, near, far, perturb, t_rand, t_rand_out, z_vals_inject)
+        params = self._all_parameters()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            return self._render_train(rays_o, rays_d, z, z_out, background_rgb, cos_anneal_ratio, params)
         dists, mid_z = self._sections(z, N, sample_dist)
 
         bg_density = bg_rgb = bg_feat = bg_dists = bg_mid = None
@@ -238,6 +280,47 @@ class NeuSRenderer:
             "weights": weights,
             "z_vals": bg_mid if O > 0 else mid_z,                                # renderer.py:421-424
             "gradient_error": eik[0],
+            "inside_sphere": inside,
+        }
+
+    def _all_parameters(self):
+        """dpt_runner.py:121-130 order: nerf, sdf, variance, colour, (vdn)."""
+        ps = []
+        for m in (self.nerf, self.sdf_network, self.deviation_network, self.color_network, self.depth_network):
+            if m is not None:
+                ps += list(m.parameters())
+        return ps
+
+    def _render_train(self, rays_o, rays_d, z, z_out, background_rgb, cos_anneal_ratio, params):
+        """Training path: same outputs, differentiable wrt every network parameter (dpt_runner.py:253)."""
+        from vdn_hip.train import TrainEngine
+        B, dev = rays_o.shape[0], rays_o.device
+        engines = self.__dict__.setdefault("_engines", {})
+        key = (B, dev, tuple(p.data_ptr() for p in params))
+        eng = engines.get(key)
+        if eng is None:
+            engines.clear()                      # one live engine: its workspaces are GBs at B = 512
+            eng = engines[key] = TrainEngine(self, B, dev)
+        bgc = None
+        if background_rgb is not None:
+            bgc = background_rgb.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+            if bgc.numel() != 3:
+                raise ValueError("background_rgb must have 3 values")
+        z = z.contiguous()
+        color, feats, weights, eik, cdf, inside, normals, s_val, z_ret, eik_terms = _RenderCoreFn.apply(
+            eng, rays_o, rays_d, z, z_out, bgc, float(cos_anneal_ratio), *params)
+        self.last_eikonal_terms = eik_terms
+        return {
+            "render_feats": feats if self.depth_network is not None else None,
+            "color_fine": color,
+            "s_val": s_val,
+            "cdf_fine": cdf,
+            "weight_sum": weights.sum(dim=-1, keepdim=True),
+            "weight_max": torch.max(weights, dim=-1, keepdim=True)[0],
+            "gradients": normals,
+            "weights": weights,
+            "z_vals": z_ret,
+            "gradient_error": eik,
             "inside_sphere": inside,
         }
 

@@ -33,7 +33,9 @@ def ident_map(n, pad=None):
 
 
 class Layer:
-    """One GEMM layer of a stream. chunks: list of (matrix_name, use_bias, rowmap32[int32 x32])."""
+    """One GEMM layer of a stream. chunks: list of chunks; a chunk is either one piece
+    (matrix_name, use_bias, rowmap32) covering the whole contraction width, or a list of pieces
+    (matrix_name, use_bias, rowmap32, kt_begin, kt_count) when its k-tiles come from several matrices."""
 
     def __init__(self, kmap, chunks, scale=1.0, transposed=False):
         self.kmap = np.asarray(kmap, np.int32)
@@ -52,6 +54,22 @@ def dense_layer(name, kmap, nmap, bias=True, scale=1.0):
     nmap = np.asarray(nmap, np.int32)
     assert len(nmap) % 32 == 0
     return Layer(kmap, [(name, bias, nmap[i:i + 32]) for i in range(0, len(nmap), 32)], scale)
+
+
+def transposed_layer_multi(parts, fwd_kmap, scale=1.0):
+    """W^T layer whose contraction (the forward layer's padded OUTPUT order) spans several matrices:
+    parts = [(matrix_name, fwd_nmap_part)], concatenated along k in that order."""
+    fwd_kmap = np.asarray(fwd_kmap, np.int32)
+    kfull = np.concatenate([np.asarray(nm, np.int32) for _, nm in parts])
+    chunks = []
+    for i in range(0, len(fwd_kmap), 32):
+        pieces, kt0 = [], 0
+        for name, nm in parts:
+            ktc = len(nm) // 32
+            pieces.append((name, False, fwd_kmap[i:i + 32], kt0, ktc))
+            kt0 += ktc
+        chunks.append(pieces)
+    return Layer(kfull, chunks, scale, transposed=True)
 
 
 def transposed_layer(name, fwd_kmap, fwd_nmap, scale=1.0):
@@ -89,6 +107,8 @@ class NetImages:
         maps, map_off = [], 0
         chunk_rows = []
         for sname, layers in streams.items():
+            if sname.startswith("_"):
+                continue
             total = sum(chunk_bytes(L.kt, fmt) * len(L.chunks) for L in layers)
             self.blobs[sname] = torch.zeros(total, dtype=torch.uint8, device=device)
             off = 0
@@ -96,11 +116,13 @@ class NetImages:
                 k_off = map_off
                 maps.append(L.kmap)
                 map_off += len(L.kmap)
-                for (mname, use_bias, rowmap) in L.chunks:
-                    n_off = map_off
-                    maps.append(np.asarray(rowmap, np.int32))
-                    map_off += 32
-                    chunk_rows.append((sname, off, mname, use_bias, k_off, n_off, L))
+                for chunk in L.chunks:
+                    pieces = chunk if isinstance(chunk, list) else [chunk + (0, 0)]
+                    for pi, (mname, use_bias, rowmap, kt0, ktc) in enumerate(pieces):
+                        n_off = map_off
+                        maps.append(np.asarray(rowmap, np.int32))
+                        map_off += 32
+                        chunk_rows.append((sname, off, mname, use_bias, k_off + 32 * kt0, n_off, L, kt0, ktc, pi == 0))
                     off += chunk_bytes(L.kt, fmt)
         self.maps = torch.from_numpy(np.concatenate(maps)).to(device)
         self._chunk_rows = chunk_rows
@@ -124,7 +146,7 @@ class NetImages:
             wn[i]["rows"], wn[i]["cols"] = v.shape
         ch = np.zeros(len(self._chunk_rows), dtype=lib.struct_dtype("VdnChunkDesc"))
         mp = self.maps.data_ptr()
-        for i, (sname, off, mname, use_bias, k_off, n_off, L) in enumerate(self._chunk_rows):
+        for i, (sname, off, mname, use_bias, k_off, n_off, L, kt0, ktc, first) in enumerate(self._chunk_rows):
             g, v, b = self.matrices[mname]
             rows, cols = v.shape
             ch[i]["src"] = self.weff.data_ptr() + 4 * self.w_off[mname]
@@ -140,6 +162,7 @@ class NetImages:
             ch[i]["k_pad"] = len(L.kmap)
             ch[i]["scale"] = L.scale
             ch[i]["fmt"] = self.fmt
+            ch[i]["kt_begin"], ch[i]["kt_count"], ch[i]["write_bias"] = kt0, ktc, int(first)
         self.wn_table = torch.from_numpy(wn.view(np.uint8)).to(self.device)
         self.chunk_table = torch.from_numpy(ch.view(np.uint8)).to(self.device)
         self._n_wn, self._n_ch = len(wn), len(ch)
@@ -195,7 +218,19 @@ def sdf_streams(d_in, d_out, d_hidden, n_layers, skip_in, multires):
     nm8[256] = 0                        # sdf row
     last_full = dense_layer("lin8", ident_map(256), nm8, True)
     sweep = [transposed_layer(n, km, nm, sc) for (n, km, nm, sc) in reversed(fwd[0:8])]
-    return {"sdf": hidden + [last_sdf], "full": hidden + [last_full] + sweep}
+    # adjoint of the forward pass: W8^T, W7^T .. W1^T
+    fbar = [transposed_layer("lin8", ident_map(256), nm8)] + [transposed_layer(n, km, nm, sc) for (n, km, nm, sc) in reversed(fwd[1:8])]
+    return {"sdf": hidden + [last_sdf], "full": hidden + [last_full] + sweep, "fbar": fbar}
+
+
+def sdf_layer_maps():
+    """(name, kmap, nmap, scale) of the 9 SDF layers in image coordinates (for the weight-gradient scatter)."""
+    st = sdf_streams(3, 257, 256, 8, (4,), 6)
+    out = []
+    for l, L in enumerate(st["full"][:9]):
+        nmap = np.concatenate([c[2] for c in L.chunks])
+        out.append(("lin%d" % l, L.kmap, nmap, L.scale))
+    return out
 
 
 def rendering_streams(d_feature, mode, d_in, d_out, d_hidden, n_layers, multires_view):
@@ -209,8 +244,12 @@ def rendering_streams(d_feature, mode, d_in, d_out, d_hidden, n_layers, multires
     layers = [dense_layer("lin0", km0, ident_map(256))]
     for l in (1, 2, 3):
         layers.append(dense_layer("lin%d" % l, ident_map(256), ident_map(256)))
-    layers.append(dense_layer("lin4", ident_map(256), ident_map(d_out, 96 if d_out == 96 else 32)))
-    return {"fwd": layers}
+    nm4 = ident_map(d_out, 96 if d_out == 96 else 32)
+    layers.append(dense_layer("lin4", ident_map(256), nm4))
+    bwd = [transposed_layer("lin4", ident_map(256), nm4)]
+    bwd += [transposed_layer("lin%d" % l, ident_map(256), ident_map(256)) for l in (3, 2, 1)]
+    bwd.append(transposed_layer("lin0", km0, ident_map(256)))
+    return {"fwd": layers, "bwd": bwd}
 
 
 def nerf_streams(D, W, d_in, d_in_view, multires, multires_view, skips, rgb_dims, gen_depth_feats, dpt_dim):
@@ -240,4 +279,12 @@ def nerf_streams(D, W, d_in, d_in_view, multires, multires_view, skips, rgb_dims
         nm = ident_map(96)
         out.chunks += [("dpt_linear", True, nm[i:i + 32]) for i in (0, 32, 64)]
     layers.append(out)
-    return {"fwd": layers}
+    # adjoint chain: Wout^T, Wviews^T, Whead^T, W7^T .. W1^T
+    out_parts = [("rgb_linear", ident_map(3, 32))] + ([("dpt_linear", ident_map(96))] if gen_depth_feats else [])
+    bwd = [transposed_layer_multi(out_parts, ident_map(128))]
+    bwd.append(transposed_layer("views_linears.0", kmv, ident_map(128)))
+    bwd.append(transposed_layer_multi([("feature_linear", ident_map(256)), ("alpha_linear", ident_map(1, 32))], ident_map(256)))
+    bwd += [transposed_layer("pts_linears.%d" % i, ident_map(256), ident_map(256)) for i in (7, 6)]
+    bwd.append(transposed_layer("pts_linears.5", km5, ident_map(256)))
+    bwd += [transposed_layer("pts_linears.%d" % i, ident_map(256), ident_map(256)) for i in (4, 3, 2, 1)]
+    return {"fwd": layers, "bwd": bwd, "_km5": km5, "_kmv": kmv}

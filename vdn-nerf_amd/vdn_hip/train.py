@@ -1,0 +1,393 @@
+"""Training-step engine: persistent workspaces + descriptor tables that drive the forward-with-saves
+and the hand-derived backward of NeuSRenderer.render on the MI355X kernels.
+
+One TrainEngine per (renderer, batch size). forward() is the differentiable part of render() -
+render_core_outside + render_core (renderer.py:100-145, 209-330) at given, detached z - with every
+activation the adjoint needs kept in HBM; backward() runs
+  composite_bwd -> RenderingNetwork bwd (colour, VDN) -> SDF rbar/fbar -> NeRF bwd
+  -> one batched weight-gradient GEMM -> finalize/scatter -> weight-norm backward
+and returns d loss / d parameter for every parameter, in module.parameters() order.
+"""
+import numpy as np
+import torch
+
+from . import images, lib
+
+PTS_PER_SPLIT = 4096
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _Net:
+    """Gradient-side state of one network: d W_eff flat buffer, per-parameter gradient buffers."""
+
+    def __init__(self, module, dev):
+        self.module = module
+        self.img = module._images()
+        self.dweff = torch.zeros_like(self.img.weff)
+        self.grads = {}          # id(param) -> persistent grad tensor
+        for name, (g, v, b) in self.img.matrices.items():
+            for t in (g, v, b):
+                if t is not None:
+                    self.grads[id(t)] = torch.zeros_like(t)
+
+    def dweff_view(self, name):
+        v = self.img.matrices[name][1]
+        o = self.img.w_off[name]
+        return self.dweff[o:o + v.numel()].view(v.shape)
+
+    def dw_target(self, name):
+        """Where the finalize pass writes d W for matrix `name`: d W_eff (weight-normed) or the .grad buffer itself."""
+        g, v, b = self.img.matrices[name]
+        return self.dweff_view(name) if g is not None else self.grads[id(v)]
+
+    def bias_target(self, name):
+        b = self.img.matrices[name][2]
+        return None if b is None else self.grads[id(b)]
+
+
+class TrainEngine:
+    def __init__(self, renderer, B, dev):
+        self.r = renderer
+        self.B, self.dev = B, dev
+        S, I, O = renderer.n_samples, renderer.n_importance, renderer.n_outside
+        self.N = S + I
+        self.T = self.N + O
+        self.P = B * self.N
+        self.Q = B * self.T
+        self.wdepth = renderer.depth_network is not None
+        f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        P, Q, N, T = self.P, self.Q, self.N, self.T
+        w = self.w = {}
+        # ---- forward saves
+        w["dists"], w["mid_z"] = f(B, N), f(B, N)
+        w["sdf"], w["feat"], w["normals"] = f(P), f(P, 256), f(P, 3)
+        w["S"], w["H"], w["V"], w["PE"] = f(8, P, 256), f(8, P, 256), f(8, P, 256), f(P, 64)
+        w["col_out"], w["col_h"], w["col_small"] = f(P, 3), f(4, P, 256), f(P, 64)
+        if self.wdepth:
+            w["vdn_out"], w["vdn_h"], w["vdn_small"] = f(P, 96), f(4, P, 256), f(P, 64)
+        if O > 0:
+            w["z_feed"], w["bg_dists"], w["bg_mid"] = f(B, T), f(B, T), f(B, T)
+            w["bg_density"], w["bg_rgb"] = f(Q), f(Q, 3)
+            w["bg_feat"] = f(Q, 96) if self.wdepth else None
+            w["nf_h"], w["nf_pe"], w["nf_feature"], w["nf_vpe"], w["nf_hv"] = f(8, Q, 256), f(Q, 96), f(Q, 256), f(Q, 32), f(Q, 128)
+        w["weights"], w["alpha"], w["cdf"], w["inside"] = f(B, T), f(B, T), f(B, N), f(B, N)
+        w["color"], w["wsum"], w["wmax"], w["s_val"] = f(B, 3), f(B, 1), f(B, 1), f(B, 1)
+        w["eik_partial"], w["eik"] = f(B, 2), f(3)
+        w["feat_out"] = f(B, 96) if self.wdepth else None
+        # ---- backward intermediates
+        w["d_sdf"], w["d_normals"], w["d_color"], w["d_featvec"] = f(P), f(P, 3), f(P, 3), f(P, 256)
+        w["d_vdn"] = f(P, 96) if self.wdepth else None
+        w["d_var_partial"], w["d_variance"] = f(B), f(1)
+        w["col_dout"], w["col_dh"] = f(P, 32), f(4, P, 256)
+        if self.wdepth:
+            w["vdn_dout"], w["vdn_dh"] = f(P, 96), f(4, P, 256)
+        w["UB"], w["EX"], w["AB"] = f(P * 2144), f(8, P, 256), f(P * 2336)
+        if O > 0:
+            w["d_bg_density"], w["d_bg_rgb"] = f(Q), f(Q, 3)
+            w["d_bg_feat"] = f(Q, 96) if self.wdepth else None
+            w["nf_do"], w["nf_dv"], w["nf_dhead"], w["nf_dh"] = f(Q, 128 if self.wdepth else 32), f(Q, 128), f(Q, 288), f(8, Q, 256)
+        self.nets = {"sdf": _Net(renderer.sdf_network, dev), "color": _Net(renderer.color_network, dev)}
+        if self.wdepth:
+            self.nets["vdn"] = _Net(renderer.depth_network, dev)
+        if O > 0:
+            self.nets["nerf"] = _Net(renderer.nerf, dev)
+        self._build_dw_plan()
+
+    # ------------------------------------------------------------------------------------------
+    # weight-gradient plan
+    # ------------------------------------------------------------------------------------------
+    def _build_dw_plan(self):
+        w, P, Q = self.w, self.P, self.Q
+        ent = []    # dict(net, name, rmap, cmap, scale, A, A2, B, B2, bias(bool), Pn, extra)
+        ub_off, off = {}, 0
+        for l, cols in enumerate((64, 256, 256, 256, 288, 256, 256, 256, 256)):
+            ub_off[l] = (off, cols)
+            off += P * cols
+        UB = lambda l, c0=0: (w["UB"], ub_off[l][0] + c0, ub_off[l][1])          # (tensor, elem offset, ld)
+        AB = lambda l: (w["AB"], 0, 288) if l == 8 else (w["AB"], P * 288 + (7 - l) * P * 256, 256)
+        sl = lambda t, l, ld=256: (t, l * t.shape[1] * t.shape[2], ld)             # layer slice of a [L,P,ld] tensor
+        whole = lambda t, c0=0: (t, c0, t.shape[1])
+        maps = images.sdf_layer_maps()
+        for l, (name, km, nm, sc) in enumerate(maps):
+            if l == 8:
+                ent.append(dict(net="sdf", name=name, rmap=nm, cmap=km, scale=sc, A=AB(8), B=sl(w["H"], 7), bias=True, Pn=P))
+                continue
+            A, A2 = AB(l), sl(w["V"], l)
+            if l == 0:
+                ent.append(dict(net="sdf", name=name, rmap=nm, cmap=km, scale=sc, A=A, B=whole(w["PE"]), A2=A2, B2=UB(0), bias=True, Pn=P))
+            elif l == 4:
+                ent.append(dict(net="sdf", name=name, rmap=nm, cmap=km[:224], scale=sc, A=A, B=sl(w["H"], 3), A2=A2, B2=UB(4), bias=True, Pn=P))
+                ent.append(dict(net="sdf", name=name, rmap=nm, cmap=km[224:], scale=sc, A=A, B=whole(w["PE"]), A2=A2, B2=UB(4, 224), bias=False, Pn=P))
+            else:
+                ent.append(dict(net="sdf", name=name, rmap=nm, cmap=km, scale=sc, A=A, B=sl(w["H"], l - 1), A2=A2, B2=UB(l), bias=True, Pn=P))
+        # d W8[row 0, :] += colsum(ub_8) / scale   (u_8 = W8[0,:] / scale)
+        ent.append(dict(net="sdf", name="lin8", rmap=images.ident_map(256), cmap=None, scale=1.0, A=UB(8), B=None, bias=False, Pn=P,
+                        extra_row0=True))
+
+        def rendering(net, dh, dout, save_h, small, d_out):
+            km0 = self.nets[net].img.streams["fwd"][0].kmap
+            pad = 96 if d_out == 96 else 32
+            ent.append(dict(net=net, name="lin0", rmap=images.ident_map(256), cmap=km0[:256], scale=1.0, A=sl(dh, 0), B=whole(w["feat"]), bias=True, Pn=P))
+            ent.append(dict(net=net, name="lin0", rmap=images.ident_map(256), cmap=km0[256:], scale=1.0, A=sl(dh, 0), B=whole(small), bias=False, Pn=P))
+            for l in (1, 2, 3):
+                ent.append(dict(net=net, name="lin%d" % l, rmap=images.ident_map(256), cmap=images.ident_map(256), scale=1.0,
+                                A=sl(dh, l), B=sl(save_h, l - 1), bias=True, Pn=P))
+            ent.append(dict(net=net, name="lin4", rmap=images.ident_map(d_out, pad), cmap=images.ident_map(256), scale=1.0,
+                            A=whole(dout), B=sl(save_h, 3), bias=True, Pn=P))
+        rendering("color", w["col_dh"], w["col_dout"], w["col_h"], w["col_small"], 3)
+        if self.wdepth:
+            rendering("vdn", w["vdn_dh"], w["vdn_dout"], w["vdn_h"], w["vdn_small"], 96)
+        if "nerf" in self.nets:
+            st = self.nets["nerf"].img.streams
+            km5, kmv = st["_km5"], st["_kmv"]
+            I256 = images.ident_map(256)
+            dh, h = w["nf_dh"], w["nf_h"]
+            ent.append(dict(net="nerf", name="pts_linears.0", rmap=I256, cmap=images.ident_map(84, 96), scale=1.0, A=sl(dh, 0), B=whole(w["nf_pe"]), bias=True, Pn=Q))
+            for i in (1, 2, 3, 4, 6, 7):
+                ent.append(dict(net="nerf", name="pts_linears.%d" % i, rmap=I256, cmap=I256, scale=1.0, A=sl(dh, i), B=sl(h, i - 1), bias=True, Pn=Q))
+            ent.append(dict(net="nerf", name="pts_linears.5", rmap=I256, cmap=km5[:96], scale=1.0, A=sl(dh, 5), B=whole(w["nf_pe"]), bias=True, Pn=Q))
+            ent.append(dict(net="nerf", name="pts_linears.5", rmap=I256, cmap=km5[96:], scale=1.0, A=sl(dh, 5), B=sl(h, 4), bias=False, Pn=Q))
+            ent.append(dict(net="nerf", name="feature_linear", rmap=I256, cmap=I256, scale=1.0, A=(w["nf_dhead"], 0, 288), B=sl(h, 7), bias=True, Pn=Q))
+            ent.append(dict(net="nerf", name="alpha_linear", rmap=images.ident_map(1, 32), cmap=I256, scale=1.0, A=(w["nf_dhead"], 256, 288), B=sl(h, 7), bias=True, Pn=Q))
+            ent.append(dict(net="nerf", name="views_linears.0", rmap=images.ident_map(128), cmap=kmv[:256], scale=1.0, A=whole(w["nf_dv"]), B=whole(w["nf_feature"]), bias=True, Pn=Q))
+            ent.append(dict(net="nerf", name="views_linears.0", rmap=images.ident_map(128), cmap=kmv[256:], scale=1.0, A=whole(w["nf_dv"]), B=whole(w["nf_vpe"]), bias=False, Pn=Q))
+            ldo = w["nf_do"].shape[1]
+            ent.append(dict(net="nerf", name="rgb_linear", rmap=images.ident_map(3, 32), cmap=images.ident_map(128), scale=1.0, A=(w["nf_do"], 0, ldo), B=whole(w["nf_hv"]), bias=True, Pn=Q))
+            if self.wdepth:
+                ent.append(dict(net="nerf", name="dpt_linear", rmap=images.ident_map(96), cmap=images.ident_map(128), scale=1.0, A=(w["nf_do"], 32, ldo), B=whole(w["nf_hv"]), bias=True, Pn=Q))
+
+        # ---- tables
+        dev = self.dev
+        all_maps, moff = [], 0
+        dw = np.zeros(len(ent), dtype=lib.struct_dtype("VdnDwDesc"))
+        fin = np.zeros(len(ent), dtype=lib.struct_dtype("VdnDwFinalizeDesc"))
+        slab_elems, cs_elems, wg = 0, 0, 0
+        lay = []
+        for i, e in enumerate(ent):
+            mt = len(e["rmap"]) // 32
+            nt = 0 if e["cmap"] is None else len(e["cmap"]) // 32
+            K = e["Pn"] * (2 if e.get("A2") is not None else 1)
+            splits = max(1, (K + PTS_PER_SPLIT - 1) // PTS_PER_SPLIT)
+            lay.append((mt, nt, splits, slab_elems, cs_elems, moff, wg))
+            all_maps.append(np.asarray(e["rmap"], np.int32))
+            moff_r = moff
+            moff += mt * 32
+            if nt:
+                all_maps.append(np.asarray(e["cmap"], np.int32))
+                moff += nt * 32
+            slab_elems += splits * mt * 32 * nt * 32
+            cs_elems += splits * mt * 32
+            wg += ((mt + 3) // 4) * max((nt + 3) // 4, 1) * splits
+        self.dw_total_wgs = wg
+        self.maps = torch.from_numpy(np.concatenate(all_maps)).to(dev)
+        self.slab = torch.empty(max(slab_elems, 1), dtype=torch.float32, device=dev)
+        self.colsum = torch.empty(max(cs_elems, 1), dtype=torch.float32, device=dev)
+        P4 = lambda spec: spec[0].data_ptr() + 4 * spec[1]
+        for i, e in enumerate(ent):
+            mt, nt, splits, so, co, mo, wg0 = lay[i]
+            d = dw[i]
+            d["A1"], d["lda1"] = P4(e["A"]), e["A"][2]
+            if e["B"] is not None:
+                d["B1"], d["ldb1"] = P4(e["B"]), e["B"][2]
+            if e.get("A2") is not None:
+                d["A2"], d["lda2"], d["B2"], d["ldb2"] = P4(e["A2"]), e["A2"][2], P4(e["B2"]), e["B2"][2]
+            d["P"], d["m_tiles"], d["n_tiles"], d["splits"], d["wg_begin"] = e["Pn"], mt, nt, splits, wg0
+            d["slab"] = self.slab.data_ptr() + 4 * so
+            want_cs = e["bias"] or e.get("extra_row0")
+            d["colsum"] = self.colsum.data_ptr() + 4 * co if want_cs else 0
+            net = self.nets[e["net"]]
+            fd = fin[i]
+            fd["slab"], fd["colsum"] = d["slab"], d["colsum"]
+            fd["rmap"] = self.maps.data_ptr() + 4 * mo
+            fd["cmap"] = self.maps.data_ptr() + 4 * (mo + mt * 32)
+            fd["splits"], fd["M"], fd["N"] = splits, mt * 32, nt * 32
+            fd["scale"] = e["scale"]
+            if e.get("extra_row0"):
+                tgt = net.dw_target(e["name"])
+                fd["btarget"], fd["bscale"], fd["accumulate"] = tgt.data_ptr(), 1.0 / float(self.r.sdf_network.scale), 1
+            else:
+                tgt = net.dw_target(e["name"])
+                fd["target"], fd["t_stride"] = tgt.data_ptr(), tgt.shape[1]
+                if e["bias"]:
+                    bt = net.bias_target(e["name"])
+                    fd["btarget"], fd["bscale"] = bt.data_ptr(), 1.0
+        self.dw_table = torch.from_numpy(dw.view(np.uint8)).to(dev)
+        self.fin_table = torch.from_numpy(fin.view(np.uint8)).to(dev)
+        self.n_dw = len(ent)
+        self.fin_max_M = int(max(len(e["rmap"]) for e in ent))
+        # weight-norm backward table
+        rows = []
+        for net in self.nets.values():
+            for name, (g, v, b) in net.img.matrices.items():
+                if g is not None:
+                    rows.append((g, v, net.img.inv_norm[net.img.r_off[name]:], net.dweff_view(name), net.grads[id(g)], net.grads[id(v)]))
+        wn = np.zeros(len(rows), dtype=lib.struct_dtype("VdnWeightNormBwdDesc"))
+        for i, (g, v, inv, dwe, dg, dv) in enumerate(rows):
+            wn[i]["g"], wn[i]["v"], wn[i]["inv_norm"], wn[i]["dw_eff"] = g.data_ptr(), v.data_ptr(), inv.data_ptr(), dwe.data_ptr()
+            wn[i]["dg"], wn[i]["dv"], wn[i]["rows"], wn[i]["cols"] = dg.data_ptr(), dv.data_ptr(), v.shape[0], v.shape[1]
+        self.wn_table = torch.from_numpy(wn.view(np.uint8)).to(dev)
+        self.n_wn = len(rows)
+        self.wn_max_rows = max(r[1].shape[0] for r in rows)
+        self._param_ptrs = self._ptr_key()
+
+    def _ptr_key(self):
+        return tuple(p.data_ptr() for net in self.nets.values() for p in net.module.parameters())
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, rays_o, rays_d, z, z_out, background_rgb, cos_anneal_ratio):
+        """Differentiable part of render() at detached z [B,N] (+ z_out [B,O]); returns the output tensors."""
+        r, w, B, N, T = self.r, self.w, self.B, self.N, self.T
+        st = _stream()
+        for net in self.nets.values():
+            net.img = net.module._images()           # refresh weight images if parameters changed
+        if self._ptr_key() != self._param_ptrs:
+            raise RuntimeError("parameters were re-allocated after the training engine was built; rebuild it")
+        sample_dist = 2.0 / r.n_samples
+        a = lib.VdnSectionArgs()
+        a.z, a.dists, a.mid_z, a.sample_dist, a.B, a.n, a.ld = z.data_ptr(), w["dists"].data_ptr(), w["mid_z"].data_ptr(), sample_dist, B, N, z.stride(0)
+        lib.call("vdn_sections", a, st)
+        O = r.n_outside
+        if O > 0:
+            m = lib.VdnMergeArgs()
+            m.z, m.new_z, m.z_out = z.data_ptr(), z_out.data_ptr(), w["z_feed"].data_ptr()
+            m.B, m.M, m.K, m.ld, m.ld_out = B, N, O, z.stride(0), T
+            lib.call("vdn_merge_sorted", m, st)
+            a = lib.VdnSectionArgs()
+            a.z, a.dists, a.mid_z, a.sample_dist, a.B, a.n, a.ld = w["z_feed"].data_ptr(), w["bg_dists"].data_ptr(), w["bg_mid"].data_ptr(), sample_dist, B, T, T
+            lib.call("vdn_sections", a, st)
+            n = lib.VdnNerfArgs()
+            n.blob = self.nets["nerf"].img.blobs["fwd"].data_ptr()
+            n.rays_o, n.rays_d, n.z, n.n_per_ray, n.P = rays_o.data_ptr(), rays_d.data_ptr(), w["bg_mid"].data_ptr(), T, self.Q
+            n.density, n.rgb = w["bg_density"].data_ptr(), w["bg_rgb"].data_ptr()
+            n.feat = w["bg_feat"].data_ptr() if w["bg_feat"] is not None else None
+            n.save_h, n.save_pe, n.save_feature, n.save_vpe, n.save_hv = (w[k].data_ptr() for k in ("nf_h", "nf_pe", "nf_feature", "nf_vpe", "nf_hv"))
+            lib.call("vdn_nerf_mlp_fwd_f32", n, st)
+        s = lib.VdnSdfArgs()
+        img = self.nets["sdf"].img
+        s.blob = img.blobs["full"].data_ptr()
+        s.rays_o, s.rays_d, s.z, s.n_per_ray, s.z_ld, s.sdf_ld = rays_o.data_ptr(), rays_d.data_ptr(), w["mid_z"].data_ptr(), N, N, N
+        s.P, s.scale = self.P, float(r.sdf_network.scale)
+        s.sdf, s.feat, s.normals, s.S = w["sdf"].data_ptr(), w["feat"].data_ptr(), w["normals"].data_ptr(), w["S"].data_ptr()
+        s.w8row = img.weff_view("lin8").data_ptr()
+        s.H, s.V, s.PE = w["H"].data_ptr(), w["V"].data_ptr(), w["PE"].data_ptr()
+        lib.call("vdn_sdf_mlp_fwd_f32", 1, s, st)
+
+        def rnet(net, out, save_h, small, d_out, module):
+            c = lib.VdnRenderNetArgs()
+            c.blob = self.nets[net].img.blobs["fwd"].data_ptr()
+            c.rays_o, c.rays_d, c.z, c.n_per_ray = rays_o.data_ptr(), rays_d.data_ptr(), w["mid_z"].data_ptr(), N
+            c.normals, c.feat, c.out = w["normals"].data_ptr(), w["feat"].data_ptr(), out.data_ptr()
+            c.save_h, c.save_small = save_h.data_ptr(), small.data_ptr()
+            c.P, c.d_out, c.squeeze_out = self.P, d_out, int(module.squeeze_out)
+            lib.call("vdn_rendernet_fwd_f32", c, st)
+        if self.wdepth:
+            rnet("vdn", w["vdn_out"], w["vdn_h"], w["vdn_small"], 96, r.depth_network)
+        rnet("color", w["col_out"], w["col_h"], w["col_small"], 3, r.color_network)
+
+        c = self._composite_common(lib.VdnCompositeArgs(), rays_o, rays_d, background_rgb, cos_anneal_ratio)
+        c.weights, c.alpha_out, c.cdf, c.inside_sphere = w["weights"].data_ptr(), w["alpha"].data_ptr(), w["cdf"].data_ptr(), w["inside"].data_ptr()
+        c.color_out, c.weight_sum, c.weight_max, c.s_val = w["color"].data_ptr(), w["wsum"].data_ptr(), w["wmax"].data_ptr(), w["s_val"].data_ptr()
+        c.eik_partial, c.eik_out = w["eik_partial"].data_ptr(), w["eik"].data_ptr()
+        if self.wdepth:
+            c.feat_out = w["feat_out"].data_ptr()
+        lib.call("vdn_alpha_composite_fwd", c, st)
+        self._ctx = (rays_o, rays_d, background_rgb, cos_anneal_ratio, z)
+        self.generation = getattr(self, "generation", 0) + 1
+        return w
+
+    def _composite_common(self, c, rays_o, rays_d, background_rgb, cos_anneal_ratio):
+        w, r = self.w, self.r
+        c.rays_o, c.rays_d, c.sdf, c.normals = rays_o.data_ptr(), rays_d.data_ptr(), w["sdf"].data_ptr(), w["normals"].data_ptr()
+        c.dists, c.mid_z, c.color = w["dists"].data_ptr(), w["mid_z"].data_ptr(), w["col_out"].data_ptr()
+        c.variance = r.deviation_network.variance.data_ptr()
+        if self.wdepth:
+            c.feat, c.feat_ch = w["vdn_out"].data_ptr(), 96
+        if r.n_outside > 0:
+            c.bg_density, c.bg_rgb, c.bg_dists = w["bg_density"].data_ptr(), w["bg_rgb"].data_ptr(), w["bg_dists"].data_ptr()
+            if self.wdepth:
+                c.bg_feat = w["bg_feat"].data_ptr()
+        if background_rgb is not None:
+            c.background_rgb = background_rgb.data_ptr()
+        c.cos_anneal_ratio = float(cos_anneal_ratio)
+        c.B, c.N, c.T = self.B, self.N, self.T
+        return c
+
+    # ------------------------------------------------------------------------------------------
+    def backward(self, g_color, g_feat, g_weights, g_eik):
+        """Upstream grads (any may be None) -> list of parameter grads (clones) per network."""
+        r, w, st = self.r, self.w, _stream()
+        rays_o, rays_d, background_rgb, car, z = self._ctx
+        c = self._composite_common(lib.VdnCompositeBwdArgs(), rays_o, rays_d, background_rgb, car)
+        c.alpha, c.weights, c.eik = w["alpha"].data_ptr(), w["weights"].data_ptr(), w["eik"].data_ptr()
+        keep = [t.contiguous() if t is not None else None for t in (g_color, g_feat, g_weights, g_eik)]
+        g_color, g_feat, g_weights, g_eik = keep
+        c.g_color = g_color.data_ptr() if g_color is not None else None
+        c.g_feat = g_feat.data_ptr() if (g_feat is not None and self.wdepth) else None
+        c.g_weights = g_weights.data_ptr() if g_weights is not None else None
+        c.g_eik = g_eik.data_ptr() if g_eik is not None else None
+        c.d_sdf, c.d_normals, c.d_color = w["d_sdf"].data_ptr(), w["d_normals"].data_ptr(), w["d_color"].data_ptr()
+        use_vdn = self.wdepth and g_feat is not None
+        if self.wdepth:
+            c.d_feat = w["d_vdn"].data_ptr()
+            if g_feat is None:
+                w["d_vdn"].zero_()
+        if r.n_outside > 0:
+            c.d_bg_density, c.d_bg_rgb = w["d_bg_density"].data_ptr(), w["d_bg_rgb"].data_ptr()
+            if self.wdepth:
+                c.d_bg_feat = w["d_bg_feat"].data_ptr()
+                if g_feat is None:
+                    w["d_bg_feat"].zero_()
+        c.d_var_partial, c.d_variance = w["d_var_partial"].data_ptr(), w["d_variance"].data_ptr()
+        lib.call("vdn_alpha_composite_bwd", c, st)
+
+        def rnet_bwd(net, g_out, out, save_h, dout, dh, d_out, module, accumulate):
+            b = lib.VdnRenderNetBwdArgs()
+            b.blob = self.nets[net].img.blobs["bwd"].data_ptr()
+            b.g_out, b.out, b.save_h = g_out.data_ptr(), out.data_ptr(), save_h.data_ptr()
+            b.delta_out, b.delta_h = dout.data_ptr(), dh.data_ptr()
+            b.d_feat, b.d_normals = w["d_featvec"].data_ptr(), w["d_normals"].data_ptr()
+            b.acc_feat, b.acc_normals = int(accumulate), 1
+            b.P, b.d_out, b.squeeze_out = self.P, d_out, int(module.squeeze_out)
+            lib.call("vdn_rendernet_bwd_f32", b, st)
+        # d_normals already holds the alpha + eikonal parts: the heads add their input gradients into it;
+        # d_featvec is overwritten by the first head and accumulated by the second
+        rnet_bwd("color", w["d_color"], w["col_out"], w["col_h"], w["col_dout"], w["col_dh"], 3, r.color_network, False)
+        # (accumulate flag covers both d_feat and d_normals; d_normals must always accumulate)
+        if self.wdepth:
+            rnet_bwd("vdn", w["d_vdn"], w["vdn_out"], w["vdn_h"], w["vdn_dout"], w["vdn_dh"], 96, r.depth_network, True)
+
+        rb = lib.VdnSdfRbarArgs()
+        img = self.nets["sdf"].img
+        rb.blob = img.blobs["full"].data_ptr()
+        rb.rays_o, rb.rays_d, rb.z, rb.n_per_ray, rb.z_ld = rays_o.data_ptr(), rays_d.data_ptr(), w["mid_z"].data_ptr(), self.N, self.N
+        rb.P, rb.scale = self.P, float(r.sdf_network.scale)
+        rb.g_normals, rb.S, rb.V, rb.UB, rb.EX = w["d_normals"].data_ptr(), w["S"].data_ptr(), w["V"].data_ptr(), w["UB"].data_ptr(), w["EX"].data_ptr()
+        lib.call("vdn_sdf_bwd_rbar_f32", rb, st)
+        fb = lib.VdnSdfFbarArgs()
+        fb.blob = img.blobs["fbar"].data_ptr()
+        fb.g_sdf, fb.g_feat, fb.S, fb.EX, fb.AB = w["d_sdf"].data_ptr(), w["d_featvec"].data_ptr(), w["S"].data_ptr(), w["EX"].data_ptr(), w["AB"].data_ptr()
+        fb.P, fb.scale = self.P, float(r.sdf_network.scale)
+        lib.call("vdn_sdf_bwd_fbar_f32", fb, st)
+
+        if r.n_outside > 0:
+            nb = lib.VdnNerfBwdArgs()
+            nb.blob = self.nets["nerf"].img.blobs["bwd"].data_ptr()
+            nb.g_density, nb.g_rgb = w["d_bg_density"].data_ptr(), w["d_bg_rgb"].data_ptr()
+            nb.g_feat = w["d_bg_feat"].data_ptr() if self.wdepth else None
+            nb.save_h, nb.save_hv = w["nf_h"].data_ptr(), w["nf_hv"].data_ptr()
+            nb.delta_o, nb.delta_v, nb.delta_head, nb.delta_h = (w[k].data_ptr() for k in ("nf_do", "nf_dv", "nf_dhead", "nf_dh"))
+            nb.P = self.Q
+            lib.call("vdn_nerf_mlp_bwd_f32", nb, st)
+
+        lib.call("vdn_dw_gemm_f32", lib.ptr(self.dw_table), self.n_dw, self.dw_total_wgs, st)
+        lib.call("vdn_dw_finalize", lib.ptr(self.fin_table), self.n_dw, self.fin_max_M, 0, st)
+        lib.call("vdn_dw_finalize", lib.ptr(self.fin_table), self.n_dw, self.fin_max_M, 1, st)
+        lib.call("vdn_weightnorm_bwd", lib.ptr(self.wn_table), self.n_wn, self.wn_max_rows, st)
+        out = {}
+        for key, net in self.nets.items():
+            out[key] = [net.grads[id(p)].clone() for p in net.module.parameters()]
+        out["variance"] = w["d_variance"].reshape(()).clone()
+        return out
