@@ -360,6 +360,32 @@ typedef struct {
 } VdnCompositeBwdArgs;
 int vdn_alpha_composite_bwd(const VdnCompositeBwdArgs* args_host, void* stream);
 
+/* ---- caller semantics of dpt_runner.py:208-243 fused into one launch: loss terms + d loss / d outputs.
+ * loss = L1(color)/mask_sum + igr*eik + mask_w*BCE(clip(weight_sum)) + depth_w*L1(feats)/mask_sum.
+ * out_scalars = [loss, color_loss, psnr, eikonal, depth_loss, mask_loss]. `grad_scale` multiplies the
+ * per-ray gradients (1/world_size under data parallelism). */
+typedef struct {
+    const float* color;        /* [B,3] */
+    const float* true_rgb;     /* [B,3] */
+    const float* mask;         /* [B] or NULL (= ones, use_mask False) */
+    const float* feats;        /* [B,C] or NULL */
+    const float* gt_feats;     /* [B,C] or NULL */
+    const float* weights;      /* [B,T] (for weight_sum) */
+    const float* eik;          /* [3] gradient_error, num, den */
+    float igr_weight, mask_weight, depth_weight, grad_scale;
+    int32_t B, T, C, _pad;
+    float* g_color;            /* [B,3] */
+    float* g_feats;            /* [B,C] or NULL */
+    float* g_weights;          /* [B,T] or NULL (only needed when mask_weight != 0) */
+    float* g_eik;              /* [1] */
+    float* out_scalars;        /* [6] */
+} VdnLossArgs;
+int vdn_loss_fwd_bwd(const VdnLossArgs* args_host, void* stream);
+
+/* torch.optim.Adam (no weight decay, no amsgrad) over flat buffers: dpt_runner.py:144,254. */
+int vdn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  float lr, float beta1, float beta2, float eps, int32_t step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,7 +55,7 @@ def test_sdf_network_stage(env, dev, golden, P):
     got = rend.sdf_network(pts.to(dev)).cpu()
     assert got.shape == (P, 257)
     assert relmax(got.numpy(), out.numpy()) < 1e-5
-    assert relmax(rend.sdf_network.sdf(pts.to(dev)).cpu().numpy(), out[:, :1].numpy()) < 1e-5
+    assert relmax(rend.sdf_network.sdf(pts.to(dev)).detach().cpu().numpy(), out[:, :1].numpy()) < 1e-5
     gg = rend.sdf_network.gradient(pts.to(dev)).cpu()
     assert gg.shape == (P, 1, 3)
     assert relmax(gg[:, 0].numpy(), grad.numpy()) < 1e-5
@@ -69,16 +69,16 @@ def test_rendering_and_nerf_stage(env, dev, golden):
     rend, nets, _ = env(3, True, 0.3)
     pts, dirs = g(fx["pts"], dev), g(fx["dirs"], dev)
     feat, grad = g(fx["sdf_out"][:, 1:], dev), g(fx["sdf_grad"], dev)
-    col = rend.color_network(pts, grad, dirs, feat).cpu().numpy()
-    vdn = rend.depth_network(pts, grad, dirs, feat).cpu().numpy()
+    col = rend.color_network(pts, grad, dirs, feat).detach().cpu().numpy()
+    vdn = rend.depth_network(pts, grad, dirs, feat).detach().cpu().numpy()
     assert col.shape == (96, 3) and vdn.shape == (96, 96)
     assert relmax(col, fx["color"]) < 1e-5
     assert relmax(vdn, fx["vdn"]) < 1e-5
     a, rgb, ft = rend.nerf(g(fx["pts4"], dev), dirs)
     assert a.shape == (96, 1)
-    assert relmax(a.cpu().numpy(), fx["nerf_alpha"]) < 1e-5
-    assert relmax(rgb.cpu().numpy(), fx["nerf_rgb"]) < 1e-5
-    assert relmax(ft.cpu().numpy(), fx["nerf_feat"]) < 1e-5
+    assert relmax(a.detach().cpu().numpy(), fx["nerf_alpha"]) < 1e-5
+    assert relmax(rgb.detach().cpu().numpy(), fx["nerf_rgb"]) < 1e-5
+    assert relmax(ft.detach().cpu().numpy(), fx["nerf_feat"]) < 1e-5
 
 
 def test_sample_pdf_known_answer(dev, golden, env):
@@ -104,8 +104,8 @@ def test_sample_pdf_known_answer(dev, golden, env):
         lib.call("vdn_merge_sorted", m, _stream())
         zc, idx = torch.sort(torch.cat([torch.tensor(z), torch.tensor(nz)], -1), dim=-1, stable=True)
         sc = torch.gather(torch.cat([torch.tensor(sdf), torch.tensor(nsdf)], -1), 1, idx)
-        assert np.array_equal(zb.cpu().numpy()[:, :M + K], zc.numpy())
-        assert np.array_equal(sb.cpu().numpy()[:, :M + K], sc.numpy())
+        assert np.array_equal(zb.detach().cpu().numpy()[:, :M + K], zc.numpy())
+        assert np.array_equal(sb.detach().cpu().numpy()[:, :M + K], sc.numpy())
 
 
 CASES = ["white_v03_c0", "white_v03_c05_det", "white_v065_c1", "wdepth_v03_c05", "wdepth_v065_c1",
@@ -123,17 +123,28 @@ def _render(rend, fx, dev, inject):
                        t_rand_out=g(fx["t_rand_out"], dev), **kw)
 
 
+@pytest.mark.parametrize("grad_mode", ["inference", "training"])
 @pytest.mark.parametrize("name", CASES)
-def test_render_vs_reference_golden(env, dev, golden, name):
+def test_render_vs_reference_golden(env, dev, golden, name, grad_mode):
     """End to end against the REFERENCE's outputs: per-ray tensors at 1e-4; with the reference's z injected
     also the per-sample tensors."""
     fx = golden(name)
     rend, _, _ = env(int(fx["seed"]), bool(fx["wdepth"]), float(fx["variance"]), n_importance=int(fx["n_importance"]))
+    # 'inference' = torch.no_grad() path (per-call buffers); 'training' = the autograd node with kept activations
+    torch.set_grad_enabled(grad_mode == "training")
+    try:
+        _check_golden(rend, fx, dev)
+    finally:
+        torch.set_grad_enabled(True)
+
+
+def _check_golden(rend, fx, dev):
     out = _render(rend, fx, dev, inject=False)
+    assert out["color_fine"].requires_grad == torch.is_grad_enabled()
     keys = ["color_fine", "weight_sum", "s_val", "z_vals", "gradient_error", "inside_sphere"] + (["render_feats"] if fx["wdepth"] else [])
     for k in keys:
         assert tuple(out[k].shape) == fx["out_" + k].shape, k
-        assert relmax(out[k].cpu().numpy(), fx["out_" + k]) < 1e-4, k
+        assert relmax(out[k].detach().cpu().numpy(), fx["out_" + k]) < 1e-4, k
     assert set(out.keys()) == {"render_feats", "color_fine", "s_val", "cdf_fine", "weight_sum", "weight_max", "gradients",
                                "weights", "z_vals", "gradient_error", "inside_sphere"}
     if not fx["wdepth"]:
@@ -146,7 +157,7 @@ def test_render_vs_reference_golden(env, dev, golden, name):
     tol = 1e-4 if float(fx["variance"]) < 0.5 else 3e-4
     for k in ("weights", "cdf_fine", "gradients", "weight_max", "color_fine", "weight_sum"):
         assert tuple(out[k].shape) == fx["out_" + k].shape, k
-        assert relmax(out[k].cpu().numpy(), fx["out_" + k]) < (1e-4 if k in ("color_fine", "weight_sum", "gradients") else tol), k
+        assert relmax(out[k].detach().cpu().numpy(), fx["out_" + k]) < (1e-4 if k in ("color_fine", "weight_sum", "gradients") else tol), k
 
 
 def test_sampler_rounds_vs_oracle(env, dev, golden):
@@ -157,14 +168,14 @@ def test_sampler_rounds_vs_oracle(env, dev, golden):
     rend, nets, _ = env(int(fx["seed"]), False, 0.3)
     o, d, near, far = (g(fx[k], dev) for k in ("rays_o", "rays_d", "near", "far"))
     z, z_out = rend._sample(o, d, near.reshape(-1), far.reshape(-1), 1.0, g(fx["t_rand"], dev), g(fx["t_rand_out"], dev), None)
-    zz = z.cpu().numpy()
+    zz = z.detach().cpu().numpy()
     assert zz.shape == (int(fx["B"]), 128) and np.all(np.diff(zz, axis=1) >= 0)
     ref = fx["z_vals_inside"]
     frac_bad = np.mean(np.abs(zz - ref) > 1e-4)
     assert frac_bad < 0.03, frac_bad
     tt = torch.tensor
     zc, zo = orc.coarse_and_outside_z(tt(fx["near"]), tt(fx["far"]), orc.RendererConf(), 1.0, tt(fx["t_rand"]), tt(fx["t_rand_out"]))
-    assert relmax(z_out.cpu().numpy(), zo.numpy()) < 1e-6
+    assert relmax(z_out.detach().cpu().numpy(), zo.numpy()) < 1e-6
 
 
 @pytest.mark.parametrize("B", [1, 3, 130])
@@ -184,7 +195,7 @@ def test_render_ragged_batches_vs_oracle(env, dev, B):
     out = rend.render(g(o, dev), g(d, dev), g(near, dev), g(far, dev), background_rgb=torch.ones(1, 3, device=dev),
                       cos_anneal_ratio=0.7, t_rand=g(t1, dev), t_rand_out=g(t2, dev))
     for k in ("color_fine", "weight_sum", "render_feats", "gradient_error"):
-        assert relmax(out[k].cpu().numpy(), ref[k].detach().numpy()) < 1e-4, k
+        assert relmax(out[k].detach().cpu().numpy(), ref[k].detach().numpy()) < 1e-4, k
 
 
 def test_lattice_vs_reference(env, dev, golden):

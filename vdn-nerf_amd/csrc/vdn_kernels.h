@@ -22,6 +22,7 @@ using DwDesc = ::VdnDwDesc;
 using DwFinalizeDesc = ::VdnDwFinalizeDesc;
 using WeightNormBwdDesc = ::VdnWeightNormBwdDesc;
 using CompositeBwdArgs = ::VdnCompositeBwdArgs;
+using LossArgs = ::VdnLossArgs;
 
 // Kernels needing more than 64 KiB of dynamic LDS opt in once per process.
 template <class K>

@@ -75,19 +75,8 @@ class _RenderCoreFn(torch.autograd.Function):
             raise RuntimeError("NeuSRenderer.render was called again before this result's backward(): the training "
                                "engine keeps the activations of the latest forward only")
         g_feats = g_feats if (g_feats is not None and g_feats.numel() > 0) else None
-        grads = eng.backward(g_color, g_feats, g_weights, g_eik)
-        r = eng.r
-        flat = []
-        for key, mod in (("nerf", r.nerf), ("sdf", r.sdf_network), ("variance", r.deviation_network),
-                         ("color", r.color_network), ("vdn", r.depth_network)):
-            if mod is None:
-                continue
-            if key == "variance":
-                flat.append(grads["variance"])
-            elif key in grads:
-                flat += grads[key]
-            else:
-                flat += [None] * len(list(mod.parameters()))      # network not on the path (n_outside == 0)
+        eng.backward(g_color, g_feats, g_weights, g_eik)
+        flat = eng.param_grads(clone=True)        # clones: the engine's buffers are reused by the next step
         assert len(flat) == ctx.n_params
         return (None,) * 7 + tuple(flat)
 

@@ -167,6 +167,10 @@ class NetImages:
         self.chunk_table = torch.from_numpy(ch.view(np.uint8)).to(self.device)
         self._n_wn, self._n_ch = len(wn), len(ch)
 
+    def invalidate(self):
+        """Parameters were written outside torch's version tracking (fused Adam through raw pointers)."""
+        self._key = None
+
     def refresh(self, stream):
         """Re-materialise W_eff and all chunk images if any parameter changed (in place or rebound)."""
         params = [t for n in self.names for t in self.matrices[n] if t is not None]

@@ -82,6 +82,7 @@ def load():
     for fn in FUNCTIONS:
         f = getattr(lib, fn)       # AttributeError here = header/library mismatch
         f.restype = ctypes.c_int
+    lib.vdn_adam_step.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int64] + [ctypes.c_float] * 4 + [ctypes.c_int32, ctypes.c_void_p]
     if lib.vdn_abi_version() != int(re.search(r"#define\s+VDN_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1)):
         raise VdnError("libvdn_render.so ABI version does not match include/vdn_render.h; rebuild")
     _lib = lib

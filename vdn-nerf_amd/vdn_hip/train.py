@@ -21,17 +21,17 @@ def _stream():
 
 
 class _Net:
-    """Gradient-side state of one network: d W_eff flat buffer, per-parameter gradient buffers."""
+    """Gradient-side state of one network: d W_eff flat buffer, per-parameter gradient views."""
 
-    def __init__(self, module, dev):
+    def __init__(self, module, dev, grad_views):
         self.module = module
         self.img = module._images()
         self.dweff = torch.zeros_like(self.img.weff)
-        self.grads = {}          # id(param) -> persistent grad tensor
+        self.grads = {}          # id(param) -> view into the engine's flat gradient buffer
         for name, (g, v, b) in self.img.matrices.items():
             for t in (g, v, b):
                 if t is not None:
-                    self.grads[id(t)] = torch.zeros_like(t)
+                    self.grads[id(t)] = grad_views[id(t)]
 
     def dweff_view(self, name):
         v = self.img.matrices[name][1]
@@ -89,11 +89,21 @@ class TrainEngine:
             w["d_bg_density"], w["d_bg_rgb"] = f(Q), f(Q, 3)
             w["d_bg_feat"] = f(Q, 96) if self.wdepth else None
             w["nf_do"], w["nf_dv"], w["nf_dhead"], w["nf_dh"] = f(Q, 128 if self.wdepth else 32), f(Q, 128), f(Q, 288), f(8, Q, 256)
-        self.nets = {"sdf": _Net(renderer.sdf_network, dev), "color": _Net(renderer.color_network, dev)}
+        # one flat gradient buffer over all parameters, in dpt_runner.py:121-130 order (nerf, sdf, variance,
+        # colour, vdn): the single message of the data-parallel all-reduce
+        self.params = renderer._all_parameters()
+        total = sum(p.numel() for p in self.params)
+        self.grad_flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        views, off = {}, 0
+        for p in self.params:
+            views[id(p)] = self.grad_flat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+        self.grad_views = views
+        self.nets = {"sdf": _Net(renderer.sdf_network, dev, views), "color": _Net(renderer.color_network, dev, views)}
         if self.wdepth:
-            self.nets["vdn"] = _Net(renderer.depth_network, dev)
+            self.nets["vdn"] = _Net(renderer.depth_network, dev, views)
         if O > 0:
-            self.nets["nerf"] = _Net(renderer.nerf, dev)
+            self.nets["nerf"] = _Net(renderer.nerf, dev, views)
         self._build_dw_plan()
 
     # ------------------------------------------------------------------------------------------
@@ -340,7 +350,8 @@ class TrainEngine:
                 c.d_bg_feat = w["d_bg_feat"].data_ptr()
                 if g_feat is None:
                     w["d_bg_feat"].zero_()
-        c.d_var_partial, c.d_variance = w["d_var_partial"].data_ptr(), w["d_variance"].data_ptr()
+        c.d_var_partial = w["d_var_partial"].data_ptr()
+        c.d_variance = self.grad_views[id(r.deviation_network.variance)].data_ptr()
         lib.call("vdn_alpha_composite_bwd", c, st)
 
         def rnet_bwd(net, g_out, out, save_h, dout, dh, d_out, module, accumulate):
@@ -386,8 +397,9 @@ class TrainEngine:
         lib.call("vdn_dw_finalize", lib.ptr(self.fin_table), self.n_dw, self.fin_max_M, 0, st)
         lib.call("vdn_dw_finalize", lib.ptr(self.fin_table), self.n_dw, self.fin_max_M, 1, st)
         lib.call("vdn_weightnorm_bwd", lib.ptr(self.wn_table), self.n_wn, self.wn_max_rows, st)
-        out = {}
-        for key, net in self.nets.items():
-            out[key] = [net.grads[id(p)].clone() for p in net.module.parameters()]
-        out["variance"] = w["d_variance"].reshape(()).clone()
-        return out
+        # gradients now sit in self.grad_flat (views per parameter in self.grad_views)
+        return self.grad_flat
+
+    def param_grads(self, clone=True):
+        """Per-parameter gradients in renderer._all_parameters() order."""
+        return [self.grad_views[id(p)].clone() if clone else self.grad_views[id(p)] for p in self.params]

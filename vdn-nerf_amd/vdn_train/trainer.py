@@ -1,0 +1,162 @@
+"""Training loop semantics of the reference's Runner.train (dpt_runner.py:173-299, 304-323, 350-381)
+on the MI355X engine: loss, Adam, warm-up + cosine learning rate, cos-anneal, the VDN depth-loss
+ramp, checkpoints in the reference's key schema, and ray-sharded data parallelism.
+
+The hot loop does not go through autograd: TrainEngine.forward -> fused loss kernel ->
+TrainEngine.backward -> (one all-reduce of the flat gradient) -> fused Adam on flat buffers.
+"""
+import math
+
+import numpy as np
+import torch
+
+from vdn_hip import lib
+from vdn_hip.train import TrainEngine
+
+DEFAULT_TRAIN_CONF = dict(learning_rate=5e-4, learning_rate_alpha=0.05, end_iter=300000, warm_up_end=5000, anneal_end=50000,
+                          igr_weight=0.1, mask_weight=0.0, use_white_bkgd=True, extract_depth=False, depth_start_iter=5000)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Trainer:
+    def __init__(self, renderer, batch_size, device, conf=None, world_size=1, rank=0):
+        self.r, self.B, self.dev = renderer, batch_size, torch.device(device)
+        self.conf = dict(DEFAULT_TRAIN_CONF)
+        self.conf.update(conf or {})
+        self.world, self.rank = world_size, rank
+        self.iter_step, self.depth_iter = 0, 0
+        # flatten: every Parameter becomes a view of one buffer (names / state_dict unchanged), so Adam is one
+        # launch and the gradient all-reduce one message
+        self.params = renderer._all_parameters()
+        total = sum(p.numel() for p in self.params)
+        self.param_flat = torch.empty(total, dtype=torch.float32, device=self.dev)
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                n = p.numel()
+                self.param_flat[off:off + n].copy_(p.detach().reshape(-1))
+                p.data = self.param_flat[off:off + n].view(p.shape)
+                off += n
+        self.exp_avg = torch.zeros_like(self.param_flat)
+        self.exp_avg_sq = torch.zeros_like(self.param_flat)
+        self.engine = TrainEngine(renderer, batch_size, self.dev)
+        B, T = batch_size, self.engine.T
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.dev)
+        self.g_color, self.g_weights, self.g_eik, self.scalars = f(B, 3), f(B, T), f(1), f(6)
+        self.g_feats = f(B, 96) if self.engine.wdepth else None
+        self.bg = torch.ones(3, device=self.dev) if self.conf["use_white_bkgd"] else None
+
+    # ---- schedules (dpt_runner.py:304-319, 167-171)
+    def learning_rate(self):
+        c = self.conf
+        if self.iter_step < c["warm_up_end"]:
+            factor = self.iter_step / c["warm_up_end"]
+        else:
+            progress = (self.iter_step - c["warm_up_end"]) / (c["end_iter"] - c["warm_up_end"])
+            factor = (math.cos(math.pi * progress) + 1.0) * 0.5 * (1 - c["learning_rate_alpha"]) + c["learning_rate_alpha"]
+        return c["learning_rate"] * factor
+
+    def cos_anneal_ratio(self):
+        return 1.0 if self.conf["anneal_end"] == 0 else min(1.0, self.iter_step / self.conf["anneal_end"])
+
+    def depth_iter_weight(self, total_iter=5000):
+        return 1.0 / (math.exp(-10 * (self.depth_iter / total_iter - 0.5)) + 1.0)
+
+    # ---- one iteration of dpt_runner.py:197-259
+    def train_step(self, rays_o, rays_d, near, far, true_rgb, gt_feats=None, mask=None, t_rand=None, t_rand_out=None,
+                   z_vals_inject=None):
+        r, eng, st = self.r, self.engine, _stream()
+        B = self.B
+        with torch.no_grad():
+            z, z_out = r._sample(rays_o, rays_d, near.reshape(B), far.reshape(B), r.perturb, t_rand, t_rand_out, z_vals_inject)
+        w = eng.forward(rays_o, rays_d, z.contiguous(), z_out, self.bg, self.cos_anneal_ratio())
+        if self.world > 1:
+            import torch.distributed as dist
+            # the eikonal term is a ratio of sums over the GLOBAL batch (renderer.py:313-315)
+            dist.all_reduce(w["eik"][1:3])
+            w["eik"][0:1].copy_(w["eik"][1:2] / (w["eik"][2:3] + 1e-5))
+        depth_on = self.conf["extract_depth"] and self.iter_step > self.conf["depth_start_iter"] and gt_feats is not None
+        a = lib.VdnLossArgs()
+        a.color, a.true_rgb, a.weights, a.eik = w["color"].data_ptr(), true_rgb.data_ptr(), w["weights"].data_ptr(), w["eik"].data_ptr()
+        a.mask = mask.data_ptr() if mask is not None else None
+        a.igr_weight, a.mask_weight = self.conf["igr_weight"], self.conf["mask_weight"]
+        a.grad_scale = 1.0 / self.world
+        a.B, a.T, a.C = B, eng.T, 96
+        a.g_color, a.g_eik, a.out_scalars = self.g_color.data_ptr(), self.g_eik.data_ptr(), self.scalars.data_ptr()
+        if self.conf["mask_weight"] != 0.0:
+            a.g_weights = self.g_weights.data_ptr()
+        if depth_on:
+            a.feats, a.gt_feats, a.g_feats = w["feat_out"].data_ptr(), gt_feats.data_ptr(), self.g_feats.data_ptr()
+            a.depth_weight = self.depth_iter_weight()
+            self.depth_iter += 1
+        lib.call("vdn_loss_fwd_bwd", a, st)
+        grad = eng.backward(self.g_color, self.g_feats if depth_on else None,
+                            self.g_weights if self.conf["mask_weight"] != 0.0 else None, self.g_eik)
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(grad)                  # one flat message: all gradients of all networks
+        lib.load().vdn_adam_step(self.param_flat.data_ptr(), grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                 self.param_flat.numel(), self.learning_rate(), 0.9, 0.999, 1e-8, self.iter_step + 1 - self._step0(), st)
+        for net in eng.nets.values():
+            net.img.invalidate()                   # weights changed behind torch's version counters
+        self.iter_step += 1
+        return self.scalars        # device tensor [loss, color_loss, psnr, eikonal, depth_loss, mask_loss]; no host sync here
+
+    def _step0(self):
+        return getattr(self, "_adam_step_offset", 0)
+
+    # ---- checkpoints in the reference's schema (dpt_runner.py:366-381, 350-359)
+    def state_dict(self):
+        r = self.r
+        state, off = {}, 0
+        for i, p in enumerate(self.params):
+            n = p.numel()
+            state[i] = {"step": torch.tensor(float(self.iter_step - self._step0())),
+                        "exp_avg": self.exp_avg[off:off + n].view(p.shape).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[off:off + n].view(p.shape).clone()}
+            off += n
+        opt = {"state": state if self.iter_step > self._step0() else {},
+               "param_groups": [{"lr": self.learning_rate(), "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0, "amsgrad": False,
+                                 "params": list(range(len(self.params)))}]}
+        cl = lambda m: {k: v.detach().clone() for k, v in m.state_dict().items()}
+        return {"nerf": cl(r.nerf), "sdf_network_fine": cl(r.sdf_network), "variance_network_fine": cl(r.deviation_network),
+                "color_network_fine": cl(r.color_network),
+                "depth_network_fine": cl(r.depth_network) if r.depth_network is not None else None,
+                "optimizer": opt, "iter_step": self.iter_step}
+
+    def save_checkpoint(self, path):
+        torch.save(self.state_dict(), path)
+
+    def load_checkpoint(self, path_or_dict):
+        ck = torch.load(path_or_dict, map_location=self.dev) if isinstance(path_or_dict, str) else path_or_dict
+        r = self.r
+        with torch.no_grad():
+            def load(mod, sd, strict=True):
+                own = dict(mod.named_parameters())
+                for k, v in sd.items():
+                    if k in own:
+                        own[k].copy_(v.to(self.dev))           # in place: parameters stay views of the flat buffer
+                    elif strict:
+                        raise KeyError(k)
+            load(r.nerf, ck["nerf"], strict=False)                                   # dpt_runner.py:352
+            load(r.sdf_network, ck["sdf_network_fine"])
+            load(r.deviation_network, ck["variance_network_fine"])
+            load(r.color_network, ck["color_network_fine"])
+            self.iter_step = int(ck["iter_step"])
+            if (r.depth_network is not None and ck.get("depth_network_fine") is not None
+                    and self.iter_step > self.conf["depth_start_iter"]):             # dpt_runner.py:358-359
+                load(r.depth_network, ck["depth_network_fine"])
+            st = ck["optimizer"]["state"]
+            off = 0
+            steps = 0
+            for i, p in enumerate(self.params):
+                n = p.numel()
+                if i in st:
+                    self.exp_avg[off:off + n].copy_(st[i]["exp_avg"].reshape(-1).to(self.dev))
+                    self.exp_avg_sq[off:off + n].copy_(st[i]["exp_avg_sq"].reshape(-1).to(self.dev))
+                    steps = int(st[i]["step"])
+                off += n
+            self._adam_step_offset = self.iter_step - steps
