@@ -25,6 +25,7 @@ import torch
 # algorithmic FLOPs (2 per MAC, GEMM work only) - SURVEY.md 8d
 F_SDF, F_SDF1, F_GRAD, F_COL, F_VDN, F_NERF, F_NERF_DPT = 1049088, 918016, 918016, 542720, 590336, 1208320, 1232896
 FLOP_PER_RAY_FWD = 112 * F_SDF1 + 128 * (F_SDF + F_GRAD) + 128 * F_COL + 160 * F_NERF          # 617 406 464
+FLOP_PER_RAY_TRAIN = 112 * F_SDF1 + 3 * (128 * (F_SDF + F_GRAD) + 128 * F_COL + 160 * F_NERF)  # 1 646 583 808
 PEAK = {"f32": 157.3e12, "bf16": 2.5e15}     # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -44,7 +45,8 @@ def time_kernel(fn, iters=10):
 
 
 def cpu_baseline(B, seed, max_seconds=30.0):
-    """The oracle's render() forward on the host cores, same workload, bounded sample."""
+    """The oracle's training step (render forward + loss + autograd backward) on the host cores, same workload,
+    bounded sample. Adam is excluded (negligible against the 8 s step)."""
     import oracle.neus_oracle as orc
     from vdn_train import synth
     st = synth.make_all_states(seed, wdepth=False)
@@ -54,22 +56,28 @@ def cpu_baseline(B, seed, max_seconds=30.0):
     near, far = synth.near_far_from_sphere(o, d)
     t1, t2 = synth.jitter(seed, 0, B)
     tt = torch.tensor
+    nets = orc.nets_from_numpy(st, requires_grad=True)
     args = (nets, tt(o), tt(d), tt(near), tt(far))
     kw = dict(background_rgb=torch.ones(1, 3), cos_anneal_ratio=0.5, t_rand=tt(t1), t_rand_out=tt(t2))
+    rgb = tt(synth.target_colors(o, d))
+    params = [p for _, p in orc.all_params(nets)]
     cores = torch.get_num_threads()
+
+    def one():
+        lo = orc.loss_from_render(orc.render(*args, **kw), rgb)
+        torch.autograd.grad(lo["loss"], params, allow_unused=True)
     t0 = time.time()
-    with torch.no_grad():
-        pass
-    orc.render(*args, **kw)                     # warm-up (first call pays allocator / thread-pool start)
+    one()                                       # warm-up (first call pays allocator / thread-pool start)
     warm = time.time() - t0
     times = []
-    while len(times) < 5 and (sum(times) + warm) < max_seconds:
+    while len(times) < 3 and (sum(times) + warm) < max_seconds:
         t = time.time()
-        orc.render(*args, **kw)
+        one()
         times.append(time.time() - t)
     med = float(np.median(times)) if times else warm
     return {"value": B / med, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": "%d x render() forward of %d rays (64+64+32 samples), oracle fp32 on %d threads, median" % (max(len(times), 1), B, cores)}
+            "sample": "%d x (render forward + loss + backward) of %d rays (64+64+32 samples), oracle fp32 on %d threads, median"
+                      % (max(len(times), 1), B, cores)}
 
 
 def main():
@@ -92,9 +100,11 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from vdn_train import synth, factory
+    from vdn_train.trainer import Trainer
     seed, B = 0, args.batch
     st = synth.make_all_states(seed, wdepth=False)
     rend = factory.build_renderer(wdepth=False, device=dev, states=st)
+    trainer = Trainer(rend, B, dev, world_size=world, rank=rank)
     cams = synth.make_cameras(seed)
     perm = np.argsort(synth.uniform(seed, "perm", (len(cams),)))
     bg = torch.ones(1, 3, device=dev)
@@ -103,13 +113,13 @@ def main():
     def batch(step):
         o, d = synth.random_pixel_batch(seed, step, int(perm[step % len(perm)]), B, rank=rank, cams=cams)
         near, far = synth.near_far_from_sphere(o, d)
-        return g(o), g(d), g(near), g(far)
+        return g(o), g(d), g(near), g(far), g(synth.target_colors(o, d))
 
     batches = [batch(s) for s in range(args.warmup + args.steps)]     # resident in HBM before the timed region
 
     def step(i):
-        o, d, near, far = batches[i]
-        return rend.render(o, d, near, far, background_rgb=bg, cos_anneal_ratio=0.5)
+        # one iteration of dpt_runner.py:197-259: sample -> render -> loss -> backward -> (all-reduce) -> Adam
+        return trainer.train_step(*batches[i])
 
     for i in range(args.warmup):
         step(i)
@@ -133,25 +143,41 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    loss_final = float(out[0].item())
+    # forward-only render() throughput on the same rays (inference path), reported beside the headline
+    with torch.no_grad():
+        for i in range(2):
+            rend.render(*batches[i][:4], background_rgb=bg, cos_anneal_ratio=0.5)
+        fence()
+        t1 = time.time()
+        nf = max(5, args.steps // 2)
+        for i in range(nf):
+            rend.render(*batches[i % len(batches)][:4], background_rgb=bg, cos_anneal_ratio=0.5)
+        fence()
+        fwd_rays_per_s = world * B * nf / (time.time() - t1)
+
     if rank == 0:
         rays = world * B * args.steps
         value = rays / dt
         # dominant kernel: fused PE -> SDF MLP -> feature + analytic gradient sweep, 65 536 points
-        o, d, near, far = batches[0]
-        z, _ = rend._sample(o, d, near.reshape(-1), far.reshape(-1), 0.0, None, None, None)
-        _, mid = rend._sections(z, z.shape[1], 2.0 / rend.n_samples)
-        tk = time_kernel(lambda: rend.sdf_network._run(1, rays=(o, d, mid)))
+        o, d, near, far = batches[0][:4]
+        with torch.no_grad():
+            z, _ = rend._sample(o, d, near.reshape(-1), far.reshape(-1), 0.0, None, None, None)
+            _, mid = rend._sections(z, z.shape[1], 2.0 / rend.n_samples)
+            tk = time_kernel(lambda: rend.sdf_network._run(1, rays=(o, d, mid)))
         flops = (F_SDF + F_GRAD) * mid.numel()
         dtype = "f32"
         line = {
             "metric": "rays/sec (512-ray batch, 128 samples/ray)", "value": value, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": "NeuSRenderer.render forward, womsk_white shapes (SDF 8x256 + colour 4x256 + NeRF 8x256), "
-                                   "512 rays x (64 coarse + 64 importance + 32 outside) per GPU per step, hierarchical sampling on",
+            "config": {"workload": "training step of womsk_white (hierarchical sampling + render forward + backward + gradient "
+                                   "all-reduce + Adam): SDF 8x256 + colour 4x256 + NeRF 8x256, 512 rays x (64 coarse + 64 importance "
+                                   "+ 32 outside) per GPU per step",
                        "rays_per_gpu": B, "samples_per_ray": 128, "outside_samples": 32, "parallelism": "dp%d" % world,
-                       "flop_per_ray": FLOP_PER_RAY_FWD},
-            "model_flops_per_s": value * FLOP_PER_RAY_FWD,
+                       "flop_per_ray": FLOP_PER_RAY_TRAIN, "allreduce_bytes": trainer.param_flat.numel() * 4},
+            "model_flops_per_s": value * FLOP_PER_RAY_TRAIN,
+            "forward_only_rays_per_s": fwd_rays_per_s, "final_loss": loss_final,
             "roofline": {"bound": "mfma", "kernel": "sdf_f32_kernel<1> (PE + SDF MLP + gradient sweep, 65536 points)",
                          "achieved": flops / tk / 1e12, "peak": PEAK[dtype] / 1e12, "unit": "TFLOP/s",
                          "frac": flops / tk / PEAK[dtype], "traffic": None, "kernel_ms": tk * 1e3},

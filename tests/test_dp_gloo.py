@@ -1,0 +1,83 @@
+"""Data-parallel recipe (vdn_train/dp.py) on CPU with gloo, world_size 2: ray shards + eikonal
+numerator/denominator all-reduce + one flat gradient all-reduce == one process on the concatenated
+batch. Compute is the oracle (this is a test of the host-side DP logic, not of the kernels)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle.neus_oracle as orc
+from vdn_train import dp, synth
+
+B_PER_RANK, WORLD, SEED = 6, 2, 17
+
+
+def _batch(rank):
+    cams = synth.make_cameras(SEED)
+    px = np.floor(synth.uniform(SEED, "dp/x%d" % rank, (B_PER_RANK,)) * 400) + 200
+    py = np.floor(synth.uniform(SEED, "dp/y%d" % rank, (B_PER_RANK,)) * 400) + 200
+    o, d = synth.pixel_rays(cams[0], px, py)
+    near, far = synth.near_far_from_sphere(o, d)
+    t1, t2 = synth.jitter(SEED, 0, B_PER_RANK, rank=rank)
+    return [torch.tensor(x) for x in (o, d, near, far, t1, t2, synth.target_colors(o, d))]
+
+
+def _render(nets, b):
+    o, d, near, far, t1, t2, rgb = b
+    return orc.render(nets, o, d, near, far, background_rgb=torch.ones(1, 3), cos_anneal_ratio=0.5, t_rand=t1, t_rand_out=t2)
+
+
+def _worker(rank, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    torch.set_num_threads(2)
+    nets = orc.nets_from_numpy(synth.make_all_states(SEED), requires_grad=True)
+    b = _batch(rank)
+    out = _render(nets, b)
+    nd = torch.stack([out["eik_num"].detach(), out["eik_den"].detach()])
+    local_num = nd[0].clone()
+    dp.global_eikonal(nd)                                   # in place: global (num, den)
+    eik = (out["eik_num"] + (nd[0] - local_num)) / (nd[1] + 1e-5)     # gradient flows through the local numerator only
+    loss = (out["color_fine"] - b[6]).abs().sum() / (B_PER_RANK + 1e-5) / WORLD + 0.1 * eik / WORLD * WORLD
+    # note: the eikonal term is already the GLOBAL value; each rank differentiates only its own numerator
+    named = orc.all_params(nets)
+    gs = torch.autograd.grad((out["color_fine"] - b[6]).abs().sum() / (B_PER_RANK + 1e-5) / WORLD + 0.1 * eik, [p for _, p in named], allow_unused=True)
+    flat = torch.cat([(torch.zeros_like(p) if gr is None else gr).reshape(-1) for (_, p), gr in zip(named, gs)])
+    # remove the double-counted constant part: d/dtheta of (nd[0]-local_num) is zero, so nothing to fix
+    dp.allreduce_flat(flat)
+    if rank == 0:
+        q.put((flat.numpy(), float(eik)))
+    dist.destroy_process_group()
+
+
+def test_dp_equals_single_process_on_concatenated_batch():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, port, q)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    flat, eik = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    # single process, concatenated batch
+    nets = orc.nets_from_numpy(synth.make_all_states(SEED), requires_grad=True)
+    bs = [_batch(r) for r in range(WORLD)]
+    cat = [torch.cat([bs[r][i] for r in range(WORLD)], 0) for i in range(7)]
+    out = _render(nets, cat)
+    # mean of the per-rank colour means == colour mean of the union for equal shards (mask_sum = B + 1e-5 each)
+    col = sum((out["color_fine"][r * B_PER_RANK:(r + 1) * B_PER_RANK] - bs[r][6]).abs().sum() / (B_PER_RANK + 1e-5) for r in range(WORLD)) / WORLD
+    loss = col + 0.1 * out["gradient_error"]
+    named = orc.all_params(nets)
+    gs = torch.autograd.grad(loss, [p for _, p in named], allow_unused=True)
+    ref = torch.cat([(torch.zeros_like(p) if gr is None else gr).reshape(-1) for (_, p), gr in zip(named, gs)]).numpy()
+    assert abs(eik - out["gradient_error"].item()) < 1e-6 * abs(eik)
+    assert flat.shape == ref.shape == (1409087,)             # the all-reduce payload of SURVEY.md 8e
+    assert np.abs(flat - ref).max() < 1e-5 * np.abs(ref).max()

@@ -12,6 +12,7 @@ import torch
 
 from vdn_hip import lib
 from vdn_hip.train import TrainEngine
+from vdn_train import dp
 
 DEFAULT_TRAIN_CONF = dict(learning_rate=5e-4, learning_rate_alpha=0.05, end_iter=300000, warm_up_end=5000, anneal_end=50000,
                           igr_weight=0.1, mask_weight=0.0, use_white_bkgd=True, extract_depth=False, depth_start_iter=5000)
@@ -74,10 +75,8 @@ class Trainer:
             z, z_out = r._sample(rays_o, rays_d, near.reshape(B), far.reshape(B), r.perturb, t_rand, t_rand_out, z_vals_inject)
         w = eng.forward(rays_o, rays_d, z.contiguous(), z_out, self.bg, self.cos_anneal_ratio())
         if self.world > 1:
-            import torch.distributed as dist
             # the eikonal term is a ratio of sums over the GLOBAL batch (renderer.py:313-315)
-            dist.all_reduce(w["eik"][1:3])
-            w["eik"][0:1].copy_(w["eik"][1:2] / (w["eik"][2:3] + 1e-5))
+            w["eik"][0:1].copy_(dp.global_eikonal(w["eik"][1:3]).reshape(1))
         depth_on = self.conf["extract_depth"] and self.iter_step > self.conf["depth_start_iter"] and gt_feats is not None
         a = lib.VdnLossArgs()
         a.color, a.true_rgb, a.weights, a.eik = w["color"].data_ptr(), true_rgb.data_ptr(), w["weights"].data_ptr(), w["eik"].data_ptr()
@@ -96,8 +95,7 @@ class Trainer:
         grad = eng.backward(self.g_color, self.g_feats if depth_on else None,
                             self.g_weights if self.conf["mask_weight"] != 0.0 else None, self.g_eik)
         if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(grad)                  # one flat message: all gradients of all networks
+            dp.allreduce_flat(grad)                # one flat message: all gradients of all networks
         lib.load().vdn_adam_step(self.param_flat.data_ptr(), grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                                  self.param_flat.numel(), self.learning_rate(), 0.9, 0.999, 1e-8, self.iter_step + 1 - self._step0(), st)
         for net in eng.nets.values():
