@@ -69,16 +69,18 @@ typedef struct {
     int32_t P;                 /* B * n_per_ray (or number of explicit points) */
     float scale;               /* SDFNetwork(scale=...) */
     float* sdf;                /* out, see sdf_ld */
-    float* feat;               /* [P,256] out (mode 1) */
+    void* feat;               /* [P,256] out (mode 1) */
     float* normals;            /* [P,3] out (mode 1) */
-    float* S;                  /* [8,P,256] workspace: softplus'(pre-activation) per hidden layer (mode 1) */
+    void* S;                  /* [8,P,256] workspace: softplus'(pre-activation) per hidden layer (mode 1) */
     const float* w8row;        /* [256] row 0 of the last layer's effective weight (mode 1) */
     /* training-mode saves (mode 1), all optional (NULL = not saved): */
-    float* H;                  /* [8,P,256] H[l] = softplus output of layer l (= input of layer l+1) */
-    float* V;                  /* [8,P,256] V[l] = sweep value v_l = u_{l+1} * softplus'(a_l) */
-    float* PE;                 /* [P,64] positional encoding of the point (39 valid) */
+    void* H;                  /* [8,P,256] H[l] = softplus output of layer l (= input of layer l+1) */
+    void* V;                  /* [8,P,256] V[l] = sweep value v_l = u_{l+1} * softplus'(a_l) */
+    void* PE;                 /* [P,64] positional encoding of the point (39 valid) */
 } VdnSdfArgs;
 int vdn_sdf_mlp_fwd_f32(int mode, const VdnSdfArgs* args_host, void* stream);
+/* bf16-MFMA variant: blob holds bf16 chunks (fmt 1); feat / S / H / V / PE are bf16 arrays; sdf / normals stay f32. */
+int vdn_sdf_mlp_fwd_bf16(int mode, const VdnSdfArgs* args_host, void* stream);
 
 /* ---- RenderingNetwork (colour head / 96-channel VDN head): fields.py:148-176, mode 'idr' ------
  * points are regenerated as rays_o[r] + rays_d[r]*z[p] (renderer.py:233), r = p / n_per_ray. */
@@ -88,18 +90,19 @@ typedef struct {
     const float* rays_d;       /* [B,3] (also the view direction, renderer.py:234) */
     const float* z;            /* [P] section mid-points */
     const float* normals;      /* [P,3]  d sdf / d x */
-    const float* feat;         /* [P,256] SDF feature vector */
+    const void* feat;          /* [P,256] SDF feature vector (f32 or bf16, per entry point) */
     const float* pts;          /* [P,3] explicit points (standalone RenderingNetwork.forward) or NULL */
     const float* dirs;         /* [P,3] explicit view dirs or NULL (then rays_d[r]) */
     float* out;                /* [P,d_out] */
-    float* save_h;             /* [4,P,256] post-ReLU hidden activations (training) or NULL */
-    float* save_small;         /* [P,64] the non-feature inputs [points, PE(view), normals] (33 valid) or NULL */
+    void* save_h;              /* [4,P,256] post-ReLU hidden activations (training) or NULL */
+    void* save_small;          /* [P,64] the non-feature inputs [points, PE(view), normals] (33 valid) or NULL */
     int32_t n_per_ray;
     int32_t P;
     int32_t d_out;             /* 1..4 or 96 */
     int32_t squeeze_out;       /* 1: sigmoid (fields.py:170-171), 0: relu */
 } VdnRenderNetArgs;
 int vdn_rendernet_fwd_f32(const VdnRenderNetArgs* args_host, void* stream);
+int vdn_rendernet_fwd_bf16(const VdnRenderNetArgs* args_host, void* stream);   /* bf16-MFMA variant: bf16 chunk blob, bf16 activation workspaces */
 
 /* ---- background NeRF: fields.py:324-353 + the inverted-sphere points of renderer.py:112-115 ---- */
 typedef struct {
@@ -113,15 +116,16 @@ typedef struct {
     float* rgb;                /* [P,3] */
     float* feat;               /* [P,96] dpt_linear output, or NULL when gen_depth_feats is off */
     /* training-mode saves, optional: */
-    float* save_h;             /* [8,P,256] post-ReLU outputs of pts_linears.0..7 */
-    float* save_pe;            /* [P,96] PE10(pts4) (84 valid) */
-    float* save_feature;       /* [P,256] feature_linear output */
-    float* save_vpe;           /* [P,32] PE4(view) (27 valid) */
-    float* save_hv;            /* [P,128] views_linears.0 output (post-ReLU) */
+    void* save_h;             /* [8,P,256] post-ReLU outputs of pts_linears.0..7 */
+    void* save_pe;            /* [P,96] PE10(pts4) (84 valid) */
+    void* save_feature;       /* [P,256] feature_linear output */
+    void* save_vpe;           /* [P,32] PE4(view) (27 valid) */
+    void* save_hv;            /* [P,128] views_linears.0 output (post-ReLU) */
     int32_t n_per_ray;
     int32_t P;
 } VdnNerfArgs;
 int vdn_nerf_mlp_fwd_f32(const VdnNerfArgs* args_host, void* stream);
+int vdn_nerf_mlp_fwd_bf16(const VdnNerfArgs* args_host, void* stream);   /* bf16-MFMA variant: bf16 chunk blob, bf16 activation workspaces */
 
 /* ---- per-ray stages of NeuSRenderer (one wavefront per ray) -----------------------------------*/
 
@@ -223,10 +227,10 @@ typedef struct {
     const char* blob;          /* 'bwd' stream: W4^T, W3^T, W2^T, W1^T, W0^T */
     const float* g_out;        /* [P,d_out] gradient wrt the network output */
     const float* out;          /* [P,d_out] forward output (post sigmoid / relu) */
-    const float* save_h;       /* [4,P,256] from the forward */
-    float* delta_out;          /* [P,32] (d_out<=4) or [P,96]: delta of the last layer */
-    float* delta_h;            /* [4,P,256]: deltas of hidden layers 0..3 */
-    float* d_feat;             /* [P,256] d loss / d feature_vector */
+    const void* save_h;       /* [4,P,256] from the forward */
+    void* delta_out;          /* [P,32] (d_out<=4) or [P,96]: delta of the last layer */
+    void* delta_h;            /* [4,P,256]: deltas of hidden layers 0..3 */
+    void* d_feat;             /* [P,256] d loss / d feature_vector */
     float* d_normals;          /* [P,3] */
     int32_t acc_feat;          /* 0: overwrite d_feat, 1: add into it */
     int32_t acc_normals;       /* 0: overwrite d_normals, 1: add into it */
@@ -235,6 +239,7 @@ typedef struct {
     int32_t squeeze_out;
 } VdnRenderNetBwdArgs;
 int vdn_rendernet_bwd_f32(const VdnRenderNetBwdArgs* args_host, void* stream);
+int vdn_rendernet_bwd_bf16(const VdnRenderNetBwdArgs* args_host, void* stream);   /* bf16-MFMA variant: bf16 chunk blob, bf16 activation workspaces */
 
 /* backward of the background NeRF (fields.py:324-353). */
 typedef struct {
@@ -242,15 +247,16 @@ typedef struct {
     const float* g_density;    /* [P] */
     const float* g_rgb;        /* [P,3] */
     const float* g_feat;       /* [P,96] or NULL */
-    const float* save_h;       /* [8,P,256] */
-    const float* save_hv;      /* [P,128] */
-    float* delta_o;            /* [P,128] ([P,32] without the dpt head): delta of [rgb | dpt] */
-    float* delta_v;            /* [P,128] delta of views_linears.0 */
-    float* delta_head;         /* [P,288] delta of [feature_linear (256) | alpha_linear (1)] */
-    float* delta_h;            /* [8,P,256] deltas of pts_linears.0..7 */
+    const void* save_h;       /* [8,P,256] */
+    const void* save_hv;      /* [P,128] */
+    void* delta_o;            /* [P,128] ([P,32] without the dpt head): delta of [rgb | dpt] */
+    void* delta_v;            /* [P,128] delta of views_linears.0 */
+    void* delta_head;         /* [P,288] delta of [feature_linear (256) | alpha_linear (1)] */
+    void* delta_h;            /* [8,P,256] deltas of pts_linears.0..7 */
     int32_t P;
 } VdnNerfBwdArgs;
 int vdn_nerf_mlp_bwd_f32(const VdnNerfBwdArgs* args_host, void* stream);
+int vdn_nerf_mlp_bwd_bf16(const VdnNerfBwdArgs* args_host, void* stream);   /* bf16-MFMA variant: bf16 chunk blob, bf16 activation workspaces */
 
 /* backward of SDFNetwork.forward + .gradient (fields.py:72-108), i.e. including the double backward
  * through the input-gradient. Two chains (DESIGN.md 'Backward'):
@@ -271,31 +277,33 @@ typedef struct {
     int32_t P;
     float scale;
     const float* g_normals;    /* [P,3] d loss / d (d sdf/d x) */
-    const float* S;            /* [8,P,256] from the forward */
-    const float* V;            /* [8,P,256] from the forward */
-    float* UB;                 /* out, see above */
-    float* EX;                 /* out */
+    const void* S;            /* [8,P,256] from the forward */
+    const void* V;            /* [8,P,256] from the forward */
+    void* UB;                 /* out, see above */
+    void* EX;                 /* out */
 } VdnSdfRbarArgs;
 int vdn_sdf_bwd_rbar_f32(const VdnSdfRbarArgs* args_host, void* stream);
+int vdn_sdf_bwd_rbar_bf16(const VdnSdfRbarArgs* args_host, void* stream);   /* bf16-MFMA variant: bf16 chunk blob, bf16 activation workspaces */
 
 typedef struct {
     const char* blob;          /* 'fbar' stream: W8^T, W7^T .. W1^T */
     const float* g_sdf;        /* [P] */
-    const float* g_feat;       /* [P,256] */
-    const float* S;            /* [8,P,256] */
-    const float* EX;           /* [8,P,256] from rbar */
-    float* AB;                 /* out, see above */
+    const void* g_feat;       /* [P,256] */
+    const void* S;            /* [8,P,256] */
+    const void* EX;           /* [8,P,256] from rbar */
+    void* AB;                 /* out, see above */
     int32_t P;
     float scale;
 } VdnSdfFbarArgs;
 int vdn_sdf_bwd_fbar_f32(const VdnSdfFbarArgs* args_host, void* stream);
+int vdn_sdf_bwd_fbar_bf16(const VdnSdfFbarArgs* args_host, void* stream);   /* bf16-MFMA variant: bf16 chunk blob, bf16 activation workspaces */
 
 /* ---- weight gradients: dW[m,n] = sum_p A[p,m] * B[p,n] over one or two (A,B) segments ----------
  * (A = per-layer delta, B = the layer's input; the second segment carries the sweep term of the SDF
  * net). K is split across workgroups; partial slabs are reduced and scattered by vdn_dw_finalize. */
 typedef struct {
-    const float* A1; const float* B1;     /* [P,lda1], [P,ldb1] */
-    const float* A2; const float* B2;     /* second segment or NULL */
+    const void* A1; const void* B1;       /* [P,lda1], [P,ldb1]  (f32 or bf16, per entry point) */
+    const void* A2; const void* B2;       /* second segment or NULL */
     int32_t lda1, ldb1, lda2, ldb2;
     int32_t P;
     int32_t m_tiles, n_tiles;             /* 32-wide column tiles of A (outputs) and B (inputs); n_tiles may be 0 */
@@ -306,6 +314,8 @@ typedef struct {
     float* colsum;                        /* [splits, m_tiles*32] partial column sums of A1, or NULL */
 } VdnDwDesc;
 int vdn_dw_gemm_f32(const VdnDwDesc* descs_dev, int n_desc, int total_wgs, void* stream);
+/* bf16 variant: A/B are bf16 row-major; with two segments `splits` must be even (first half = segment 1). */
+int vdn_dw_gemm_bf16(const VdnDwDesc* descs_dev, int n_desc, int total_wgs, void* stream);
 
 /* reduce the K-splits and scatter from image coordinates to the parameter's own layout:
  * target[rmap[i]*t_stride + cmap[j]] (+)= scale * sum_s slab[s,i,j];  btarget[rmap[i]] (+)= bscale * sum_s colsum[s,i] */

@@ -1,0 +1,114 @@
+// Backward of RenderingNetwork (colour head / VDN head) on gfx950, shared body for both policies.
+// delta chain: delta_4 = g_out * act'(out); delta_{l-1} = (W_l^T delta_l) * [h_l > 0]; the last
+// transposed layer yields d loss / d [feature | points, PE(view), normals]. Per-layer deltas go to
+// HBM row-major for the weight-gradient GEMM. Adjoint of fields.py:148-176.
+#pragma once
+#include "mlp_engine.h"
+#include "vdn_kernels.h"
+
+namespace vdn {
+
+template <class P, int NT_OUT>
+__global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_bwd_kernel(RenderNetBwdArgs a) {
+    using ST = typename P::store_t;
+    constexpr int kSlot = P::chunk_bytes(8);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    WStream<P::kWaves, kSlot> ws;
+    ws.init(a.blob, smem);
+    const int lane = ws.lane, c = lane & 31, h = lane >> 5;
+    const long p_raw = ((long)blockIdx.x * P::kWaves + ws.wave) * 32 + c;
+    const bool ok = p_raw < a.P;
+    const long p = ok ? p_raw : (long)a.P - 1;
+    const long PS = (long)a.P * 256;
+    const ST* save_h = reinterpret_cast<const ST*>(a.save_h);
+    ST* delta_h = reinterpret_cast<ST*>(a.delta_h);
+    ST* delta_out = reinterpret_cast<ST*>(a.delta_out);
+    ST* d_feat = reinterpret_cast<ST*>(a.d_feat);
+
+    typename P::template Act<8> X, Y;
+    if constexpr (NT_OUT == 1) {
+        float dl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            dl[j] = 0.0f;
+            if (j < a.d_out) {
+                const float o = a.out[p * a.d_out + j], g = a.g_out[p * a.d_out + j];
+                dl[j] = a.squeeze_out ? g * o * (1.0f - o) : (o > 0.0f ? g : 0.0f);
+            }
+        }
+        const f32x16 t16 = vals_tile<4>(dl, h, 0);
+        X.set(0, t16);
+        P::store_tile(delta_out, p, 32, 0, h, t16, ok);
+    } else {
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) {
+            const f32x16 o = F32::load_tile(a.out, p, 96, kt, h);
+            const f32x16 g = F32::load_tile(a.g_out, p, 96, kt, h);
+            f32x16 dl;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) dl[t] = a.squeeze_out ? g[t] * o[t] * (1.0f - o[t]) : (o[t] > 0.0f ? g[t] : 0.0f);
+            X.set(kt, dl);
+            P::store_tile(delta_out, p, 96, kt, h, dl, ok);
+        }
+    }
+    auto ldH = [&](int l) VDN_INL { return [=](int nt) VDN_INL { return P::load_tile(save_h + l * PS, p, 256, nt, h); }; };
+    // D = acc * [saved activation > 0]; kept in registers and stored row-major
+    auto mask_store = [&](auto& D, int l) VDN_INL {
+        return [&D, l, delta_h, PS, p, ok, h](int nt, const f32x16& acc, const f32x16& hv) VDN_INL {
+            f32x16 o;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) o[t] = hv[t] > 0.0f ? acc[t] : 0.0f;
+            D.set(nt, o);
+            P::store_tile(delta_h + l * PS, p, 256, nt, h, o, ok);
+        };
+    };
+    constexpr int C8 = P::chunk_bytes(8), CO = P::chunk_bytes(NT_OUT);
+    ws.template start<CO>();
+    dense<P, NT_OUT, 8, C8, false>(ws, X, 0, ldH(3), mask_store(Y, 3));   // W4^T
+    dense<P, 8, 8, C8, false>(ws, Y, 0, ldH(2), mask_store(X, 2));        // W3^T
+    dense<P, 8, 8, C8, false>(ws, X, 0, ldH(1), mask_store(Y, 1));        // W2^T
+    dense<P, 8, 8, C8, false>(ws, Y, 0, ldH(0), mask_store(X, 0));        // W1^T
+    f32x16 SM[2];
+    dense<P, 8, 10, 0, false>(ws, X, 0, NoPre{}, [&](int nt, const f32x16& acc, int) VDN_INL {   // W0^T
+        if (nt < 8) {
+            f32x16 o = acc;
+            if (a.acc_feat) {
+                const f32x16 prev = P::load_tile(d_feat, p, 256, nt, h);
+#pragma unroll
+                for (int t = 0; t < 16; ++t) o[t] += prev[t];
+            }
+            P::store_tile(d_feat, p, 256, nt, h, o, ok);
+        } else {
+            SM[nt - 8] = acc;
+        }
+    });
+    float small[33];
+    tiles_vals<33, 2>(SM, h, small);        // [points(3), PE(view)(27), normals(3)]
+    if (ok && h == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float prev = a.acc_normals ? a.d_normals[p * 3 + d] : 0.0f;
+            a.d_normals[p * 3 + d] = prev + small[30 + d];
+        }
+    }
+}
+
+template <class P>
+int launch_rendernet_bwd(const VdnRenderNetBwdArgs* args, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!args || args->P <= 0 || !args->blob || !args->g_out || !args->out || !args->save_h || !args->delta_out ||
+        !args->delta_h || !args->d_feat || !args->d_normals) return -1;
+    if (!(args->d_out == 96 || (args->d_out >= 1 && args->d_out <= 4))) return -2;
+    const int ppw = P::kWaves * 32;
+    const int grid = (args->P + ppw - 1) / ppw;
+    const size_t lds = 2 * P::chunk_bytes(8);
+    static bool once = (allow_big_lds(rendernet_bwd_kernel<P, 1>, lds), allow_big_lds(rendernet_bwd_kernel<P, 3>, lds), true);
+    (void)once;
+    if (args->d_out == 96)
+        hipLaunchKernelGGL((rendernet_bwd_kernel<P, 3>), dim3(grid), dim3(P::kWaves * 64), lds, stream, *args);
+    else
+        hipLaunchKernelGGL((rendernet_bwd_kernel<P, 1>), dim3(grid), dim3(P::kWaves * 64), lds, stream, *args);
+    return (int)hipGetLastError();
+}
+
+}  // namespace vdn

@@ -1,0 +1,102 @@
+// RenderingNetwork forward (colour head d_out<=4, VDN feature head d_out=96) on gfx950, shared body
+// for both precision policies. Input assembly [points(3), PE4(view_dirs)(27), normals(3),
+// feature(256)] (mode 'idr'), 4 hidden ReLU layers of 256, sigmoid output. Replaces reference
+// dpt_models/fields.py:148-176. K order inside the kernel is [feature(256) | points, PE(view),
+// normals (33 -> 64)]; the weight image builder permutes the first layer's columns accordingly.
+#pragma once
+#include "mlp_engine.h"
+#include "vdn_kernels.h"
+
+namespace vdn {
+
+template <class P, int NT_OUT>   // 1: d_out <= 4 (colour); 3: d_out = 96 (VDN head)
+__global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_fwd_kernel(RenderNetArgs a) {
+    using ST = typename P::store_t;
+    constexpr int kSlot = P::chunk_bytes(10);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    WStream<P::kWaves, kSlot> ws;
+    ws.init(a.blob, smem);
+    const int lane = ws.lane, c = lane & 31, h = lane >> 5;
+    const long p_raw = ((long)blockIdx.x * P::kWaves + ws.wave) * 32 + c;
+    const bool ok = p_raw < a.P;
+    const long p = ok ? p_raw : (long)a.P - 1;
+    const long r = p / a.n_per_ray;
+    const ST* feat = reinterpret_cast<const ST*>(a.feat);
+    ST* save_h = reinterpret_cast<ST*>(a.save_h);
+    ST* save_small = reinterpret_cast<ST*>(a.save_small);
+    const long PS = (long)a.P * 256;
+
+    typename P::template Act<10> X;
+    typename P::template Act<8> Y;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) X.set(kt, P::load_tile(feat, p, 256, kt, h));
+    {
+        float small[33];
+        float dir[3];
+        const float z = a.pts ? 0.0f : a.z[p];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            dir[d] = a.dirs ? a.dirs[p * 3 + d] : a.rays_d[r * 3 + d];
+            small[d] = a.pts ? a.pts[p * 3 + d] : a.rays_o[r * 3 + d] + a.rays_d[r * 3 + d] * z;   // renderer.py:233
+            small[30 + d] = a.normals[p * 3 + d];
+        }
+        float pe[27];
+        posenc<3, 4>(dir, pe);
+#pragma unroll
+        for (int i = 0; i < 27; ++i) small[3 + i] = pe[i];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const f32x16 t16 = vals_tile<33>(small, h, kt);
+            X.set(8 + kt, t16);
+            if (save_small != nullptr) P::store_tile(save_small, p, 64, kt, h, t16, ok);
+        }
+    }
+    auto relu_into = [&](auto& D, int l) VDN_INL {
+        return [&D, l, save_h, PS, p, ok, h](int nt, const f32x16& acc, int) VDN_INL {
+            f32x16 o;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) o[t] = fmaxf(acc[t], 0.0f);
+            D.set(nt, o);
+            if (save_h != nullptr) P::store_tile(save_h + l * PS, p, 256, nt, h, o, ok);
+        };
+    };
+    constexpr int C10 = P::chunk_bytes(10), C8 = P::chunk_bytes(8);
+    ws.template start<C10>();
+    dense<P, 10, 8, C8, true>(ws, X, 0, NoPre{}, relu_into(Y, 0));
+    dense<P, 8, 8, C8, true>(ws, Y, 0, NoPre{}, relu_into(X, 1));
+    dense<P, 8, 8, C8, true>(ws, X, 0, NoPre{}, relu_into(Y, 2));
+    dense<P, 8, 8, C8, true>(ws, Y, 0, NoPre{}, relu_into(X, 3));
+    dense<P, 8, NT_OUT, 0, true>(ws, X, 0, NoPre{}, [&](int nt, const f32x16& acc, int) VDN_INL {
+        f32x16 o;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) o[t] = a.squeeze_out ? sigmoidf_(acc[t]) : fmaxf(acc[t], 0.0f);
+        if constexpr (NT_OUT == 1) {
+            if (ok && h == 0) {
+                for (int j = 0; j < a.d_out && j < 4; ++j) a.out[p * a.d_out + j] = o[j];
+            }
+        } else {
+            F32::store_tile(a.out, p, 96, nt, h, o, ok);      // network outputs feed the per-ray kernels: always f32
+        }
+    });
+}
+
+template <class P>
+int launch_rendernet_fwd(const VdnRenderNetArgs* args, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (args == nullptr || args->P <= 0 || !args->blob || !args->normals || !args->feat || !args->out || args->n_per_ray <= 0) return -1;
+    if (!args->pts && (!args->rays_o || !args->rays_d || !args->z)) return -1;
+    if (!args->dirs && !args->rays_d) return -1;
+    if (!(args->d_out == 96 || (args->d_out >= 1 && args->d_out <= 4))) return -2;
+    const int ppw = P::kWaves * 32;
+    const int grid = (args->P + ppw - 1) / ppw;
+    const size_t lds = 2 * P::chunk_bytes(10);
+    static bool once = (allow_big_lds(rendernet_fwd_kernel<P, 1>, lds), allow_big_lds(rendernet_fwd_kernel<P, 3>, lds), true);
+    (void)once;
+    if (args->d_out == 96)
+        hipLaunchKernelGGL((rendernet_fwd_kernel<P, 3>), dim3(grid), dim3(P::kWaves * 64), lds, stream, *args);
+    else
+        hipLaunchKernelGGL((rendernet_fwd_kernel<P, 1>), dim3(grid), dim3(P::kWaves * 64), lds, stream, *args);
+    return (int)hipGetLastError();
+}
+
+}  // namespace vdn

@@ -1,0 +1,237 @@
+// Backward of the SDF network including the double backward through d sdf/d x, on gfx950; shared
+// body for both precision policies.
+//
+// Forward quantities (k_sdf_fwd.h):  a_l = W_l x_l + b_l,  h_{l+1} = softplus(a_l),  s_l = softplus'(a_l),
+// sweep  v_l = u_{l+1} * s_l,  u_l = W_l^T v_l,  normal = scale * J_PE^T (u_0 + u_4[PE part]).
+// Adjoint, given (g_sdf, g_feat, g_normal):
+//   rbar (ascending l):  ub_0 = ub_4[PE] = scale * J_PE g_normal;   vb_l = W_l ub_l;
+//                        ub_{l+1} = vb_l * s_l;   ex_l = 100 * vb_l * v_l * (1 - s_l)      [softplus'' = 100 s (1-s)]
+//                        weight grads:  dW_l += v_l ub_l^T  (dw gemm), dW_8[sdf row] += colsum(ub_8) / scale
+//   fbar (descending l): ab_8 = [g_feat | g_sdf/scale];  hb_l = W_l^T ab_l;  ab_{l-1} = hb_l * s_{l-1} + ex_{l-1}
+//                        weight grads:  dW_l += ab_l x_l^T,  db_l = colsum(ab_l)
+// This is the hand-derived form of what autograd builds for reference fields.py:97-108 with
+// create_graph=True and then differentiates in dpt_runner.py:253.
+#pragma once
+#include "mlp_engine.h"
+#include "vdn_kernels.h"
+
+namespace vdn {
+
+template <class P>
+__global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_rbar_kernel(SdfRbarArgs a) {
+    using ST = typename P::store_t;
+    constexpr int kSlot = P::chunk_bytes(9);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    WStream<P::kWaves, kSlot> ws;
+    ws.init(a.blob, smem);
+    const int lane = ws.lane, c = lane & 31, h = lane >> 5;
+    const long p_raw = ((long)blockIdx.x * P::kWaves + ws.wave) * 32 + c;
+    const bool ok = p_raw < a.P;
+    const long p = ok ? p_raw : (long)a.P - 1;
+    const long Pn = a.P, PS = Pn * 256;
+    const ST* S = reinterpret_cast<const ST*>(a.S);
+    const ST* V = reinterpret_cast<const ST*>(a.V);
+    ST* EX = reinterpret_cast<ST*>(a.EX);
+
+    float xin[3];
+    if (a.pts != nullptr) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) xin[d] = a.pts[p * 3 + d] * a.scale;
+    } else {
+        const long r = p / a.n_per_ray;
+        const float z = a.z[r * a.z_ld + (p - r * a.n_per_ray)];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) xin[d] = (a.rays_o[r * 3 + d] + a.rays_d[r * 3 + d] * z) * a.scale;
+    }
+    // ub_total = scale * J_PE g_n  (39 values): adjoint of n = scale * J^T u
+    float ub39[39];
+    {
+        float gn[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            gn[d] = a.g_normals[p * 3 + d] * a.scale;
+            ub39[d] = gn[d];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const float f = (float)(1 << k);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                float sn, co;
+                sincosf(xin[d] * f, &sn, &co);
+                ub39[3 + 6 * k + d] = f * co * gn[d];
+                ub39[3 + 6 * k + 3 + d] = -f * sn * gn[d];
+            }
+        }
+    }
+    ST* ub0 = reinterpret_cast<ST*>(a.UB);
+    ST* ub1 = ub0 + Pn * 64;
+    ST* ub2 = ub1 + PS;
+    ST* ub3 = ub2 + PS;
+    ST* ub4 = ub3 + PS;
+    ST* ub5 = ub4 + Pn * 288;
+    ST* ub6 = ub5 + PS;
+    ST* ub7 = ub6 + PS;
+    ST* ub8 = ub7 + PS;
+
+    typename P::template Act<9> X;
+    typename P::template Act<8> Y;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const f32x16 t16 = vals_tile<39>(ub39, h, kt);
+        X.set(kt, t16);
+        P::store_tile(ub0, p, 64, kt, h, t16, ok);
+    }
+    struct SV { f32x16 s, v; };
+    auto ldSV = [&](int l) VDN_INL {
+        return [=](int nt) VDN_INL {
+            SV r;
+            r.s = P::load_tile(S + l * PS, p, 256, nt, h);
+            r.v = P::load_tile(V + l * PS, p, 256, nt, h);
+            return r;
+        };
+    };
+    // epilogue of layer l: ub_{l+1} = vb * s_l -> D (registers) and dst (HBM); ex_l -> EX[l]
+    auto epi = [&](auto& D, ST* dst, int ld, int l) VDN_INL {
+        return [&D, dst, ld, l, EX, PS, p, ok, h](int nt, const f32x16& acc, const SV& sv) VDN_INL {
+            f32x16 ub, ex;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                ub[t] = acc[t] * sv.s[t];
+                ex[t] = 100.0f * acc[t] * sv.v[t] * (1.0f - sv.s[t]);
+            }
+            D.set(nt, ub);
+            P::store_tile(dst, p, ld, nt, h, ub, ok);
+            P::store_tile(EX + l * PS, p, 256, nt, h, ex, ok);
+        };
+    };
+    constexpr int C2 = P::chunk_bytes(2), C8 = P::chunk_bytes(8), C9 = P::chunk_bytes(9);
+    ws.template start<C2>();
+    dense<P, 2, 8, C8, false>(ws, X, 0, ldSV(0), epi(Y, ub1, 256, 0));
+    dense<P, 8, 8, C8, false>(ws, Y, 0, ldSV(1), epi(X, ub2, 256, 1));
+    dense<P, 8, 8, C8, false>(ws, X, 0, ldSV(2), epi(Y, ub3, 256, 2));
+    dense<P, 8, 7, C9, false>(ws, Y, 0, ldSV(3), epi(X, ub4, 288, 3));      // ub_4[h part]: 7 tiles
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {                                        // ub_4[PE part] = ub_total
+        const f32x16 t16 = vals_tile<39>(ub39, h, kt);
+        X.set(7 + kt, t16);
+        P::store_tile(ub4, p, 288, 7 + kt, h, t16, ok);
+    }
+    dense<P, 9, 8, C8, false>(ws, X, 0, ldSV(4), epi(Y, ub5, 256, 4));
+    dense<P, 8, 8, C8, false>(ws, Y, 0, ldSV(5), epi(X, ub6, 256, 5));
+    dense<P, 8, 8, C8, false>(ws, X, 0, ldSV(6), epi(Y, ub7, 256, 6));
+    dense<P, 8, 8, 0, false>(ws, Y, 0, ldSV(7), epi(X, ub8, 256, 7));
+}
+
+template <class P>
+__global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_fbar_kernel(SdfFbarArgs a) {
+    using ST = typename P::store_t;
+    constexpr int kSlot = P::chunk_bytes(9);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    WStream<P::kWaves, kSlot> ws;
+    ws.init(a.blob, smem);
+    const int lane = ws.lane, c = lane & 31, h = lane >> 5;
+    const long p_raw = ((long)blockIdx.x * P::kWaves + ws.wave) * 32 + c;
+    const bool ok = p_raw < a.P;
+    const long p = ok ? p_raw : (long)a.P - 1;
+    const long Pn = a.P, PS = Pn * 256;
+    const ST* S = reinterpret_cast<const ST*>(a.S);
+    const ST* EX = reinterpret_cast<const ST*>(a.EX);
+    const ST* g_feat = reinterpret_cast<const ST*>(a.g_feat);
+    ST* ab8 = reinterpret_cast<ST*>(a.AB);
+    auto ab = [&](int l) VDN_INL { return ab8 + Pn * 288 + (long)(7 - l) * PS; };   // l = 7..0
+
+    typename P::template Act<9> X;
+    typename P::template Act<8> Y;
+#pragma unroll
+    for (int kt = 0; kt < 9; ++kt) {
+        f32x16 t16;
+        if (kt < 8) {
+            t16 = P::load_tile(g_feat, p, 256, kt, h);
+        } else {
+            float g1[1] = {a.g_sdf[p] / a.scale};
+            t16 = vals_tile<1>(g1, h, 0);
+        }
+        X.set(kt, t16);
+        P::store_tile(ab8, p, 288, kt, h, t16, ok);
+    }
+    struct SE { f32x16 s, e; };
+    auto ldSE = [&](int l) VDN_INL {
+        return [=](int nt) VDN_INL {
+            SE r;
+            r.s = P::load_tile(S + l * PS, p, 256, nt, h);
+            r.e = P::load_tile(EX + l * PS, p, 256, nt, h);
+            return r;
+        };
+    };
+    auto epi = [&](auto& D, int l) VDN_INL {       // ab_l = hb_{l+1} * s_l + ex_l
+        ST* dst = ab(l);
+        return [&D, dst, p, ok, h](int nt, const f32x16& acc, const SE& se) VDN_INL {
+            f32x16 o;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) o[t] = acc[t] * se.s[t] + se.e[t];
+            D.set(nt, o);
+            P::store_tile(dst, p, 256, nt, h, o, ok);
+        };
+    };
+    constexpr int C7 = P::chunk_bytes(7), C8 = P::chunk_bytes(8), C9 = P::chunk_bytes(9);
+    ws.template start<C9>();
+    dense<P, 9, 8, C8, false>(ws, X, 0, ldSE(7), epi(Y, 7));     // W8^T
+    dense<P, 8, 8, C8, false>(ws, Y, 0, ldSE(6), epi(X, 6));     // W7^T
+    dense<P, 8, 8, C8, false>(ws, X, 0, ldSE(5), epi(Y, 5));     // W6^T
+    dense<P, 8, 8, C8, false>(ws, Y, 0, ldSE(4), epi(X, 4));     // W5^T
+    {   // W4^T: 9 output tiles = [h4 part (7) | PE part (2, no gradient wanted)]
+        ST* dst = ab(3);
+        dense<P, 8, 9, C7, false>(ws, X, 0,
+            [&](int nt) VDN_INL {
+                SE r;
+                if (nt < 7) {
+                    r.s = P::load_tile(S + 3 * PS, p, 256, nt, h);
+                    r.e = P::load_tile(EX + 3 * PS, p, 256, nt, h);
+                } else {
+                    r.s = f32x16{};
+                    r.e = f32x16{};
+                }
+                return r;
+            },
+            [&](int nt, const f32x16& acc, const SE& se) VDN_INL {
+                if (nt < 7) {
+                    f32x16 o;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) o[t] = acc[t] * se.s[t] + se.e[t];
+                    Y.set(nt, o);
+                    P::store_tile(dst, p, 256, nt, h, o, ok);
+                }
+            });
+    }
+    dense<P, 7, 8, C8, false>(ws, Y, 0, ldSE(2), epi(X, 2));     // W3^T
+    dense<P, 8, 8, C8, false>(ws, X, 0, ldSE(1), epi(Y, 1));     // W2^T
+    dense<P, 8, 8, 0, false>(ws, Y, 0, ldSE(0), epi(X, 0));      // W1^T
+}
+
+template <class P>
+int launch_sdf_rbar(const VdnSdfRbarArgs* args, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!args || args->P <= 0 || !args->blob || !args->g_normals || !args->S || !args->V || !args->UB || !args->EX) return -1;
+    if (!args->pts && (!args->rays_o || !args->rays_d || !args->z || args->n_per_ray <= 0 || args->z_ld < args->n_per_ray)) return -2;
+    const int ppw = P::kWaves * 32;
+    const size_t lds = 2 * P::chunk_bytes(9);
+    static bool once = (allow_big_lds(sdf_rbar_kernel<P>, lds), true);
+    (void)once;
+    hipLaunchKernelGGL((sdf_rbar_kernel<P>), dim3((args->P + ppw - 1) / ppw), dim3(P::kWaves * 64), lds, stream, *args);
+    return (int)hipGetLastError();
+}
+
+template <class P>
+int launch_sdf_fbar(const VdnSdfFbarArgs* args, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!args || args->P <= 0 || !args->blob || !args->g_sdf || !args->g_feat || !args->S || !args->EX || !args->AB) return -1;
+    const int ppw = P::kWaves * 32;
+    const size_t lds = 2 * P::chunk_bytes(9);
+    static bool once = (allow_big_lds(sdf_fbar_kernel<P>, lds), true);
+    (void)once;
+    hipLaunchKernelGGL((sdf_fbar_kernel<P>), dim3((args->P + ppw - 1) / ppw), dim3(P::kWaves * 64), lds, stream, *args);
+    return (int)hipGetLastError();
+}
+
+}  // namespace vdn

@@ -1,0 +1,206 @@
+// SDF network forward on gfx950 (shared body for the F32 and BF16 policies of mlp_engine.h).
+// Fuses: point generation (o + d*z) -> positional encoding -> 9 weight-normed layers with
+// Softplus(beta=100) and the skip at layer 4 -> [sdf | 256-d feature], and (FULL mode) the analytic
+// reverse sweep that yields d sdf / d x, all with activations resident in registers.
+// Replaces reference dpt_models/fields.py:72-108 (SDFNetwork.forward / .sdf / .gradient).
+#pragma once
+#include "mlp_engine.h"
+#include "vdn_kernels.h"
+
+namespace vdn {
+
+template <class P, int MODE>   // MODE 0: sdf only; 1: sdf + feature + normals (+ training saves)
+__global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(SdfArgs a) {
+    using ST = typename P::store_t;
+    constexpr int kSlot = P::chunk_bytes(9);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    WStream<P::kWaves, kSlot> ws;
+    ws.init(a.blob, smem);
+    const int lane = ws.lane, c = lane & 31, h = lane >> 5;
+    const long p_raw = ((long)blockIdx.x * P::kWaves + ws.wave) * 32 + c;
+    const bool ok = p_raw < a.P;
+    const long p = ok ? p_raw : (long)a.P - 1;
+
+    float xin[3];
+    long sdf_idx = p;
+    if (a.pts != nullptr) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) xin[d] = a.pts[p * 3 + d] * a.scale;
+    } else {
+        const long r = p / a.n_per_ray;
+        const long sidx = p - r * a.n_per_ray;
+        const float z = a.z[r * a.z_ld + sidx];
+        sdf_idx = r * a.sdf_ld + sidx;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) xin[d] = (a.rays_o[r * 3 + d] + a.rays_d[r * 3 + d] * z) * a.scale;
+    }
+    constexpr bool SV = (MODE == 1);
+    ST* S = reinterpret_cast<ST*>(a.S);
+    ST* Hs = reinterpret_cast<ST*>(a.H);
+    ST* Vs = reinterpret_cast<ST*>(a.V);
+    const long PS = (long)a.P * 256;
+
+    typename P::template Act<9> X, Y;
+    auto put_pe = [&](int tile0) VDN_INL {
+        float pe[39];
+        posenc<3, 6>(xin, pe);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const f32x16 t16 = vals_tile<39>(pe, h, kt);
+            X.set(tile0 + kt, t16);
+            if constexpr (SV) {
+                if (tile0 == 0 && a.PE != nullptr) P::store_tile(reinterpret_cast<ST*>(a.PE), p, 64, kt, h, t16, ok);
+            }
+        }
+    };
+    // hidden layer epilogue: D <- softplus100(acc); S <- softplus'(acc) (and H <- the activation) row-major
+    auto hidden = [&](auto& D, int l) VDN_INL {
+        return [&D, l, S, Hs, PS, p, ok, h](int nt, const f32x16& acc, int) VDN_INL {
+            f32x16 hv, sv;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                if constexpr (SV) {
+                    float a_, b_;
+                    softplus100_both(acc[t], a_, b_);
+                    hv[t] = a_;
+                    sv[t] = b_;
+                } else {
+                    hv[t] = softplus100_fast(acc[t]);
+                }
+            }
+            D.set(nt, hv);
+            if constexpr (SV) {
+                P::store_tile(S + l * PS, p, 256, nt, h, sv, ok);
+                if (Hs != nullptr) P::store_tile(Hs + l * PS, p, 256, nt, h, hv, ok);
+            }
+        };
+    };
+    constexpr int C2 = P::chunk_bytes(2), C7 = P::chunk_bytes(7), C8 = P::chunk_bytes(8), C9 = P::chunk_bytes(9);
+    put_pe(0);
+    ws.template start<C2>();
+    dense<P, 2, 8, C8, true>(ws, X, 0, NoPre{}, hidden(Y, 0));
+    dense<P, 8, 8, C8, true>(ws, Y, 0, NoPre{}, hidden(X, 1));
+    dense<P, 8, 8, C8, true>(ws, X, 0, NoPre{}, hidden(Y, 2));
+    dense<P, 8, 7, C9, true>(ws, Y, 0, NoPre{}, hidden(X, 3));
+    put_pe(7);   // skip: layer-4 input = [h4 (217 -> 7 tiles) | PE (39 -> 2 tiles)] / sqrt2 (1/sqrt2 is in the image)
+    dense<P, 9, 8, C8, true>(ws, X, 0, NoPre{}, hidden(Y, 4));
+    dense<P, 8, 8, C8, true>(ws, Y, 0, NoPre{}, hidden(X, 5));
+    dense<P, 8, 8, C8, true>(ws, X, 0, NoPre{}, hidden(Y, 6));
+    dense<P, 8, 8, C8, true>(ws, Y, 0, NoPre{}, hidden(X, 7));
+
+    const float inv_scale = 1.0f / a.scale;
+    if constexpr (MODE == 0) {
+        // last layer reduced to its sdf row (image row 0 = W8 row 0)
+        dense<P, 8, 1, 0, true>(ws, X, 0, NoPre{}, [&](int, const f32x16& acc, int) VDN_INL {
+            if (ok && h == 0) a.sdf[sdf_idx] = acc[0] * inv_scale;
+        });
+    } else {
+        // image rows: 0..255 = feature rows (W8 rows 1..256), 256 = sdf row (W8 row 0)
+        ST* feat = reinterpret_cast<ST*>(a.feat);
+        dense<P, 8, 9, C8, true>(ws, X, 0, NoPre{}, [&](int nt, const f32x16& acc, int) VDN_INL {
+            if (nt < 8) {
+                P::store_tile(feat, p, 256, nt, h, acc, ok);
+            } else {
+                if (ok && h == 0) a.sdf[sdf_idx] = acc[0] * inv_scale;
+            }
+        });
+        // ---- reverse sweep: u = d sdf / d(layer input), v = u (.) softplus'(a_l) ------------------
+        // Every sweep layer's epilogue multiplies its output tile by the S tile of the layer below
+        // (loaded right after the chunk acquire), so X/Y always hold v, ready to be the B operand.
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) {
+            const f32x16 w8 = F32::load_tile(a.w8row, 0, 0, kt, h);
+            const f32x16 s7 = P::load_tile(S + 7 * PS, p, 256, kt, h);
+            f32x16 v7;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) v7[t] = w8[t] * inv_scale * s7[t];
+            Y.set(kt, v7);
+            if (Vs != nullptr) P::store_tile(Vs + 7 * PS, p, 256, kt, h, v7, ok);
+        }
+        auto loadS = [&](int layer) VDN_INL {
+            return [=](int nt) VDN_INL { return P::load_tile(S + layer * PS, p, 256, nt, h); };
+        };
+        auto mulInto = [&](auto& D, int layer) VDN_INL {     // D <- v_layer = u (.) s_layer; optionally kept for the backward
+            return [&D, layer, Vs, PS, p, ok, h](int nt, const f32x16& acc, const f32x16& sv) VDN_INL {
+                f32x16 v;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) v[t] = acc[t] * sv[t];
+                D.set(nt, v);
+                if (Vs != nullptr) P::store_tile(Vs + layer * PS, p, 256, nt, h, v, ok);
+            };
+        };
+        // d/dx through the positional encoding (transpose Jacobian), accumulated into n[]
+        float n[3] = {0.0f, 0.0f, 0.0f};
+        auto pe_backward = [&](const f32x16 (&U2)[2]) VDN_INL {
+            float u[39];
+            tiles_vals<39, 2>(U2, h, u);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) n[d] += u[d];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const float f = (float)(1 << k);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    float sn, co;
+                    sincosf(xin[d] * f, &sn, &co);
+                    n[d] += f * (co * u[3 + 6 * k + d] - sn * u[3 + 6 * k + 3 + d]);
+                }
+            }
+        };
+        dense<P, 8, 8, C8, false>(ws, Y, 0, loadS(6), mulInto(X, 6));   // through W7^T
+        dense<P, 8, 8, C8, false>(ws, X, 0, loadS(5), mulInto(Y, 5));   // W6^T
+        dense<P, 8, 8, C8, false>(ws, Y, 0, loadS(4), mulInto(X, 4));   // W5^T
+        {   // W4^T: 9 output tiles = [h4 part (7 tiles) | PE part (2 tiles)]
+            f32x16 UPE[2];
+            dense<P, 8, 9, C7, false>(ws, X, 0,
+                [&](int nt) VDN_INL { return nt < 7 ? P::load_tile(S + 3 * PS, p, 256, nt, h) : f32x16{}; },
+                [&](int nt, const f32x16& acc, const f32x16& sv) VDN_INL {
+                    if (nt < 7) {
+                        f32x16 v;
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) v[t] = acc[t] * sv[t];
+                        Y.set(nt, v);
+                        if (Vs != nullptr) P::store_tile(Vs + 3 * PS, p, 256, nt, h, v, ok);
+                    } else {
+                        UPE[nt - 7] = acc;
+                    }
+                });
+            pe_backward(UPE);
+        }
+        dense<P, 7, 8, C8, false>(ws, Y, 0, loadS(2), mulInto(X, 2));   // W3^T
+        dense<P, 8, 8, C8, false>(ws, X, 0, loadS(1), mulInto(Y, 1));   // W2^T
+        dense<P, 8, 8, C8, false>(ws, Y, 0, loadS(0), mulInto(X, 0));   // W1^T
+        f32x16 U0[2];
+        dense<P, 8, 2, 0, false>(ws, X, 0, NoPre{}, [&](int nt, const f32x16& acc, int) VDN_INL { U0[nt] = acc; });   // W0^T
+        pe_backward(U0);
+        if (ok && h == 0) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) a.normals[p * 3 + d] = n[d] * a.scale;
+        }
+    }
+}
+
+template <class P>
+int launch_sdf_fwd(int mode, const VdnSdfArgs* args, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (args == nullptr || args->P <= 0 || args->blob == nullptr) return -1;
+    if (args->pts == nullptr && (args->rays_o == nullptr || args->rays_d == nullptr || args->z == nullptr || args->n_per_ray <= 0 ||
+                                 args->z_ld < args->n_per_ray || args->sdf_ld < args->n_per_ray)) return -2;
+    const int ppw = P::kWaves * 32;
+    const int grid = (args->P + ppw - 1) / ppw;
+    const size_t lds = 2 * P::chunk_bytes(9);
+    static bool once = (allow_big_lds(sdf_fwd_kernel<P, 0>, lds), allow_big_lds(sdf_fwd_kernel<P, 1>, lds), true);
+    (void)once;
+    if (mode == 0) {
+        if (args->sdf == nullptr) return -3;
+        hipLaunchKernelGGL((sdf_fwd_kernel<P, 0>), dim3(grid), dim3(P::kWaves * 64), lds, stream, *args);
+    } else if (mode == 1) {
+        if (!args->sdf || !args->feat || !args->normals || !args->S || !args->w8row) return -3;
+        hipLaunchKernelGGL((sdf_fwd_kernel<P, 1>), dim3(grid), dim3(P::kWaves * 64), lds, stream, *args);
+    } else {
+        return -4;
+    }
+    return (int)hipGetLastError();
+}
+
+}  // namespace vdn

@@ -1,0 +1,280 @@
+// MLP engine for gfx950: weights streamed through LDS as the MFMA A operand, activations chained
+// in registers as the B operand (see vdn_common.h for the activation-tile layout). Two precision
+// policies share every kernel body:
+//
+//   F32  : v_mfma_f32_32x32x2_f32, exact fp32 (parity path).       4 waves / workgroup, 1 wave / SIMD.
+//          chunk = [KT*4 groups][64 lanes][4 f32] + 32 f32 bias (+pad) = KT*4096 + 1024 bytes
+//          lane (i,h) of group g holds W[nt*32+i][8g+4h .. +3]; HBM activations stored as f32.
+//   BF16 : v_mfma_f32_32x32x16_bf16, bf16 operands / fp32 accumulate (throughput path).
+//          8 waves / workgroup, 2 waves / SIMD.
+//          chunk = [KT*2 k-steps][64 lanes][8 bf16] + 32 f32 bias (+pad) = KT*2048 + 1024 bytes
+//          lane (i,h) element j of k-step s holds W[nt*32+i][16s + 8(j>>2) + 4h + (j&3)], which is the
+//          k order in which a 32x32 accumulator tile converts to B fragments with no lane movement;
+//          HBM activations stored as bf16.
+//
+// Chunks of one kernel lie in global memory in the exact order the kernel consumes them, so weight
+// streaming is one linear walk: each chunk is fetched with global_load_lds (1 KiB per
+// wave-instruction) into one of two LDS slots while the previous chunk is being multiplied.
+#pragma once
+#include "vdn_common.h"
+
+namespace vdn {
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+VDN_DEV unsigned pack_bf16x2(float a, float b) {
+    bf16x2_t v = {(__bf16)a, (__bf16)b};      // v_cvt_pk_bf16_f32 (round to nearest even)
+    return __builtin_bit_cast(unsigned, v);
+}
+VDN_DEV float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+VDN_DEV float bf16_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
+
+template <int NWAVES, int SLOT_BYTES>
+struct WStream {
+    const char* g;   // global cursor: first byte of the next chunk to fetch
+    char* lds;       // base of the two slots
+    int slot;        // slot holding the current chunk
+    int wave, lane;
+
+    VDN_DEV void init(const char* blob, char* smem) {
+        g = blob;
+        lds = smem;
+        slot = 1;
+        wave = threadIdx.x >> 6;
+        lane = threadIdx.x & 63;
+    }
+    template <int BYTES>
+    VDN_DEV void issue(int s) {
+        static_assert(BYTES % 1024 == 0 && BYTES <= SLOT_BYTES, "chunk size");
+        constexpr int pieces = BYTES / 1024;
+#pragma unroll
+        for (int i = 0; i < (pieces + NWAVES - 1) / NWAVES; ++i) {
+            const int piece = wave + i * NWAVES;
+            if (piece < pieces) glds16(g + piece * 1024 + lane * 16, lds + s * SLOT_BYTES + piece * 1024);
+        }
+        g += BYTES;
+    }
+    template <int FIRST_BYTES>
+    VDN_DEV void start() { issue<FIRST_BYTES>(0); }
+    // Make the chunk issued last current (all waves), then start fetching the next one.
+    template <int NEXT_BYTES>
+    VDN_DEV const char* acquire() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        slot ^= 1;
+        if constexpr (NEXT_BYTES > 0) issue<NEXT_BYTES>(slot ^ 1);
+        return lds + slot * SLOT_BYTES;
+    }
+};
+
+struct NoPre {
+    VDN_DEV int operator()(int) const { return 0; }
+};
+
+// ---------------------------------------------------------------------------------------------
+struct F32 {
+    static constexpr int kWaves = 4;
+    static constexpr int kMinWavesPerEU = 1;
+    static constexpr int chunk_bytes(int KT) { return KT * 4096 + 1024; }
+    using store_t = float;
+
+    template <int NT>
+    struct Act {
+        float r[NT * 16];
+        VDN_DEV void set(int tile, const f32x16& v) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                float x = v[t];
+                // materialise here: otherwise LLVM sinks a register-only epilogue down to its use in the
+                // next layer and keeps every tile's accumulator alive (volatile asm is not reordered
+                // across the volatile wait in WStream::acquire)
+                asm volatile("" : "+v"(x));
+                r[tile * 16 + t] = x;
+            }
+        }
+        template <class A2>
+        VDN_DEV void copy_tile(int dt, const A2& src, int st) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) r[dt * 16 + t] = src.r[st * 16 + t];
+        }
+    };
+
+    // acc = (bias) + W[chunk] . X over KT input tiles starting at X tile `x0`
+    template <int KT, bool BIAS, class ActT>
+    static VDN_DEV f32x16 mma(const char* w, const ActT& X, int x0, int lane) {
+        const int h = lane >> 5;
+        const f32x4* wa = reinterpret_cast<const f32x4*>(w) + lane;
+        f32x16 acc;
+        if constexpr (BIAS) {
+            const f32x4* bias = reinterpret_cast<const f32x4*>(w + KT * 4096);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b = bias[2 * q + h];   // features 8q+4h .. +3
+                acc[4 * q + 0] = b[0]; acc[4 * q + 1] = b[1]; acc[4 * q + 2] = b[2]; acc[4 * q + 3] = b[3];
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[t] = 0.0f;
+        }
+        static_for<KT * 4>([&](auto g_c) VDN_INL {
+            constexpr int g = decltype(g_c)::value;
+            const f32x4 a = wa[g * 64];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], X.r[x0 * 16 + 4 * g + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], X.r[x0 * 16 + 4 * g + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], X.r[x0 * 16 + 4 * g + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], X.r[x0 * 16 + 4 * g + 3], acc, 0, 0, 0);
+        });
+        return acc;
+    }
+
+    // row-major [P, ld] <-> activation tile: lane (c,h) owns 16-byte pieces at column 32*tile + 8q + 4h
+    static VDN_DEV void store_tile(float* base, long row, int ld, int tile, int h, const f32x16& v, bool ok) {
+        if (!ok) return;
+        float* p = base + row * ld + tile * 32 + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+            *reinterpret_cast<f32x4*>(p + 8 * q) = o;
+        }
+    }
+    static VDN_DEV f32x16 load_tile(const float* base, long row, int ld, int tile, int h) {
+        const float* p = base + row * ld + tile * 32 + 4 * h;
+        f32x16 r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(p + 8 * q);
+            r[4 * q] = o[0]; r[4 * q + 1] = o[1]; r[4 * q + 2] = o[2]; r[4 * q + 3] = o[3];
+        }
+        return r;
+    }
+};
+
+struct BF16 {
+    static constexpr int kWaves = 8;
+    static constexpr int kMinWavesPerEU = 2;
+    static constexpr int chunk_bytes(int KT) { return KT * 2048 + 1024; }
+    using store_t = unsigned short;   // bf16 bits
+
+    template <int NT>
+    struct Act {
+        bf16x8 r[NT * 2];
+        VDN_DEV void set(int tile, const f32x16& v) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                u32x4 pk;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    unsigned x = pack_bf16x2(v[8 * s + 2 * j], v[8 * s + 2 * j + 1]);
+                    asm volatile("" : "+v"(x));      // materialise here (see F32::Act::set)
+                    pk[j] = x;
+                }
+                r[tile * 2 + s] = __builtin_bit_cast(bf16x8, pk);
+            }
+        }
+        template <class A2>
+        VDN_DEV void copy_tile(int dt, const A2& src, int st) {
+            r[dt * 2] = src.r[st * 2];
+            r[dt * 2 + 1] = src.r[st * 2 + 1];
+        }
+    };
+
+    template <int KT, bool BIAS, class ActT>
+    static VDN_DEV f32x16 mma(const char* w, const ActT& X, int x0, int lane) {
+        const int h = lane >> 5;
+        const bf16x8* wa = reinterpret_cast<const bf16x8*>(w) + lane;
+        f32x16 acc;
+        if constexpr (BIAS) {
+            const f32x4* bias = reinterpret_cast<const f32x4*>(w + KT * 2048);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b = bias[2 * q + h];
+                acc[4 * q + 0] = b[0]; acc[4 * q + 1] = b[1]; acc[4 * q + 2] = b[2]; acc[4 * q + 3] = b[3];
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[t] = 0.0f;
+        }
+        static_for<KT * 2>([&](auto s_c) VDN_INL {
+            constexpr int s = decltype(s_c)::value;
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[s * 64], X.r[x0 * 2 + s], acc, 0, 0, 0);
+        });
+        return acc;
+    }
+
+    // row-major bf16 [P, ld]: lane (c,h) owns 8-byte pieces (4 bf16) at column 32*tile + 8q + 4h
+    static VDN_DEV void store_tile(unsigned short* base, long row, int ld, int tile, int h, const f32x16& v, bool ok) {
+        if (!ok) return;
+        unsigned short* p = base + row * ld + tile * 32 + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint2 o;
+            o.x = pack_bf16x2(v[4 * q], v[4 * q + 1]);
+            o.y = pack_bf16x2(v[4 * q + 2], v[4 * q + 3]);
+            *reinterpret_cast<uint2*>(p + 8 * q) = o;
+        }
+    }
+    static VDN_DEV f32x16 load_tile(const unsigned short* base, long row, int ld, int tile, int h) {
+        const unsigned short* p = base + row * ld + tile * 32 + 4 * h;
+        f32x16 r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint2 o = *reinterpret_cast<const uint2*>(p + 8 * q);
+            r[4 * q] = bf16_lo(o.x); r[4 * q + 1] = bf16_hi(o.x); r[4 * q + 2] = bf16_lo(o.y); r[4 * q + 3] = bf16_hi(o.y);
+        }
+        return r;
+    }
+};
+
+// One dense layer on the wave's 32 points: for every output tile nt, acc = bias + W[nt] . X[x0 ..],
+// then epi(nt, acc, aux) with aux = pre(nt) evaluated right after the chunk is acquired (so its
+// loads overlap the MFMA loop). NEXT_BYTES = size of the chunk that follows this layer's last chunk
+// in the stream (0 at the end of the stream).
+template <class P, int KT, int NT, int NEXT_BYTES, bool BIAS, class WS, class ActT, class Pre, class Epi>
+VDN_DEV void dense(WS& ws, const ActT& X, int x0, Pre&& pre, Epi&& epi) {
+    const int lane = ws.lane;
+    static_for<NT>([&](auto nt_c) VDN_INL {
+        constexpr int nt = decltype(nt_c)::value;
+        const char* w = (nt + 1 < NT) ? ws.template acquire<P::chunk_bytes(KT)>()
+                                      : ws.template acquire<NEXT_BYTES>();
+        auto aux = pre(nt);
+        const f32x16 acc = P::template mma<KT, BIAS>(w, X, x0, lane);
+        epi(nt, acc, aux);
+        // keep each tile's epilogue inside its own chunk step: without this the scheduler sinks the
+        // register-only epilogues of several tiles past the barriers and runs out of registers
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+// per-point vector -> one activation tile (f32x16), zero beyond NF
+template <int NF>
+VDN_DEV f32x16 vals_tile(const float (&vals)[NF], int h, int tile) {
+    f32x16 o;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int f0 = 32 * tile + (t & 3) + 8 * (t >> 2);
+        const int f1 = f0 + 4;
+        const float a = f0 < NF ? vals[f0 < NF ? f0 : 0] : 0.0f;
+        const float b = f1 < NF ? vals[f1 < NF ? f1 : 0] : 0.0f;
+        o[t] = h ? b : a;
+    }
+    return o;
+}
+// NT tiles (f32x16 each) -> full per-point vector on every lane
+template <int NF, int NT>
+VDN_DEV void tiles_vals(const f32x16 (&T)[NT], int h, float (&vals)[NF]) {
+#pragma unroll
+    for (int tile = 0; tile < NT; ++tile) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int f0 = 32 * tile + (t & 3) + 8 * (t >> 2);
+            const int f1 = f0 + 4;
+            const float mine = T[tile][t];
+            const float other = __shfl_xor(mine, 32);
+            if (f0 < NF) vals[f0 < NF ? f0 : 0] = h ? other : mine;
+            if (f1 < NF) vals[f1 < NF ? f1 : 0] = h ? mine : other;
+        }
+    }
+}
+
+}  // namespace vdn

@@ -39,8 +39,8 @@ __global__ __launch_bounds__(256) void dw_gemm_f32_kernel(const DwDesc* descs, i
         const bool valid = pp < k_end;
         const bool seg2 = pp >= P;
         const long idx = seg2 ? pp - P : pp;
-        const float* A = seg2 ? d.A2 : d.A1;
-        const float* Bm = seg2 ? d.B2 : d.B1;
+        const float* A = reinterpret_cast<const float*>(seg2 ? d.A2 : d.A1);
+        const float* Bm = reinterpret_cast<const float*>(seg2 ? d.B2 : d.B1);
         const int lda = seg2 ? d.lda2 : d.lda1, ldb = seg2 ? d.ldb2 : d.ldb1;
         float a0 = 0.0f, a1 = 0.0f, b0 = 0.0f, b1 = 0.0f;
         if (valid) {

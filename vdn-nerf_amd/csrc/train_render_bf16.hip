@@ -1,0 +1,3 @@
+// bf16 instantiation of the RenderingNetwork backward kernel - see k_render_bwd.h
+#include "k_render_bwd.h"
+extern "C" int vdn_rendernet_bwd_bf16(const VdnRenderNetBwdArgs* args, void* stream) { return vdn::launch_rendernet_bwd<vdn::BF16>(args, stream); }

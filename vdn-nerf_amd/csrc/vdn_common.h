@@ -18,6 +18,9 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 #include <utility>
 
 #define VDN_DEV __device__ __forceinline__
+// lambdas inside kernels capture register arrays by reference: they must always be inlined, or the
+// arrays escape to scratch memory
+#define VDN_INL __attribute__((always_inline))
 
 namespace vdn {
 

@@ -51,7 +51,21 @@ class _PlainLinear(nn.Module):
 
 
 class _HipNet(nn.Module):
-    """Lazily built device state (effective weights + MFMA chunk streams) shared by the networks."""
+    """Lazily built device state (effective weights + MFMA chunk streams) shared by the networks.
+
+    `precision` (not a reference kwarg; set as an attribute or through vdn_train.factory):
+      "fp32" - exact-f32 MFMA kernels, the parity path (<= 1e-4 vs the reference);
+      "bf16" - bf16-operand / fp32-accumulate MFMA kernels, bf16 activation workspaces: the throughput path.
+    """
+    precision = "fp32"
+
+    def _sfx(self):
+        if self.precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16', got %r" % (self.precision,))
+        return "_f32" if self.precision == "fp32" else "_bf16"
+
+    def _store_dtype(self):
+        return torch.float32 if self.precision == "fp32" else torch.bfloat16
 
     def _images(self):
         dev = next(self.parameters()).device
@@ -59,8 +73,9 @@ class _HipNet(nn.Module):
             raise RuntimeError("%s lives on %s; move it to the MI355X with .to('cuda') (no CPU path)"
                                % (type(self).__name__, dev))
         st = self.__dict__.get("_img")
-        if st is None or st.device != dev:
-            st = images.NetImages(self._matrices(), self._streams(), dev)
+        fmt = images.FMT_F32 if self._sfx() == "_f32" else images.FMT_BF16
+        if st is None or st.device != dev or st.fmt != fmt:
+            st = images.NetImages(self._matrices(), self._streams(), dev, fmt)
             self.__dict__["_img"] = st
         st.refresh(_stream())
         return st
@@ -135,15 +150,15 @@ class SDFNetwork(_HipNet):
         a.sdf = sdf.data_ptr()
         if mode == 0:
             a.blob = img.blobs["sdf"].data_ptr()
-            lib.call("vdn_sdf_mlp_fwd_f32", 0, a, _stream())
+            lib.call("vdn_sdf_mlp_fwd" + self._sfx(), 0, a, _stream())
             return sdf
-        feat = torch.empty(P, 256, dtype=torch.float32, device=dev)
+        feat = torch.empty(P, 256, dtype=self._store_dtype(), device=dev)
         normals = torch.empty(P, 3, dtype=torch.float32, device=dev)
-        S = torch.empty(8, P, 256, dtype=torch.float32, device=dev)
+        S = torch.empty(8, P, 256, dtype=self._store_dtype(), device=dev)
         a.blob = img.blobs["full"].data_ptr()
         a.feat, a.normals, a.S = feat.data_ptr(), normals.data_ptr(), S.data_ptr()
         a.w8row = img.weff_view("lin8").data_ptr()
-        lib.call("vdn_sdf_mlp_fwd_f32", 1, a, _stream())
+        lib.call("vdn_sdf_mlp_fwd" + self._sfx(), 1, a, _stream())
         if workspace is not None:
             workspace["S"] = S
         return sdf, feat, normals
@@ -152,7 +167,7 @@ class SDFNetwork(_HipNet):
         if inputs.numel() == 0:
             return inputs.new_zeros(0, self.conf["d_out"])
         sdf, feat, _ = self._run(1, pts=inputs.detach())
-        return torch.cat([sdf[:, None], feat], dim=-1)
+        return torch.cat([sdf[:, None], feat.float()], dim=-1)
 
     def sdf(self, x):
         if x.numel() == 0:
@@ -208,7 +223,7 @@ class RenderingNetwork(_HipNet):
         d_out = self.conf["d_out"]
         out = torch.empty(P, d_out, dtype=torch.float32, device=dev)
         a.out, a.P, a.d_out, a.squeeze_out = out.data_ptr(), P, d_out, int(self.squeeze_out)
-        lib.call("vdn_rendernet_fwd_f32", a, _stream())
+        lib.call("vdn_rendernet_fwd" + self._sfx(), a, _stream())
         return out
 
     def forward(self, points, normals, view_dirs, feature_vectors):
@@ -216,7 +231,7 @@ class RenderingNetwork(_HipNet):
             _require_gpu(t, "RenderingNetwork " + n)
         if points.shape[0] == 0:
             return points.new_zeros(0, self.conf["d_out"])
-        return self._run(normals.detach().contiguous(), feature_vectors.detach().contiguous(),
+        return self._run(normals.detach().contiguous(), feature_vectors.detach().to(self._store_dtype()).contiguous(),
                          pts=points.detach().contiguous(), dirs=view_dirs.detach().contiguous())
 
 
@@ -276,7 +291,7 @@ class NeRF(_HipNet):
         rgb = torch.empty(P, 3, dtype=torch.float32, device=dev)
         feat = torch.empty(P, 96, dtype=torch.float32, device=dev) if self.gen_depth_feats else None
         a.density, a.rgb, a.feat, a.P = density.data_ptr(), rgb.data_ptr(), (feat.data_ptr() if feat is not None else None), P
-        lib.call("vdn_nerf_mlp_fwd_f32", a, _stream())
+        lib.call("vdn_nerf_mlp_fwd" + self._sfx(), a, _stream())
         return density, rgb, feat
 
     def forward(self, input_pts, input_views):

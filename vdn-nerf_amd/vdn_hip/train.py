@@ -58,37 +58,44 @@ class TrainEngine:
         self.P = B * self.N
         self.Q = B * self.T
         self.wdepth = renderer.depth_network is not None
+        precs = {m.precision for m in (renderer.nerf, renderer.sdf_network, renderer.color_network, renderer.depth_network) if m is not None}
+        if len(precs) != 1:
+            raise ValueError("all networks of a renderer must share one precision, got %s" % sorted(precs))
+        self.precision = precs.pop()
+        self.sfx = "_f32" if self.precision == "fp32" else "_bf16"
+        sdt = torch.float32 if self.precision == "fp32" else torch.bfloat16     # MLP-internal workspaces
         f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        fs = lambda *shape: torch.empty(*shape, dtype=sdt, device=dev)
         P, Q, N, T = self.P, self.Q, self.N, self.T
         w = self.w = {}
         # ---- forward saves
         w["dists"], w["mid_z"] = f(B, N), f(B, N)
-        w["sdf"], w["feat"], w["normals"] = f(P), f(P, 256), f(P, 3)
-        w["S"], w["H"], w["V"], w["PE"] = f(8, P, 256), f(8, P, 256), f(8, P, 256), f(P, 64)
-        w["col_out"], w["col_h"], w["col_small"] = f(P, 3), f(4, P, 256), f(P, 64)
+        w["sdf"], w["feat"], w["normals"] = f(P), fs(P, 256), f(P, 3)
+        w["S"], w["H"], w["V"], w["PE"] = fs(8, P, 256), fs(8, P, 256), fs(8, P, 256), fs(P, 64)
+        w["col_out"], w["col_h"], w["col_small"] = f(P, 3), fs(4, P, 256), fs(P, 64)
         if self.wdepth:
-            w["vdn_out"], w["vdn_h"], w["vdn_small"] = f(P, 96), f(4, P, 256), f(P, 64)
+            w["vdn_out"], w["vdn_h"], w["vdn_small"] = f(P, 96), fs(4, P, 256), fs(P, 64)
         if O > 0:
             w["z_feed"], w["bg_dists"], w["bg_mid"] = f(B, T), f(B, T), f(B, T)
             w["bg_density"], w["bg_rgb"] = f(Q), f(Q, 3)
             w["bg_feat"] = f(Q, 96) if self.wdepth else None
-            w["nf_h"], w["nf_pe"], w["nf_feature"], w["nf_vpe"], w["nf_hv"] = f(8, Q, 256), f(Q, 96), f(Q, 256), f(Q, 32), f(Q, 128)
+            w["nf_h"], w["nf_pe"], w["nf_feature"], w["nf_vpe"], w["nf_hv"] = fs(8, Q, 256), fs(Q, 96), fs(Q, 256), fs(Q, 32), fs(Q, 128)
         w["weights"], w["alpha"], w["cdf"], w["inside"] = f(B, T), f(B, T), f(B, N), f(B, N)
         w["color"], w["wsum"], w["wmax"], w["s_val"] = f(B, 3), f(B, 1), f(B, 1), f(B, 1)
         w["eik_partial"], w["eik"] = f(B, 2), f(3)
         w["feat_out"] = f(B, 96) if self.wdepth else None
         # ---- backward intermediates
-        w["d_sdf"], w["d_normals"], w["d_color"], w["d_featvec"] = f(P), f(P, 3), f(P, 3), f(P, 256)
+        w["d_sdf"], w["d_normals"], w["d_color"], w["d_featvec"] = f(P), f(P, 3), f(P, 3), fs(P, 256)
         w["d_vdn"] = f(P, 96) if self.wdepth else None
         w["d_var_partial"], w["d_variance"] = f(B), f(1)
-        w["col_dout"], w["col_dh"] = f(P, 32), f(4, P, 256)
+        w["col_dout"], w["col_dh"] = fs(P, 32), fs(4, P, 256)
         if self.wdepth:
-            w["vdn_dout"], w["vdn_dh"] = f(P, 96), f(4, P, 256)
-        w["UB"], w["EX"], w["AB"] = f(P * 2144), f(8, P, 256), f(P * 2336)
+            w["vdn_dout"], w["vdn_dh"] = fs(P, 96), fs(4, P, 256)
+        w["UB"], w["EX"], w["AB"] = fs(P * 2144), fs(8, P, 256), fs(P * 2336)
         if O > 0:
             w["d_bg_density"], w["d_bg_rgb"] = f(Q), f(Q, 3)
             w["d_bg_feat"] = f(Q, 96) if self.wdepth else None
-            w["nf_do"], w["nf_dv"], w["nf_dhead"], w["nf_dh"] = f(Q, 128 if self.wdepth else 32), f(Q, 128), f(Q, 288), f(8, Q, 256)
+            w["nf_do"], w["nf_dv"], w["nf_dhead"], w["nf_dh"] = fs(Q, 128 if self.wdepth else 32), fs(Q, 128), fs(Q, 288), fs(8, Q, 256)
         # one flat gradient buffer over all parameters, in dpt_runner.py:121-130 order (nerf, sdf, variance,
         # colour, vdn): the single message of the data-parallel all-reduce
         self.params = renderer._all_parameters()
@@ -181,6 +188,8 @@ class TrainEngine:
             nt = 0 if e["cmap"] is None else len(e["cmap"]) // 32
             K = e["Pn"] * (2 if e.get("A2") is not None else 1)
             splits = max(1, (K + PTS_PER_SPLIT - 1) // PTS_PER_SPLIT)
+            if e.get("A2") is not None:
+                splits += splits % 2          # bf16 GEMM: first half of the splits = segment 1, second half = segment 2
             lay.append((mt, nt, splits, slab_elems, cs_elems, moff, wg))
             all_maps.append(np.asarray(e["rmap"], np.int32))
             moff_r = moff
@@ -195,7 +204,7 @@ class TrainEngine:
         self.maps = torch.from_numpy(np.concatenate(all_maps)).to(dev)
         self.slab = torch.empty(max(slab_elems, 1), dtype=torch.float32, device=dev)
         self.colsum = torch.empty(max(cs_elems, 1), dtype=torch.float32, device=dev)
-        P4 = lambda spec: spec[0].data_ptr() + 4 * spec[1]
+        P4 = lambda spec: spec[0].data_ptr() + spec[0].element_size() * spec[1]
         for i, e in enumerate(ent):
             mt, nt, splits, so, co, mo, wg0 = lay[i]
             d = dw[i]
@@ -274,7 +283,7 @@ class TrainEngine:
             n.density, n.rgb = w["bg_density"].data_ptr(), w["bg_rgb"].data_ptr()
             n.feat = w["bg_feat"].data_ptr() if w["bg_feat"] is not None else None
             n.save_h, n.save_pe, n.save_feature, n.save_vpe, n.save_hv = (w[k].data_ptr() for k in ("nf_h", "nf_pe", "nf_feature", "nf_vpe", "nf_hv"))
-            lib.call("vdn_nerf_mlp_fwd_f32", n, st)
+            lib.call("vdn_nerf_mlp_fwd" + self.sfx, n, st)
         s = lib.VdnSdfArgs()
         img = self.nets["sdf"].img
         s.blob = img.blobs["full"].data_ptr()
@@ -283,7 +292,7 @@ class TrainEngine:
         s.sdf, s.feat, s.normals, s.S = w["sdf"].data_ptr(), w["feat"].data_ptr(), w["normals"].data_ptr(), w["S"].data_ptr()
         s.w8row = img.weff_view("lin8").data_ptr()
         s.H, s.V, s.PE = w["H"].data_ptr(), w["V"].data_ptr(), w["PE"].data_ptr()
-        lib.call("vdn_sdf_mlp_fwd_f32", 1, s, st)
+        lib.call("vdn_sdf_mlp_fwd" + self.sfx, 1, s, st)
 
         def rnet(net, out, save_h, small, d_out, module):
             c = lib.VdnRenderNetArgs()
@@ -292,7 +301,7 @@ class TrainEngine:
             c.normals, c.feat, c.out = w["normals"].data_ptr(), w["feat"].data_ptr(), out.data_ptr()
             c.save_h, c.save_small = save_h.data_ptr(), small.data_ptr()
             c.P, c.d_out, c.squeeze_out = self.P, d_out, int(module.squeeze_out)
-            lib.call("vdn_rendernet_fwd_f32", c, st)
+            lib.call("vdn_rendernet_fwd" + self.sfx, c, st)
         if self.wdepth:
             rnet("vdn", w["vdn_out"], w["vdn_h"], w["vdn_small"], 96, r.depth_network)
         rnet("color", w["col_out"], w["col_h"], w["col_small"], 3, r.color_network)
@@ -362,7 +371,7 @@ class TrainEngine:
             b.d_feat, b.d_normals = w["d_featvec"].data_ptr(), w["d_normals"].data_ptr()
             b.acc_feat, b.acc_normals = int(accumulate), 1
             b.P, b.d_out, b.squeeze_out = self.P, d_out, int(module.squeeze_out)
-            lib.call("vdn_rendernet_bwd_f32", b, st)
+            lib.call("vdn_rendernet_bwd" + self.sfx, b, st)
         # d_normals already holds the alpha + eikonal parts: the heads add their input gradients into it;
         # d_featvec is overwritten by the first head and accumulated by the second
         rnet_bwd("color", w["d_color"], w["col_out"], w["col_h"], w["col_dout"], w["col_dh"], 3, r.color_network, False)
@@ -376,12 +385,12 @@ class TrainEngine:
         rb.rays_o, rb.rays_d, rb.z, rb.n_per_ray, rb.z_ld = rays_o.data_ptr(), rays_d.data_ptr(), w["mid_z"].data_ptr(), self.N, self.N
         rb.P, rb.scale = self.P, float(r.sdf_network.scale)
         rb.g_normals, rb.S, rb.V, rb.UB, rb.EX = w["d_normals"].data_ptr(), w["S"].data_ptr(), w["V"].data_ptr(), w["UB"].data_ptr(), w["EX"].data_ptr()
-        lib.call("vdn_sdf_bwd_rbar_f32", rb, st)
+        lib.call("vdn_sdf_bwd_rbar" + self.sfx, rb, st)
         fb = lib.VdnSdfFbarArgs()
         fb.blob = img.blobs["fbar"].data_ptr()
         fb.g_sdf, fb.g_feat, fb.S, fb.EX, fb.AB = w["d_sdf"].data_ptr(), w["d_featvec"].data_ptr(), w["S"].data_ptr(), w["EX"].data_ptr(), w["AB"].data_ptr()
         fb.P, fb.scale = self.P, float(r.sdf_network.scale)
-        lib.call("vdn_sdf_bwd_fbar_f32", fb, st)
+        lib.call("vdn_sdf_bwd_fbar" + self.sfx, fb, st)
 
         if r.n_outside > 0:
             nb = lib.VdnNerfBwdArgs()
@@ -391,9 +400,9 @@ class TrainEngine:
             nb.save_h, nb.save_hv = w["nf_h"].data_ptr(), w["nf_hv"].data_ptr()
             nb.delta_o, nb.delta_v, nb.delta_head, nb.delta_h = (w[k].data_ptr() for k in ("nf_do", "nf_dv", "nf_dhead", "nf_dh"))
             nb.P = self.Q
-            lib.call("vdn_nerf_mlp_bwd_f32", nb, st)
+            lib.call("vdn_nerf_mlp_bwd" + self.sfx, nb, st)
 
-        lib.call("vdn_dw_gemm_f32", lib.ptr(self.dw_table), self.n_dw, self.dw_total_wgs, st)
+        lib.call("vdn_dw_gemm" + self.sfx, lib.ptr(self.dw_table), self.n_dw, self.dw_total_wgs, st)
         lib.call("vdn_dw_finalize", lib.ptr(self.fin_table), self.n_dw, self.fin_max_M, 0, st)
         lib.call("vdn_dw_finalize", lib.ptr(self.fin_table), self.n_dw, self.fin_max_M, 1, st)
         lib.call("vdn_weightnorm_bwd", lib.ptr(self.wn_table), self.n_wn, self.wn_max_rows, st)

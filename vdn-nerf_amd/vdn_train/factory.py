@@ -19,7 +19,7 @@ CONF = {
 }
 
 
-def build_renderer(wdepth=False, device="cuda", states=None, **renderer_overrides):
+def build_renderer(wdepth=False, device="cuda", states=None, precision="fp32", **renderer_overrides):
     """-> NeuSRenderer with its five networks on `device`. `states`: vdn_train.synth.make_all_states()-style
     dict of numpy arrays (checkpoint key names of dpt_runner.py:366-375)."""
     nerf_kw = dict(CONF["nerf"])
@@ -38,6 +38,9 @@ def build_renderer(wdepth=False, device="cuda", states=None, **renderer_override
         col.load_state_dict(tt(states["color_network_fine"]))
         if wdepth:
             vdn.load_state_dict(tt(states["depth_network_fine"]))
+    for m in (nerf, sdf, col, vdn):
+        if m is not None:
+            m.precision = precision          # "fp32" (parity) or "bf16" (throughput)
     mods = [m.to(device) for m in (nerf, sdf, var, col)] + ([vdn.to(device)] if wdepth else [None])
     kw = dict(CONF["neus_renderer"])
     kw.update(renderer_overrides)
