@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16",
+                    help="bf16 = BASELINE.json's headline config (bf16 MFMA, fp32 accumulate); fp32 = the parity path")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -103,7 +105,7 @@ def main():
     from vdn_train.trainer import Trainer
     seed, B = 0, args.batch
     st = synth.make_all_states(seed, wdepth=False)
-    rend = factory.build_renderer(wdepth=False, device=dev, states=st)
+    rend = factory.build_renderer(wdepth=False, device=dev, states=st, precision=args.precision)
     trainer = Trainer(rend, B, dev, world_size=world, rank=rank)
     cams = synth.make_cameras(seed)
     perm = np.argsort(synth.uniform(seed, "perm", (len(cams),)))
@@ -166,7 +168,7 @@ def main():
             _, mid = rend._sections(z, z.shape[1], 2.0 / rend.n_samples)
             tk = time_kernel(lambda: rend.sdf_network._run(1, rays=(o, d, mid)))
         flops = (F_SDF + F_GRAD) * mid.numel()
-        dtype = "f32"
+        dtype = "f32" if args.precision == "fp32" else "bf16"
         line = {
             "metric": "rays/sec (512-ray batch, 128 samples/ray)", "value": value, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -178,7 +180,7 @@ def main():
                        "flop_per_ray": FLOP_PER_RAY_TRAIN, "allreduce_bytes": trainer.param_flat.numel() * 4},
             "model_flops_per_s": value * FLOP_PER_RAY_TRAIN,
             "forward_only_rays_per_s": fwd_rays_per_s, "final_loss": loss_final,
-            "roofline": {"bound": "mfma", "kernel": "sdf_f32_kernel<1> (PE + SDF MLP + gradient sweep, 65536 points)",
+            "roofline": {"bound": "mfma", "kernel": "sdf_fwd_kernel<%s,1> (fused PE + SDF MLP + gradient sweep, 65536 points)" % ("F32" if dtype == "f32" else "BF16"),
                          "achieved": flops / tk / 1e12, "peak": PEAK[dtype] / 1e12, "unit": "TFLOP/s",
                          "frac": flops / tk / PEAK[dtype], "traffic": None, "kernel_ms": tk * 1e3},
         }

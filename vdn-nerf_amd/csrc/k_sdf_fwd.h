@@ -9,17 +9,20 @@
 
 namespace vdn {
 
-template <class P, int MODE>   // MODE 0: sdf only; 1: sdf + feature + normals (+ training saves)
-__global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(SdfArgs a) {
+// MODE 0: sdf only; 1: sdf + feature + normals (+ training saves). NW = waves per workgroup (32 points each):
+// small launches use fewer waves per workgroup so that the grid still covers the 256 CUs.
+template <class P, int MODE, int NW>
+__global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(SdfArgs a) {
     using ST = typename P::store_t;
     constexpr int kSlot = P::chunk_bytes(9);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    WStream<P::kWaves, kSlot> ws;
+    WStream<NW, kSlot> ws;
     ws.init(a.blob, smem);
     const int lane = ws.lane, c = lane & 31, h = lane >> 5;
-    const long p_raw = ((long)blockIdx.x * P::kWaves + ws.wave) * 32 + c;
+    const long p_raw = ((long)blockIdx.x * NW + ws.wave) * 32 + c;
     const bool ok = p_raw < a.P;
     const long p = ok ? p_raw : (long)a.P - 1;
+    ws.all_issue = __any(ok);
 
     float xin[3];
     long sdf_idx = p;
@@ -76,17 +79,19 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_fwd_ker
         };
     };
     constexpr int C2 = P::chunk_bytes(2), C7 = P::chunk_bytes(7), C8 = P::chunk_bytes(8), C9 = P::chunk_bytes(9);
+    const int est_h = SV ? (Hs != nullptr ? 8 : 4) : 0;     // stores per hidden-layer tile (S, and H when training)
+    const int est_v = Vs != nullptr ? 4 : 0;                // stores per sweep tile (V when training)
     put_pe(0);
     ws.template start<C2>();
-    dense<P, 2, 8, C8, true>(ws, X, 0, NoPre{}, hidden(Y, 0));
-    dense<P, 8, 8, C8, true>(ws, Y, 0, NoPre{}, hidden(X, 1));
-    dense<P, 8, 8, C8, true>(ws, X, 0, NoPre{}, hidden(Y, 2));
-    dense<P, 8, 7, C9, true>(ws, Y, 0, NoPre{}, hidden(X, 3));
+    dense<P, 2, 8, C8, true>(ws, X, 0, NoPre{}, hidden(Y, 0), est_h);
+    dense<P, 8, 8, C8, true>(ws, Y, 0, NoPre{}, hidden(X, 1), est_h);
+    dense<P, 8, 8, C8, true>(ws, X, 0, NoPre{}, hidden(Y, 2), est_h);
+    dense<P, 8, 7, C9, true>(ws, Y, 0, NoPre{}, hidden(X, 3), est_h);
     put_pe(7);   // skip: layer-4 input = [h4 (217 -> 7 tiles) | PE (39 -> 2 tiles)] / sqrt2 (1/sqrt2 is in the image)
-    dense<P, 9, 8, C8, true>(ws, X, 0, NoPre{}, hidden(Y, 4));
-    dense<P, 8, 8, C8, true>(ws, Y, 0, NoPre{}, hidden(X, 5));
-    dense<P, 8, 8, C8, true>(ws, X, 0, NoPre{}, hidden(Y, 6));
-    dense<P, 8, 8, C8, true>(ws, Y, 0, NoPre{}, hidden(X, 7));
+    dense<P, 9, 8, C8, true>(ws, X, 0, NoPre{}, hidden(Y, 4), est_h);
+    dense<P, 8, 8, C8, true>(ws, Y, 0, NoPre{}, hidden(X, 5), est_h);
+    dense<P, 8, 8, C8, true>(ws, X, 0, NoPre{}, hidden(Y, 6), est_h);
+    dense<P, 8, 8, C8, true>(ws, Y, 0, NoPre{}, hidden(X, 7), est_h);
 
     const float inv_scale = 1.0f / a.scale;
     if constexpr (MODE == 0) {
@@ -147,9 +152,9 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_fwd_ker
                 }
             }
         };
-        dense<P, 8, 8, C8, false>(ws, Y, 0, loadS(6), mulInto(X, 6));   // through W7^T
-        dense<P, 8, 8, C8, false>(ws, X, 0, loadS(5), mulInto(Y, 5));   // W6^T
-        dense<P, 8, 8, C8, false>(ws, Y, 0, loadS(4), mulInto(X, 4));   // W5^T
+        dense<P, 8, 8, C8, false>(ws, Y, 0, loadS(6), mulInto(X, 6), est_v);   // through W7^T
+        dense<P, 8, 8, C8, false>(ws, X, 0, loadS(5), mulInto(Y, 5), est_v);   // W6^T
+        dense<P, 8, 8, C8, false>(ws, Y, 0, loadS(4), mulInto(X, 4), est_v);   // W5^T
         {   // W4^T: 9 output tiles = [h4 part (7 tiles) | PE part (2 tiles)]
             f32x16 UPE[2];
             dense<P, 8, 9, C7, false>(ws, X, 0,
@@ -167,9 +172,9 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_fwd_ker
                 });
             pe_backward(UPE);
         }
-        dense<P, 7, 8, C8, false>(ws, Y, 0, loadS(2), mulInto(X, 2));   // W3^T
-        dense<P, 8, 8, C8, false>(ws, X, 0, loadS(1), mulInto(Y, 1));   // W2^T
-        dense<P, 8, 8, C8, false>(ws, Y, 0, loadS(0), mulInto(X, 0));   // W1^T
+        dense<P, 7, 8, C8, false>(ws, Y, 0, loadS(2), mulInto(X, 2), est_v);   // W3^T
+        dense<P, 8, 8, C8, false>(ws, X, 0, loadS(1), mulInto(Y, 1), est_v);   // W2^T
+        dense<P, 8, 8, C8, false>(ws, Y, 0, loadS(0), mulInto(X, 0), est_v);   // W1^T
         f32x16 U0[2];
         dense<P, 8, 2, 0, false>(ws, X, 0, NoPre{}, [&](int nt, const f32x16& acc, int) VDN_INL { U0[nt] = acc; });   // W0^T
         pe_backward(U0);
@@ -180,23 +185,31 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_fwd_ker
     }
 }
 
+template <class P, int MODE, int NW>
+void launch_sdf_nw(const VdnSdfArgs* args, hipStream_t stream) {
+    const size_t lds = 2 * P::chunk_bytes(9);
+    static bool once = (allow_big_lds(sdf_fwd_kernel<P, MODE, NW>, lds), true);
+    (void)once;
+    const int grid = (args->P + NW * 32 - 1) / (NW * 32);
+    hipLaunchKernelGGL((sdf_fwd_kernel<P, MODE, NW>), dim3(grid), dim3(NW * 64), lds, stream, *args);
+}
+
 template <class P>
 int launch_sdf_fwd(int mode, const VdnSdfArgs* args, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (args == nullptr || args->P <= 0 || args->blob == nullptr) return -1;
     if (args->pts == nullptr && (args->rays_o == nullptr || args->rays_d == nullptr || args->z == nullptr || args->n_per_ray <= 0 ||
                                  args->z_ld < args->n_per_ray || args->sdf_ld < args->n_per_ray)) return -2;
-    const int ppw = P::kWaves * 32;
-    const int grid = (args->P + ppw - 1) / ppw;
-    const size_t lds = 2 * P::chunk_bytes(9);
-    static bool once = (allow_big_lds(sdf_fwd_kernel<P, 0>, lds), allow_big_lds(sdf_fwd_kernel<P, 1>, lds), true);
-    (void)once;
     if (mode == 0) {
         if (args->sdf == nullptr) return -3;
-        hipLaunchKernelGGL((sdf_fwd_kernel<P, 0>), dim3(grid), dim3(P::kWaves * 64), lds, stream, *args);
+        // waves per workgroup so that the grid is >= 256 workgroups (one per CU) when the batch allows it
+        const int tiles = (args->P + 31) / 32;
+        if (tiles >= 4 * 256) launch_sdf_nw<P, 0, 4>(args, stream);
+        else if (tiles >= 2 * 256) launch_sdf_nw<P, 0, 2>(args, stream);
+        else launch_sdf_nw<P, 0, 1>(args, stream);
     } else if (mode == 1) {
         if (!args->sdf || !args->feat || !args->normals || !args->S || !args->w8row) return -3;
-        hipLaunchKernelGGL((sdf_fwd_kernel<P, 1>), dim3(grid), dim3(P::kWaves * 64), lds, stream, *args);
+        launch_sdf_nw<P, 1, P::kWaves>(args, stream);
     } else {
         return -4;
     }

@@ -6,7 +6,7 @@
 //          chunk = [KT*4 groups][64 lanes][4 f32] + 32 f32 bias (+pad) = KT*4096 + 1024 bytes
 //          lane (i,h) of group g holds W[nt*32+i][8g+4h .. +3]; HBM activations stored as f32.
 //   BF16 : v_mfma_f32_32x32x16_bf16, bf16 operands / fp32 accumulate (throughput path).
-//          8 waves / workgroup, 2 waves / SIMD.
+//          4 waves / workgroup, 2 workgroups / CU = 2 waves / SIMD.
 //          chunk = [KT*2 k-steps][64 lanes][8 bf16] + 32 f32 bias (+pad) = KT*2048 + 1024 bytes
 //          lane (i,h) element j of k-step s holds W[nt*32+i][16s + 8(j>>2) + 4h + (j&3)], which is the
 //          k order in which a 32x32 accumulator tile converts to B fragments with no lane movement;
@@ -35,6 +35,7 @@ struct WStream {
     char* lds;       // base of the two slots
     int slot;        // slot holding the current chunk
     int wave, lane;
+    bool all_issue;  // set by the kernel: this wave has at least one in-range lane (so it issues every store)
 
     VDN_DEV void init(const char* blob, char* smem) {
         g = blob;
@@ -42,6 +43,7 @@ struct WStream {
         slot = 1;
         wave = threadIdx.x >> 6;
         lane = threadIdx.x & 63;
+        all_issue = false;
     }
     template <int BYTES>
     VDN_DEV void issue(int s) {
@@ -57,10 +59,22 @@ struct WStream {
     template <int FIRST_BYTES>
     VDN_DEV void start() { issue<FIRST_BYTES>(0); }
     // Make the chunk issued last current (all waves), then start fetching the next one.
+    // YOUNGER = number of vector-memory instructions this wave has issued AFTER the glds of the chunk being
+    // acquired and that may still be in flight (the previous tile's epilogue stores). vmcnt counts loads,
+    // stores and LDS-DMA together in issue order, so vmcnt(YOUNGER) retires the chunk without draining those
+    // stores (draining them exposes a full HBM store latency at every chunk step). `all_issue` (member) must be
+    // false for a wave whose lanes are all out of range (it skips its stores, so only vmcnt(0) is safe for it).
     template <int NEXT_BYTES>
-    VDN_DEV const char* acquire() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+    VDN_DEV const char* acquire(int younger = 0) {
+        if (!all_issue) younger = 0;
+        switch (younger) {                       // wave-uniform
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         slot ^= 1;
         if constexpr (NEXT_BYTES > 0) issue<NEXT_BYTES>(slot ^ 1);
         return lds + slot * SLOT_BYTES;
@@ -150,7 +164,9 @@ struct F32 {
 };
 
 struct BF16 {
-    static constexpr int kWaves = 8;
+    // 4 waves per workgroup and two workgroups resident per CU (2 waves / SIMD): the workgroups run their
+    // chunk barriers independently, so one computes while the other waits on memory
+    static constexpr int kWaves = 4;
     static constexpr int kMinWavesPerEU = 2;
     static constexpr int chunk_bytes(int KT) { return KT * 2048 + 1024; }
     using store_t = unsigned short;   // bf16 bits
@@ -230,16 +246,25 @@ struct BF16 {
 // then epi(nt, acc, aux) with aux = pre(nt) evaluated right after the chunk is acquired (so its
 // loads overlap the MFMA loop). NEXT_BYTES = size of the chunk that follows this layer's last chunk
 // in the stream (0 at the end of the stream).
+// epi_stores = vector-memory store instructions every in-range wave issues in epi() per tile (0, 4, 8 or 12;
+// a lower bound is safe, 0 drains the queue at every step).
 template <class P, int KT, int NT, int NEXT_BYTES, bool BIAS, class WS, class ActT, class Pre, class Epi>
-VDN_DEV void dense(WS& ws, const ActT& X, int x0, Pre&& pre, Epi&& epi) {
+VDN_DEV void dense(WS& ws, const ActT& X, int x0, Pre&& pre, Epi&& epi, int epi_stores = 0) {
     const int lane = ws.lane;
+    // pre(nt) (HBM loads feeding tile nt's epilogue) is issued one chunk step ahead of its use, so a full
+    // step of MFMA + epilogue work hides its latency; tile 0's is issued before the layer's first barrier.
+    auto aux = pre(0);
     static_for<NT>([&](auto nt_c) VDN_INL {
         constexpr int nt = decltype(nt_c)::value;
-        const char* w = (nt + 1 < NT) ? ws.template acquire<P::chunk_bytes(KT)>()
-                                      : ws.template acquire<NEXT_BYTES>();
-        auto aux = pre(nt);
+        // tile 0 follows another layer's epilogue (unknown store count): full drain there
+        const int yg = nt == 0 ? 0 : epi_stores;
+        const char* w = (nt + 1 < NT) ? ws.template acquire<P::chunk_bytes(KT)>(yg)
+                                      : ws.template acquire<NEXT_BYTES>(yg);
+        auto aux_next = aux;
+        if constexpr (nt + 1 < NT) aux_next = pre(nt + 1);
         const f32x16 acc = P::template mma<KT, BIAS>(w, X, x0, lane);
         epi(nt, acc, aux);
+        aux = aux_next;
         // keep each tile's epilogue inside its own chunk step: without this the scheduler sinks the
         // register-only epilogues of several tiles past the barriers and runs out of registers
         __builtin_amdgcn_sched_barrier(0);

@@ -51,19 +51,23 @@ VDN_DEV float hw_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.442695040888
 VDN_DEV float hw_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
 
 // Softplus(beta=100, threshold=20) and its derivative sigmoid(100 a) from one exponential
-// (reference fields.py:70; derivative in the z/(z+1) form of ATen's backward).
+// (reference fields.py:70; derivative in the z/(z+1) form of ATen's backward), written to minimise VALU
+// instructions - the epilogue, not the MFMAs, bounds the bf16 kernels:
+//   t = a * 100 log2(e);  e = 2^-|t|;  L = log2(1 + e)                      (no overflow for any a)
+//   softplus = max(a, 0) + L * ln2/100      (equals the thresholded form to < 1e-10 beyond 100 a > 20)
+//   sigmoid(100 a) = a >= 0 ? 1/(1+e) : e/(1+e)
 VDN_DEV void softplus100_both(float a, float& hval, float& sval) {
-    const float z = a * 100.0f;
-    const float e = hw_exp(fminf(z, 30.0f));
+    const float t = a * 144.26950408889634f;
+    const float e = __builtin_amdgcn_exp2f(-fabsf(t));
     const float u = 1.0f + e;
-    const bool lin = z > 20.0f;
-    hval = lin ? a : hw_log(u) * 0.01f;
-    sval = lin ? 1.0f : e * __builtin_amdgcn_rcpf(u);
+    hval = fmaf(__builtin_amdgcn_logf(u), 0.0069314718055994529f, fmaxf(a, 0.0f));
+    const float r = __builtin_amdgcn_rcpf(u);
+    sval = a >= 0.0f ? r : e * r;
 }
 VDN_DEV float softplus100_fast(float a) {
-    const float z = a * 100.0f;
-    const float e = hw_exp(fminf(z, 30.0f));
-    return z > 20.0f ? a : hw_log(1.0f + e) * 0.01f;
+    const float t = a * 144.26950408889634f;
+    const float e = __builtin_amdgcn_exp2f(-fabsf(t));
+    return fmaf(__builtin_amdgcn_logf(1.0f + e), 0.0069314718055994529f, fmaxf(a, 0.0f));
 }
 
 VDN_DEV float softplus100(float a) {
