@@ -17,7 +17,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void nerf_bwd_ke
     const long p_raw = ((long)blockIdx.x * P::kWaves + ws.wave) * 32 + c;
     const bool ok = p_raw < a.P;
     const long p = ok ? p_raw : (long)a.P - 1;
-    const long PS = (long)a.P * 256;
+    const long PS = P::plane(a.P, 256);
     constexpr int KO = DPT ? 4 : 1;
     constexpr int LDO = DPT ? 128 : 32;
     const ST* save_h = reinterpret_cast<const ST*>(a.save_h);

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void nerf_fwd_ke
     const long p = ok ? p_raw : (long)a.P - 1;
     const long r = p / a.n_per_ray;
     ST* save_h = reinterpret_cast<ST*>(a.save_h);
-    const long PS = (long)a.P * 256;
+    const long PS = P::plane(a.P, 256);
 
     float dir[3], p4[4];
 #pragma unroll

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_b
     const long p_raw = ((long)blockIdx.x * P::kWaves + ws.wave) * 32 + c;
     const bool ok = p_raw < a.P;
     const long p = ok ? p_raw : (long)a.P - 1;
-    const long PS = (long)a.P * 256;
+    const long PS = P::plane(a.P, 256);
     const ST* save_h = reinterpret_cast<const ST*>(a.save_h);
     ST* delta_h = reinterpret_cast<ST*>(a.delta_h);
     ST* delta_out = reinterpret_cast<ST*>(a.delta_out);

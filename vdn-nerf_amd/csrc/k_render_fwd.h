@@ -24,7 +24,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_f
     const ST* feat = reinterpret_cast<const ST*>(a.feat);
     ST* save_h = reinterpret_cast<ST*>(a.save_h);
     ST* save_small = reinterpret_cast<ST*>(a.save_small);
-    const long PS = (long)a.P * 256;
+    const long PS = P::plane(a.P, 256);
 
     typename P::template Act<10> X;
     typename P::template Act<8> Y;

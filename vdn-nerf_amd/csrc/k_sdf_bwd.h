@@ -28,7 +28,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_rbar_ke
     const long p_raw = ((long)blockIdx.x * P::kWaves + ws.wave) * 32 + c;
     const bool ok = p_raw < a.P;
     const long p = ok ? p_raw : (long)a.P - 1;
-    const long Pn = a.P, PS = Pn * 256;
+    const long Pn = P::rows(a.P), PS = Pn * 256;
     const ST* S = reinterpret_cast<const ST*>(a.S);
     const ST* V = reinterpret_cast<const ST*>(a.V);
     ST* EX = reinterpret_cast<ST*>(a.EX);
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_fbar_ke
     const long p_raw = ((long)blockIdx.x * P::kWaves + ws.wave) * 32 + c;
     const bool ok = p_raw < a.P;
     const long p = ok ? p_raw : (long)a.P - 1;
-    const long Pn = a.P, PS = Pn * 256;
+    const long Pn = P::rows(a.P), PS = Pn * 256;
     const ST* S = reinterpret_cast<const ST*>(a.S);
     const ST* EX = reinterpret_cast<const ST*>(a.EX);
     const ST* g_feat = reinterpret_cast<const ST*>(a.g_feat);

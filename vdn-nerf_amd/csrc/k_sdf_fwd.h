@@ -41,7 +41,7 @@ __global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(Sdf
     ST* S = reinterpret_cast<ST*>(a.S);
     ST* Hs = reinterpret_cast<ST*>(a.H);
     ST* Vs = reinterpret_cast<ST*>(a.V);
-    const long PS = (long)a.P * 256;
+    const long PS = P::plane(a.P, 256);
 
     typename P::template Act<9> X, Y;
     auto put_pe = [&](int tile0) VDN_INL {

@@ -141,6 +141,9 @@ struct F32 {
         return acc;
     }
 
+    // elements of one [P, ld] activation plane / padded point count (row-major: no padding)
+    static VDN_DEV long plane(long P, int ld) { return P * ld; }
+    static VDN_DEV long rows(long P) { return P; }
     // row-major [P, ld] <-> activation tile: lane (c,h) owns 16-byte pieces at column 32*tile + 8q + 4h
     static VDN_DEV void store_tile(float* base, long row, int ld, int tile, int h, const f32x16& v, bool ok) {
         if (!ok) return;
@@ -218,24 +221,29 @@ struct BF16 {
         return acc;
     }
 
-    // row-major bf16 [P, ld]: lane (c,h) owns 8-byte pieces (4 bf16) at column 32*tile + 8q + 4h
+    // bf16 activation planes use the tile-blocked "PT32" layout: points in blocks of 32 (= one wave's tile),
+    //   element (p, f) at  (p>>5)*(32*ld) + (f>>5)*1024 + ((f&31)>>3)*256 + ((f&7)>>2)*128 + (p&31)*4 + (f&3)
+    // so that a wave's store/load of (tile, q) is ONE contiguous 512-byte run (64 lanes x 8 B) instead of 64
+    // 8-byte pieces in 32 different rows, and the weight-gradient GEMM reads 1 KiB runs. P is padded to 32.
+    static VDN_DEV long rows(long P) { return (P + 31) & ~31L; }
+    static VDN_DEV long plane(long P, int ld) { return rows(P) * ld; }
     static VDN_DEV void store_tile(unsigned short* base, long row, int ld, int tile, int h, const f32x16& v, bool ok) {
         if (!ok) return;
-        unsigned short* p = base + row * ld + tile * 32 + 4 * h;
+        unsigned short* p = base + (row >> 5) * (32L * ld) + tile * 1024 + h * 128 + (row & 31) * 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             uint2 o;
             o.x = pack_bf16x2(v[4 * q], v[4 * q + 1]);
             o.y = pack_bf16x2(v[4 * q + 2], v[4 * q + 3]);
-            *reinterpret_cast<uint2*>(p + 8 * q) = o;
+            *reinterpret_cast<uint2*>(p + 256 * q) = o;
         }
     }
     static VDN_DEV f32x16 load_tile(const unsigned short* base, long row, int ld, int tile, int h) {
-        const unsigned short* p = base + row * ld + tile * 32 + 4 * h;
+        const unsigned short* p = base + (row >> 5) * (32L * ld) + tile * 1024 + h * 128 + (row & 31) * 4;
         f32x16 r;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const uint2 o = *reinterpret_cast<const uint2*>(p + 8 * q);
+            const uint2 o = *reinterpret_cast<const uint2*>(p + 256 * q);
             r[4 * q] = bf16_lo(o.x); r[4 * q + 1] = bf16_hi(o.x); r[4 * q + 2] = bf16_lo(o.y); r[4 * q + 3] = bf16_hi(o.y);
         }
         return r;

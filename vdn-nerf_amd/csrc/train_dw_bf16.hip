@@ -1,21 +1,23 @@
 // Weight-gradient GEMM on gfx950 with bf16 MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulate):
-// dW[m,n] = sum over points of A[p,m] * B[p,n], A/B = bf16 row-major activations written by the
-// backward chains. The contraction index (points) is the ROW index of both operands, while an MFMA
-// lane needs 8 consecutive k for one feature, so every tile is transposed on its way into LDS:
-//   global (8 rows x 4 features per lane, 8-byte loads, 256 B contiguous per half-wave)
-//   -> registers -> 16-bit interleave -> ds_write_b128 into [k-half][feature][8 x bf16]
-//   -> ds_read_b128 = one ready MFMA fragment per lane.
-// Workgroup = 4 waves = 128 x 128 outputs (wave: 2 x 2 tiles of 32 x 32), 64 points per LDS stage,
-// two stages (global loads of stage t+1 are in flight while stage t is multiplied). K is split across
-// workgroups; partial slabs are reduced by vdn_dw_finalize (train_dw_f32.hip), deterministically.
+// dW[m,n] = sum over points of A[p,m] * B[p,n], A/B = bf16 activation planes in the tile-blocked PT32 layout
+// written by the backward chains (mlp_engine.h: points in blocks of 32; within a (block, 32-feature tile):
+// [q(4)][hh(2)][point(32)][e(4)], feature = 32*tile + 8q + 4hh + e).
+//
+// The contraction index (points) is the slow index of both operands, while an MFMA lane needs 8 k-values of ONE
+// feature. Loader: one wave-instruction reads 1 KiB contiguous = half a (block, tile): lane (q2, hh, cpair) gets
+// 2 points x 4 features; the same lane position in 4 consecutive blocks gives 8 points x 4 features, which a
+// 16-bit interleave turns into four ready MFMA fragments (k order = (block, point) - identical for A and B, so
+// the contraction is unchanged). Fragments go to LDS as [k-group(16)][feature(128)][16 B]; k-group = cpair.
+// Workgroup = 4 waves = 128 x 128 outputs (wave: 2 x 2 tiles of 32 x 32); stage = 128 points = 8 k-steps; the
+// next stage's global loads are in flight (registers) while the current stage is multiplied out of LDS.
+// K is split across workgroups; partial slabs are reduced by vdn_dw_finalize (train_dw_f32.hip), deterministically.
 #include "mlp_engine.h"
 #include "vdn_kernels.h"
 
 namespace vdn {
 
-constexpr int kDwStagePts = 64;                 // points per stage = 4 k-steps of 16
-constexpr int kDwPanelBytes = 4 * 4096;         // one operand, one stage: [4 k-steps][2 halves][128 features][16 B]
-constexpr int kDwStageBytes = 2 * kDwPanelBytes;
+constexpr int kDwStagePts = 128;
+constexpr int kDwPanelBytes = 16 * 128 * 16;    // one operand: [16 k-groups][128 features][8 x bf16]
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -27,8 +29,14 @@ __global__ __launch_bounds__(256, 2) void dw_gemm_bf16_kernel(const DwDesc* desc
     const DwDesc d = descs[di];
     const int local = wg - d.wg_begin;
     const int mt4 = (d.m_tiles + 3) / 4, nt4 = max((d.n_tiles + 3) / 4, 1);
-    const int split = local / (mt4 * nt4);
-    const int tile = local % (mt4 * nt4);
+    // XCD-aware mapping: workgroup ids are dealt round-robin over the 8 XCDs (observed; used for speed only), so
+    // the tiles of one K split - which read the same A/B panels - are given ids that are equal mod 8 and adjacent in
+    // time: the second reader finds the panel in that XCD's L2 instead of HBM. wg_begin is a multiple of 8.
+    const int ntile = mt4 * nt4;
+    const int slot = local & 7, round = local >> 3;
+    const int split = slot + 8 * (round / ntile);
+    const int tile = round % ntile;
+    if (split >= d.splits) return;
     const int tm = tile / nt4, tn = tile % nt4;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
@@ -48,45 +56,56 @@ __global__ __launch_bounds__(256, 2) void dw_gemm_bf16_kernel(const DwDesc* desc
     const unsigned short* Bm = reinterpret_cast<const unsigned short*>(seg2 ? d.B2 : d.B1);
     const int lda = seg2 ? d.lda2 : d.lda1, ldb = seg2 ? d.ldb2 : d.ldb1;
 
-    // loader role: waves 0,1 -> operand A, k-step pairs {0,1},{2,3}; waves 2,3 -> operand B likewise
+    // loader role: waves 0,1 -> operand A feature tiles {0,1},{2,3} of the 128-wide panel; waves 2,3 -> operand B
     const bool load_b = wave >= 2;
-    const int ks0 = (wave & 1) * 2;
     const unsigned short* src = load_b ? Bm : A;
     const int ld = load_b ? ldb : lda;
-    const int col0 = (load_b ? tn : tm) * 128 + 4 * c;           // this lane's 4 features
-    const bool col_ok = col0 < (load_b ? d.n_tiles : d.m_tiles) * 32 && (load_b ? d.n_tiles > 0 : true);
-    uint2 regs[2][8];
+    const int ntiles = load_b ? d.n_tiles : d.m_tiles;
+    const int panel_t0 = (load_b ? tn : tm) * 4;
+    const int q2 = lane >> 5, hh = (lane >> 4) & 1, cpair = lane & 15;
+    u32x4 regs[2][2][4];       // [tile-in-pair][Q][block]
     auto load_stage = [&](long kbase) VDN_INL {
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int tl = 0; tl < 2; ++tl) {
+            const int t = panel_t0 + (wave & 1) * 2 + tl;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const long row = kbase + (ks0 + b) * 16 + 8 * h + j;
-                uint2 v = make_uint2(0u, 0u);
-                if (col_ok && row < k_end) v = *reinterpret_cast<const uint2*>(src + row * ld + col0);
-                regs[b][j] = v;
+            for (int Q = 0; Q < 2; ++Q) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const long p0 = kbase + 32 * b + 2 * cpair;        // this lane's two points
+                    u32x4 v = {0u, 0u, 0u, 0u};
+                    if (t < ntiles && p0 < k_end) {
+                        v = *reinterpret_cast<const u32x4*>(src + ((kbase >> 5) + b) * (32L * ld) + t * 1024 + (2 * Q + q2) * 256 + hh * 128 + cpair * 8);
+                        if (p0 + 1 >= k_end) { v[2] = 0u; v[3] = 0u; }   // second point beyond the range (padding rows hold garbage)
+                    }
+                    regs[tl][Q][b] = v;
+                }
             }
         }
     };
-    auto store_stage = [&](int buf) VDN_INL {
-        char* panel = smem + buf * kDwStageBytes + (load_b ? kDwPanelBytes : 0);
+    auto store_stage = [&]() VDN_INL {
+        char* panel = smem + (load_b ? kDwPanelBytes : 0);
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            // features f0..f3 of this lane, 8 points each -> four 16-byte fragments
-            u32x4 f0, f1, f2, f3;
+        for (int tl = 0; tl < 2; ++tl) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const uint2 ra = regs[b][2 * m], rb = regs[b][2 * m + 1];
-                f0[m] = (ra.x & 0xFFFFu) | (rb.x << 16);
-                f1[m] = (ra.x >> 16) | (rb.x & 0xFFFF0000u);
-                f2[m] = (ra.y & 0xFFFFu) | (rb.y << 16);
-                f3[m] = (ra.y >> 16) | (rb.y & 0xFFFF0000u);
+            for (int Q = 0; Q < 2; ++Q) {
+                // dwords of a load: d0 = (pt0: e0,e1) d1 = (pt0: e2,e3) d2 = (pt1: e0,e1) d3 = (pt1: e2,e3)
+                u32x4 f0, f1, f2, f3;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const u32x4 v = regs[tl][Q][b];
+                    f0[b] = (v[0] & 0xFFFFu) | (v[2] << 16);
+                    f1[b] = (v[0] >> 16) | (v[2] & 0xFFFF0000u);
+                    f2[b] = (v[1] & 0xFFFFu) | (v[3] << 16);
+                    f3[b] = (v[1] >> 16) | (v[3] & 0xFFFF0000u);
+                }
+                const int fl = ((wave & 1) * 2 + tl) * 32 + (2 * Q + q2) * 8 + hh * 4;     // panel-local feature of e = 0
+                char* dst = panel + (cpair * 128 + fl) * 16;
+                *reinterpret_cast<u32x4*>(dst) = f0;
+                *reinterpret_cast<u32x4*>(dst + 16) = f1;
+                *reinterpret_cast<u32x4*>(dst + 32) = f2;
+                *reinterpret_cast<u32x4*>(dst + 48) = f3;
             }
-            char* dst = panel + (ks0 + b) * 4096 + (h * 128 + 4 * c) * 16;
-            *reinterpret_cast<u32x4*>(dst) = f0;
-            *reinterpret_cast<u32x4*>(dst + 16) = f1;
-            *reinterpret_cast<u32x4*>(dst + 32) = f2;
-            *reinterpret_cast<u32x4*>(dst + 48) = f3;
         }
     };
     f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
@@ -100,20 +119,18 @@ __global__ __launch_bounds__(256, 2) void dw_gemm_bf16_kernel(const DwDesc* desc
         return s;
     };
     const long n_stages = (k_end - k_begin + kDwStagePts - 1) / kDwStagePts;
-    if (n_stages > 0) {
-        load_stage(k_begin);
-        store_stage(0);
-    }
-    __syncthreads();
+    if (n_stages > 0) load_stage(k_begin);
     for (long t = 0; t < n_stages; ++t) {
-        const int buf = (int)(t & 1);
+        __syncthreads();                         // previous stage fully consumed
+        store_stage();
+        __syncthreads();
         if (t + 1 < n_stages) load_stage(k_begin + (t + 1) * kDwStagePts);
-        const char* pa = smem + buf * kDwStageBytes;
-        const char* pb = pa + kDwPanelBytes;
+        const char* pa = smem;
+        const char* pb = smem + kDwPanelBytes;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int offa = ks * 4096 + (h * 128 + wm * 64 + c) * 16;
-            const int offb = ks * 4096 + (h * 128 + wn * 64 + c) * 16;
+        for (int ks = 0; ks < 8; ++ks) {
+            const int offa = ((2 * ks + h) * 128 + wm * 64 + c) * 16;
+            const int offb = ((2 * ks + h) * 128 + wn * 64 + c) * 16;
             const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(pa + offa);
             const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(pa + offa + 32 * 16);
             const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(pb + offb);
@@ -127,8 +144,6 @@ __global__ __launch_bounds__(256, 2) void dw_gemm_bf16_kernel(const DwDesc* desc
             acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc10, 0, 0, 0);
             acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc11, 0, 0, 0);
         }
-        if (t + 1 < n_stages) store_stage(buf ^ 1);
-        __syncthreads();
     }
     const int M = d.m_tiles * 32, N = d.n_tiles * 32;
     auto put = [&](const f32x16& acc, int mt, int nt) VDN_INL {
@@ -155,8 +170,8 @@ __global__ __launch_bounds__(256, 2) void dw_gemm_bf16_kernel(const DwDesc* desc
 extern "C" int vdn_dw_gemm_bf16(const VdnDwDesc* descs_dev, int n_desc, int total_wgs, void* stream) {
     using namespace vdn;
     if (!descs_dev || n_desc <= 0 || total_wgs <= 0) return -1;
-    static bool once = (allow_big_lds(dw_gemm_bf16_kernel, 2 * kDwStageBytes), true);
+    static bool once = (allow_big_lds(dw_gemm_bf16_kernel, 2 * kDwPanelBytes), true);
     (void)once;
-    hipLaunchKernelGGL(dw_gemm_bf16_kernel, dim3(total_wgs), dim3(256), 2 * kDwStageBytes, (hipStream_t)stream, descs_dev, n_desc);
+    hipLaunchKernelGGL(dw_gemm_bf16_kernel, dim3(total_wgs), dim3(256), 2 * kDwPanelBytes, (hipStream_t)stream, descs_dev, n_desc);
     return (int)hipGetLastError();
 }

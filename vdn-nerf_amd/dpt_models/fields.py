@@ -10,7 +10,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from vdn_hip import images, lib
+from vdn_hip import images, layout, lib
 from dpt_models.embedder import get_embedder
 
 
@@ -152,9 +152,10 @@ class SDFNetwork(_HipNet):
             a.blob = img.blobs["sdf"].data_ptr()
             lib.call("vdn_sdf_mlp_fwd" + self._sfx(), 0, a, _stream())
             return sdf
-        feat = torch.empty(P, 256, dtype=self._store_dtype(), device=dev)
+        Pr = layout.rows(P, self.precision)          # bf16 planes are tile-blocked and padded to 32 points
+        feat = torch.empty(Pr, 256, dtype=self._store_dtype(), device=dev)
         normals = torch.empty(P, 3, dtype=torch.float32, device=dev)
-        S = torch.empty(8, P, 256, dtype=self._store_dtype(), device=dev)
+        S = torch.empty(8, Pr, 256, dtype=self._store_dtype(), device=dev)
         a.blob = img.blobs["full"].data_ptr()
         a.feat, a.normals, a.S = feat.data_ptr(), normals.data_ptr(), S.data_ptr()
         a.w8row = img.weff_view("lin8").data_ptr()
@@ -167,7 +168,9 @@ class SDFNetwork(_HipNet):
         if inputs.numel() == 0:
             return inputs.new_zeros(0, self.conf["d_out"])
         sdf, feat, _ = self._run(1, pts=inputs.detach())
-        return torch.cat([sdf[:, None], feat.float()], dim=-1)
+        if self.precision == "bf16":
+            feat = layout.from_pt32(feat, inputs.shape[0], 256)
+        return torch.cat([sdf[:, None], feat], dim=-1)
 
     def sdf(self, x):
         if x.numel() == 0:
@@ -231,8 +234,10 @@ class RenderingNetwork(_HipNet):
             _require_gpu(t, "RenderingNetwork " + n)
         if points.shape[0] == 0:
             return points.new_zeros(0, self.conf["d_out"])
-        return self._run(normals.detach().contiguous(), feature_vectors.detach().to(self._store_dtype()).contiguous(),
-                         pts=points.detach().contiguous(), dirs=view_dirs.detach().contiguous())
+        fv = feature_vectors.detach().contiguous()
+        if self.precision == "bf16":
+            fv = layout.to_pt32(fv)
+        return self._run(normals.detach().contiguous(), fv, pts=points.detach().contiguous(), dirs=view_dirs.detach().contiguous())
 
 
 class NeRF(_HipNet):

@@ -11,7 +11,7 @@ and returns d loss / d parameter for every parameter, in module.parameters() ord
 import numpy as np
 import torch
 
-from . import images, lib
+from . import images, layout, lib
 
 PTS_PER_SPLIT = 4096
 
@@ -67,35 +67,39 @@ class TrainEngine:
         f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
         fs = lambda *shape: torch.empty(*shape, dtype=sdt, device=dev)
         P, Q, N, T = self.P, self.Q, self.N, self.T
+        # MLP-internal planes: row-major [P, ld] in fp32, tile-blocked + padded to 32 points in bf16 (vdn_hip/layout.py).
+        # `Pp` / `Qp` are the plane row counts; API-visible tensors (sdf, normals, colours ...) keep exact P / Q rows.
+        Pp, Qp = layout.rows(P, self.precision), layout.rows(Q, self.precision)
+        self.Pp, self.Qp = Pp, Qp
         w = self.w = {}
         # ---- forward saves
         w["dists"], w["mid_z"] = f(B, N), f(B, N)
-        w["sdf"], w["feat"], w["normals"] = f(P), fs(P, 256), f(P, 3)
-        w["S"], w["H"], w["V"], w["PE"] = fs(8, P, 256), fs(8, P, 256), fs(8, P, 256), fs(P, 64)
-        w["col_out"], w["col_h"], w["col_small"] = f(P, 3), fs(4, P, 256), fs(P, 64)
+        w["sdf"], w["feat"], w["normals"] = f(P), fs(Pp, 256), f(P, 3)
+        w["S"], w["H"], w["V"], w["PE"] = fs(8, Pp, 256), fs(8, Pp, 256), fs(8, Pp, 256), fs(Pp, 64)
+        w["col_out"], w["col_h"], w["col_small"] = f(P, 3), fs(4, Pp, 256), fs(Pp, 64)
         if self.wdepth:
-            w["vdn_out"], w["vdn_h"], w["vdn_small"] = f(P, 96), fs(4, P, 256), fs(P, 64)
+            w["vdn_out"], w["vdn_h"], w["vdn_small"] = f(P, 96), fs(4, Pp, 256), fs(Pp, 64)
         if O > 0:
             w["z_feed"], w["bg_dists"], w["bg_mid"] = f(B, T), f(B, T), f(B, T)
             w["bg_density"], w["bg_rgb"] = f(Q), f(Q, 3)
             w["bg_feat"] = f(Q, 96) if self.wdepth else None
-            w["nf_h"], w["nf_pe"], w["nf_feature"], w["nf_vpe"], w["nf_hv"] = fs(8, Q, 256), fs(Q, 96), fs(Q, 256), fs(Q, 32), fs(Q, 128)
+            w["nf_h"], w["nf_pe"], w["nf_feature"], w["nf_vpe"], w["nf_hv"] = fs(8, Qp, 256), fs(Qp, 96), fs(Qp, 256), fs(Qp, 32), fs(Qp, 128)
         w["weights"], w["alpha"], w["cdf"], w["inside"] = f(B, T), f(B, T), f(B, N), f(B, N)
         w["color"], w["wsum"], w["wmax"], w["s_val"] = f(B, 3), f(B, 1), f(B, 1), f(B, 1)
         w["eik_partial"], w["eik"] = f(B, 2), f(3)
         w["feat_out"] = f(B, 96) if self.wdepth else None
         # ---- backward intermediates
-        w["d_sdf"], w["d_normals"], w["d_color"], w["d_featvec"] = f(P), f(P, 3), f(P, 3), fs(P, 256)
+        w["d_sdf"], w["d_normals"], w["d_color"], w["d_featvec"] = f(P), f(P, 3), f(P, 3), fs(Pp, 256)
         w["d_vdn"] = f(P, 96) if self.wdepth else None
         w["d_var_partial"], w["d_variance"] = f(B), f(1)
-        w["col_dout"], w["col_dh"] = fs(P, 32), fs(4, P, 256)
+        w["col_dout"], w["col_dh"] = fs(Pp, 32), fs(4, Pp, 256)
         if self.wdepth:
-            w["vdn_dout"], w["vdn_dh"] = fs(P, 96), fs(4, P, 256)
-        w["UB"], w["EX"], w["AB"] = fs(P * 2144), fs(8, P, 256), fs(P * 2336)
+            w["vdn_dout"], w["vdn_dh"] = fs(Pp, 96), fs(4, Pp, 256)
+        w["UB"], w["EX"], w["AB"] = fs(Pp * 2144), fs(8, Pp, 256), fs(Pp * 2336)
         if O > 0:
             w["d_bg_density"], w["d_bg_rgb"] = f(Q), f(Q, 3)
             w["d_bg_feat"] = f(Q, 96) if self.wdepth else None
-            w["nf_do"], w["nf_dv"], w["nf_dhead"], w["nf_dh"] = fs(Q, 128 if self.wdepth else 32), fs(Q, 128), fs(Q, 288), fs(8, Q, 256)
+            w["nf_do"], w["nf_dv"], w["nf_dhead"], w["nf_dh"] = fs(Qp, 128 if self.wdepth else 32), fs(Qp, 128), fs(Qp, 288), fs(8, Qp, 256)
         # one flat gradient buffer over all parameters, in dpt_runner.py:121-130 order (nerf, sdf, variance,
         # colour, vdn): the single message of the data-parallel all-reduce
         self.params = renderer._all_parameters()
@@ -119,14 +123,16 @@ class TrainEngine:
     def _build_dw_plan(self):
         w, P, Q = self.w, self.P, self.Q
         ent = []    # dict(net, name, rmap, cmap, scale, A, A2, B, B2, bias(bool), Pn, extra)
+        # operand spec = (tensor, element offset of the plane inside the tensor, first column, ld of the plane)
+        Pp, Qp, prec = self.Pp, self.Qp, self.precision
         ub_off, off = {}, 0
         for l, cols in enumerate((64, 256, 256, 256, 288, 256, 256, 256, 256)):
             ub_off[l] = (off, cols)
-            off += P * cols
-        UB = lambda l, c0=0: (w["UB"], ub_off[l][0] + c0, ub_off[l][1])          # (tensor, elem offset, ld)
-        AB = lambda l: (w["AB"], 0, 288) if l == 8 else (w["AB"], P * 288 + (7 - l) * P * 256, 256)
-        sl = lambda t, l, ld=256: (t, l * t.shape[1] * t.shape[2], ld)             # layer slice of a [L,P,ld] tensor
-        whole = lambda t, c0=0: (t, c0, t.shape[1])
+            off += Pp * cols
+        UB = lambda l, c0=0: (w["UB"], ub_off[l][0], c0, ub_off[l][1])
+        AB = lambda l: (w["AB"], 0, 0, 288) if l == 8 else (w["AB"], Pp * 288 + (7 - l) * Pp * 256, 0, 256)
+        sl = lambda t, l, ld=256: (t, l * t.shape[1] * t.shape[2], 0, ld)          # layer plane of a [L, rows, ld] tensor
+        whole = lambda t, c0=0: (t, 0, c0, t.shape[1])
         maps = images.sdf_layer_maps()
         for l, (name, km, nm, sc) in enumerate(maps):
             if l == 8:
@@ -167,14 +173,14 @@ class TrainEngine:
                 ent.append(dict(net="nerf", name="pts_linears.%d" % i, rmap=I256, cmap=I256, scale=1.0, A=sl(dh, i), B=sl(h, i - 1), bias=True, Pn=Q))
             ent.append(dict(net="nerf", name="pts_linears.5", rmap=I256, cmap=km5[:96], scale=1.0, A=sl(dh, 5), B=whole(w["nf_pe"]), bias=True, Pn=Q))
             ent.append(dict(net="nerf", name="pts_linears.5", rmap=I256, cmap=km5[96:], scale=1.0, A=sl(dh, 5), B=sl(h, 4), bias=False, Pn=Q))
-            ent.append(dict(net="nerf", name="feature_linear", rmap=I256, cmap=I256, scale=1.0, A=(w["nf_dhead"], 0, 288), B=sl(h, 7), bias=True, Pn=Q))
-            ent.append(dict(net="nerf", name="alpha_linear", rmap=images.ident_map(1, 32), cmap=I256, scale=1.0, A=(w["nf_dhead"], 256, 288), B=sl(h, 7), bias=True, Pn=Q))
+            ent.append(dict(net="nerf", name="feature_linear", rmap=I256, cmap=I256, scale=1.0, A=(w["nf_dhead"], 0, 0, 288), B=sl(h, 7), bias=True, Pn=Q))
+            ent.append(dict(net="nerf", name="alpha_linear", rmap=images.ident_map(1, 32), cmap=I256, scale=1.0, A=(w["nf_dhead"], 0, 256, 288), B=sl(h, 7), bias=True, Pn=Q))
             ent.append(dict(net="nerf", name="views_linears.0", rmap=images.ident_map(128), cmap=kmv[:256], scale=1.0, A=whole(w["nf_dv"]), B=whole(w["nf_feature"]), bias=True, Pn=Q))
             ent.append(dict(net="nerf", name="views_linears.0", rmap=images.ident_map(128), cmap=kmv[256:], scale=1.0, A=whole(w["nf_dv"]), B=whole(w["nf_vpe"]), bias=False, Pn=Q))
             ldo = w["nf_do"].shape[1]
-            ent.append(dict(net="nerf", name="rgb_linear", rmap=images.ident_map(3, 32), cmap=images.ident_map(128), scale=1.0, A=(w["nf_do"], 0, ldo), B=whole(w["nf_hv"]), bias=True, Pn=Q))
+            ent.append(dict(net="nerf", name="rgb_linear", rmap=images.ident_map(3, 32), cmap=images.ident_map(128), scale=1.0, A=(w["nf_do"], 0, 0, ldo), B=whole(w["nf_hv"]), bias=True, Pn=Q))
             if self.wdepth:
-                ent.append(dict(net="nerf", name="dpt_linear", rmap=images.ident_map(96), cmap=images.ident_map(128), scale=1.0, A=(w["nf_do"], 32, ldo), B=whole(w["nf_hv"]), bias=True, Pn=Q))
+                ent.append(dict(net="nerf", name="dpt_linear", rmap=images.ident_map(96), cmap=images.ident_map(128), scale=1.0, A=(w["nf_do"], 0, 32, ldo), B=whole(w["nf_hv"]), bias=True, Pn=Q))
 
         # ---- tables
         dev = self.dev
@@ -199,20 +205,21 @@ class TrainEngine:
                 moff += nt * 32
             slab_elems += splits * mt * 32 * nt * 32
             cs_elems += splits * mt * 32
-            wg += ((mt + 3) // 4) * max((nt + 3) // 4, 1) * splits
+            ntile = ((mt + 3) // 4) * max((nt + 3) // 4, 1)
+            wg += (8 * ((splits + 7) // 8) * ntile) if self.precision == "bf16" else ntile * splits     # bf16: XCD-aware id space
         self.dw_total_wgs = wg
         self.maps = torch.from_numpy(np.concatenate(all_maps)).to(dev)
         self.slab = torch.empty(max(slab_elems, 1), dtype=torch.float32, device=dev)
         self.colsum = torch.empty(max(cs_elems, 1), dtype=torch.float32, device=dev)
-        P4 = lambda spec: spec[0].data_ptr() + spec[0].element_size() * spec[1]
+        P4 = lambda spec: spec[0].data_ptr() + spec[0].element_size() * (spec[1] + layout.col_offset_elems(spec[2], prec))
         for i, e in enumerate(ent):
             mt, nt, splits, so, co, mo, wg0 = lay[i]
             d = dw[i]
-            d["A1"], d["lda1"] = P4(e["A"]), e["A"][2]
+            d["A1"], d["lda1"] = P4(e["A"]), e["A"][3]
             if e["B"] is not None:
-                d["B1"], d["ldb1"] = P4(e["B"]), e["B"][2]
+                d["B1"], d["ldb1"] = P4(e["B"]), e["B"][3]
             if e.get("A2") is not None:
-                d["A2"], d["lda2"], d["B2"], d["ldb2"] = P4(e["A2"]), e["A2"][2], P4(e["B2"]), e["B2"][2]
+                d["A2"], d["lda2"], d["B2"], d["ldb2"] = P4(e["A2"]), e["A2"][3], P4(e["B2"]), e["B2"][3]
             d["P"], d["m_tiles"], d["n_tiles"], d["splits"], d["wg_begin"] = e["Pn"], mt, nt, splits, wg0
             d["slab"] = self.slab.data_ptr() + 4 * so
             want_cs = e["bias"] or e.get("extra_row0")
