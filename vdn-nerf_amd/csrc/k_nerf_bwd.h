@@ -74,9 +74,9 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void nerf_bwd_ke
         X.set(8, t16);
         P::store_tile(delta_head, p, 288, 8, h, t16, ok);
     }
-    dense<P, 9, 8, C8, false>(ws, X, 0, ldH(7), mask_store(Y, delta_h + 7 * PS, 256), 4);     // Whead^T
-    dense<P, 8, 8, C8, false>(ws, Y, 0, ldH(6), mask_store(X, delta_h + 6 * PS, 256), 4);     // W7^T
-    dense<P, 8, 8, C8, false>(ws, X, 0, ldH(5), mask_store(Y, delta_h + 5 * PS, 256), 4);     // W6^T
+    dense<P, 9, 8, C8, false>(ws, X, 0, ldH(7), mask_store(Y, delta_h + 7 * PS, 256), 4, 4);     // Whead^T
+    dense<P, 8, 8, C8, false>(ws, Y, 0, ldH(6), mask_store(X, delta_h + 6 * PS, 256), 4, 4);     // W7^T
+    dense<P, 8, 8, C8, false>(ws, X, 0, ldH(5), mask_store(Y, delta_h + 5 * PS, 256), 4, 4);     // W6^T
     // W5^T: 11 output tiles = [PE (3, dropped) | h4 (8)]
     dense<P, 8, 11, C8, false>(ws, Y, 0,
         [&](int nt) VDN_INL { return nt >= 3 ? P::load_tile(save_h + 4 * PS, p, 256, nt - 3, h) : f32x16{}; },
@@ -89,10 +89,10 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void nerf_bwd_ke
                 P::store_tile(delta_h + 4 * PS, p, 256, nt - 3, h, o, ok);
             }
         });
-    dense<P, 8, 8, C8, false>(ws, X, 0, ldH(3), mask_store(Y, delta_h + 3 * PS, 256), 4);     // W4^T
-    dense<P, 8, 8, C8, false>(ws, Y, 0, ldH(2), mask_store(X, delta_h + 2 * PS, 256), 4);     // W3^T
-    dense<P, 8, 8, C8, false>(ws, X, 0, ldH(1), mask_store(Y, delta_h + 1 * PS, 256), 4);     // W2^T
-    dense<P, 8, 8, 0, false>(ws, Y, 0, ldH(0), mask_store(X, delta_h + 0 * PS, 256), 4);      // W1^T
+    dense<P, 8, 8, C8, false>(ws, X, 0, ldH(3), mask_store(Y, delta_h + 3 * PS, 256), 4, 4);     // W4^T
+    dense<P, 8, 8, C8, false>(ws, Y, 0, ldH(2), mask_store(X, delta_h + 2 * PS, 256), 4, 4);     // W3^T
+    dense<P, 8, 8, C8, false>(ws, X, 0, ldH(1), mask_store(Y, delta_h + 1 * PS, 256), 4, 4);     // W2^T
+    dense<P, 8, 8, 0, false>(ws, Y, 0, ldH(0), mask_store(X, delta_h + 0 * PS, 256), 4, 4);      // W1^T
 }
 
 template <class P>

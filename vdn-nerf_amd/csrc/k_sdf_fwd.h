@@ -152,9 +152,9 @@ __global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(Sdf
                 }
             }
         };
-        dense<P, 8, 8, C8, false>(ws, Y, 0, loadS(6), mulInto(X, 6), est_v);   // through W7^T
-        dense<P, 8, 8, C8, false>(ws, X, 0, loadS(5), mulInto(Y, 5), est_v);   // W6^T
-        dense<P, 8, 8, C8, false>(ws, Y, 0, loadS(4), mulInto(X, 4), est_v);   // W5^T
+        dense<P, 8, 8, C8, false>(ws, Y, 0, loadS(6), mulInto(X, 6), est_v, 4);   // through W7^T
+        dense<P, 8, 8, C8, false>(ws, X, 0, loadS(5), mulInto(Y, 5), est_v, 4);   // W6^T
+        dense<P, 8, 8, C8, false>(ws, Y, 0, loadS(4), mulInto(X, 4), est_v, 4);   // W5^T
         {   // W4^T: 9 output tiles = [h4 part (7 tiles) | PE part (2 tiles)]
             f32x16 UPE[2];
             dense<P, 8, 9, C7, false>(ws, X, 0,
@@ -172,9 +172,9 @@ __global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(Sdf
                 });
             pe_backward(UPE);
         }
-        dense<P, 7, 8, C8, false>(ws, Y, 0, loadS(2), mulInto(X, 2), est_v);   // W3^T
-        dense<P, 8, 8, C8, false>(ws, X, 0, loadS(1), mulInto(Y, 1), est_v);   // W2^T
-        dense<P, 8, 8, C8, false>(ws, Y, 0, loadS(0), mulInto(X, 0), est_v);   // W1^T
+        dense<P, 7, 8, C8, false>(ws, Y, 0, loadS(2), mulInto(X, 2), est_v, 4);   // W3^T
+        dense<P, 8, 8, C8, false>(ws, X, 0, loadS(1), mulInto(Y, 1), est_v, 4);   // W2^T
+        dense<P, 8, 8, C8, false>(ws, Y, 0, loadS(0), mulInto(X, 0), est_v, 4);   // W1^T
         f32x16 U0[2];
         dense<P, 8, 2, 0, false>(ws, X, 0, NoPre{}, [&](int nt, const f32x16& acc, int) VDN_INL { U0[nt] = acc; });   // W0^T
         pe_backward(U0);

@@ -71,6 +71,7 @@ struct WStream {
             case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
             case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
             case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
             default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
         }
         __builtin_amdgcn_s_barrier();
@@ -254,10 +255,12 @@ struct BF16 {
 // then epi(nt, acc, aux) with aux = pre(nt) evaluated right after the chunk is acquired (so its
 // loads overlap the MFMA loop). NEXT_BYTES = size of the chunk that follows this layer's last chunk
 // in the stream (0 at the end of the stream).
-// epi_stores = vector-memory store instructions every in-range wave issues in epi() per tile (0, 4, 8 or 12;
-// a lower bound is safe, 0 drains the queue at every step).
+// epi_stores = vector-memory store instructions every in-range wave issues in epi() per tile, pre_loads = load
+// instructions in pre() per tile (their sum must be 0, 4, 8, 12 or 16; a lower bound is safe, 0 drains the queue
+// at every step). Both are younger than the glds of the chunk being acquired, so they may stay in flight across
+// the barrier: the prefetched loads then have two chunk steps to land.
 template <class P, int KT, int NT, int NEXT_BYTES, bool BIAS, class WS, class ActT, class Pre, class Epi>
-VDN_DEV void dense(WS& ws, const ActT& X, int x0, Pre&& pre, Epi&& epi, int epi_stores = 0) {
+VDN_DEV void dense(WS& ws, const ActT& X, int x0, Pre&& pre, Epi&& epi, int epi_stores = 0, int pre_loads = 0) {
     const int lane = ws.lane;
     // pre(nt) (HBM loads feeding tile nt's epilogue) is issued one chunk step ahead of its use, so a full
     // step of MFMA + epilogue work hides its latency; tile 0's is issued before the layer's first barrier.
@@ -265,7 +268,7 @@ VDN_DEV void dense(WS& ws, const ActT& X, int x0, Pre&& pre, Epi&& epi, int epi_
     static_for<NT>([&](auto nt_c) VDN_INL {
         constexpr int nt = decltype(nt_c)::value;
         // tile 0 follows another layer's epilogue (unknown store count): full drain there
-        const int yg = nt == 0 ? 0 : epi_stores;
+        const int yg = nt == 0 ? 0 : epi_stores + pre_loads;
         const char* w = (nt + 1 < NT) ? ws.template acquire<P::chunk_bytes(KT)>(yg)
                                       : ws.template acquire<NEXT_BYTES>(yg);
         auto aux_next = aux;

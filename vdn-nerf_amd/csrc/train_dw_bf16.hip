@@ -7,7 +7,7 @@
 // feature. Loader: one wave-instruction reads 1 KiB contiguous = half a (block, tile): lane (q2, hh, cpair) gets
 // 2 points x 4 features; the same lane position in 4 consecutive blocks gives 8 points x 4 features, which a
 // 16-bit interleave turns into four ready MFMA fragments (k order = (block, point) - identical for A and B, so
-// the contraction is unchanged). Fragments go to LDS as [k-group(16)][feature(128)][16 B]; k-group = cpair.
+// the contraction is unchanged). Fragments go to LDS as [k-group(16)][feature(128)][16 B] (+16 B pad per group); k-group = cpair.
 // Workgroup = 4 waves = 128 x 128 outputs (wave: 2 x 2 tiles of 32 x 32); stage = 128 points = 8 k-steps; the
 // next stage's global loads are in flight (registers) while the current stage is multiplied out of LDS.
 // K is split across workgroups; partial slabs are reduced by vdn_dw_finalize (train_dw_f32.hip), deterministically.
@@ -17,7 +17,10 @@
 namespace vdn {
 
 constexpr int kDwStagePts = 128;
-constexpr int kDwPanelBytes = 16 * 128 * 16;    // one operand: [16 k-groups][128 features][8 x bf16]
+// one operand: [16 k-groups][128 features][8 x bf16]; each k-group is padded by one 16-byte slot: a ds_write_b128 is
+// served in groups of 8 lanes = 8 consecutive k-groups, which at a 2 KiB stride would all hit the same banks
+constexpr int kDwGroupBytes = 128 * 16 + 16;
+constexpr int kDwPanelBytes = 16 * kDwGroupBytes;
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void dw_gemm_bf16_kernel(const DwDesc* desc
                     f3[b] = (v[1] >> 16) | (v[3] & 0xFFFF0000u);
                 }
                 const int fl = ((wave & 1) * 2 + tl) * 32 + (2 * Q + q2) * 8 + hh * 4;     // panel-local feature of e = 0
-                char* dst = panel + (cpair * 128 + fl) * 16;
+                char* dst = panel + cpair * kDwGroupBytes + fl * 16;
                 *reinterpret_cast<u32x4*>(dst) = f0;
                 *reinterpret_cast<u32x4*>(dst + 16) = f1;
                 *reinterpret_cast<u32x4*>(dst + 32) = f2;
@@ -129,8 +132,8 @@ __global__ __launch_bounds__(256, 2) void dw_gemm_bf16_kernel(const DwDesc* desc
         const char* pb = smem + kDwPanelBytes;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            const int offa = ((2 * ks + h) * 128 + wm * 64 + c) * 16;
-            const int offb = ((2 * ks + h) * 128 + wn * 64 + c) * 16;
+            const int offa = (2 * ks + h) * kDwGroupBytes + (wm * 64 + c) * 16;
+            const int offb = (2 * ks + h) * kDwGroupBytes + (wn * 64 + c) * 16;
             const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(pa + offa);
             const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(pa + offa + 32 * 16);
             const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(pb + offb);
