@@ -9,10 +9,10 @@ namespace vdn {
 template <class P, bool DPT>
 __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void nerf_bwd_kernel(NerfBwdArgs a) {
     using ST = typename P::store_t;
-    constexpr int kSlot = P::chunk_bytes(9);
+    constexpr int kSlot = P::stride(9);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     WStream<P::kWaves, kSlot> ws;
-    ws.init(a.blob, smem);
+    ws.init(a.blob, smem, 80);
     const int lane = ws.lane, c = lane & 31, h = lane >> 5;
     const long p_raw = ((long)blockIdx.x * P::kWaves + ws.wave) * 32 + c;
     const bool ok = p_raw < a.P;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void nerf_bwd_ke
         };
     };
     ws.all_issue = __any(ok);
-    ws.template start<CO>();
+    ws.start();
     // Wout^T: -> d hv (128), masked by the views layer's ReLU
     dense<P, KO, 4, C4, false>(ws, X, 0, [&](int nt) VDN_INL { return P::load_tile(save_hv, p, 128, nt, h); },
                                mask_store(Y, delta_v, 128), 4);
@@ -102,7 +102,7 @@ int launch_nerf_bwd(const VdnNerfBwdArgs* args, void* stream_) {
         !args->delta_o || !args->delta_v || !args->delta_head || !args->delta_h) return -1;
     const int ppw = P::kWaves * 32;
     const int grid = (args->P + ppw - 1) / ppw;
-    const size_t lds = 2 * P::chunk_bytes(9);
+    const size_t lds = 3 * P::stride(9);
     static bool once = (allow_big_lds(nerf_bwd_kernel<P, false>, lds), allow_big_lds(nerf_bwd_kernel<P, true>, lds), true);
     (void)once;
     if (args->g_feat != nullptr)

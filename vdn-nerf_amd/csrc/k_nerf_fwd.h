@@ -12,10 +12,10 @@ namespace vdn {
 template <class P, bool DPT>
 __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void nerf_fwd_kernel(NerfArgs a) {
     using ST = typename P::store_t;
-    constexpr int kSlot = P::chunk_bytes(11);
+    constexpr int kSlot = P::stride(11);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     WStream<P::kWaves, kSlot> ws;
-    ws.init(a.blob, smem);
+    ws.init(a.blob, smem, 64 + 9 + 4 + (DPT ? 4 : 1));
     const int lane = ws.lane, c = lane & 31, h = lane >> 5;
     const long p_raw = ((long)blockIdx.x * P::kWaves + ws.wave) * 32 + c;
     const bool ok = p_raw < a.P;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void nerf_fwd_ke
     const int est = save_h != nullptr ? 4 : 0;
     ws.all_issue = __any(ok);
     put_pe(true);
-    ws.template start<C3>();
+    ws.start();
     dense<P, 3, 8, C8, true>(ws, X, 0, NoPre{}, relu_into(Y, 0, sv(0), 256), est);          // pts_linears.0
     dense<P, 8, 8, C8, true>(ws, Y, 0, NoPre{}, relu_into(X, 0, sv(1), 256), est);          // 1
     dense<P, 8, 8, C8, true>(ws, X, 0, NoPre{}, relu_into(Y, 0, sv(2), 256), est);          // 2
@@ -123,7 +123,7 @@ int launch_nerf_fwd(const VdnNerfArgs* args, void* stream_) {
     if (!args->dirs && !args->rays_d) return -1;
     const int ppw = P::kWaves * 32;
     const int grid = (args->P + ppw - 1) / ppw;
-    const size_t lds = 2 * P::chunk_bytes(11);
+    const size_t lds = 3 * P::stride(11);
     static bool once = (allow_big_lds(nerf_fwd_kernel<P, false>, lds), allow_big_lds(nerf_fwd_kernel<P, true>, lds), true);
     (void)once;
     if (args->feat != nullptr)

@@ -11,10 +11,10 @@ namespace vdn {
 template <class P, int NT_OUT>
 __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_bwd_kernel(RenderNetBwdArgs a) {
     using ST = typename P::store_t;
-    constexpr int kSlot = P::chunk_bytes(8);
+    constexpr int kSlot = P::stride(8);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     WStream<P::kWaves, kSlot> ws;
-    ws.init(a.blob, smem);
+    ws.init(a.blob, smem, 42);
     const int lane = ws.lane, c = lane & 31, h = lane >> 5;
     const long p_raw = ((long)blockIdx.x * P::kWaves + ws.wave) * 32 + c;
     const bool ok = p_raw < a.P;
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_b
     };
     constexpr int C8 = P::chunk_bytes(8), CO = P::chunk_bytes(NT_OUT);
     ws.all_issue = __any(ok);
-    ws.template start<CO>();
+    ws.start();
     dense<P, NT_OUT, 8, C8, false>(ws, X, 0, ldH(3), mask_store(Y, 3), 4, 4);   // W4^T
     dense<P, 8, 8, C8, false>(ws, Y, 0, ldH(2), mask_store(X, 2), 4, 4);        // W3^T
     dense<P, 8, 8, C8, false>(ws, X, 0, ldH(1), mask_store(Y, 1), 4, 4);        // W2^T
@@ -102,7 +102,7 @@ int launch_rendernet_bwd(const VdnRenderNetBwdArgs* args, void* stream_) {
     if (!(args->d_out == 96 || (args->d_out >= 1 && args->d_out <= 4))) return -2;
     const int ppw = P::kWaves * 32;
     const int grid = (args->P + ppw - 1) / ppw;
-    const size_t lds = 2 * P::chunk_bytes(8);
+    const size_t lds = 3 * P::stride(8);
     static bool once = (allow_big_lds(rendernet_bwd_kernel<P, 1>, lds), allow_big_lds(rendernet_bwd_kernel<P, 3>, lds), true);
     (void)once;
     if (args->d_out == 96)

@@ -12,10 +12,10 @@ namespace vdn {
 template <class P, int NT_OUT>   // 1: d_out <= 4 (colour); 3: d_out = 96 (VDN head)
 __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_fwd_kernel(RenderNetArgs a) {
     using ST = typename P::store_t;
-    constexpr int kSlot = P::chunk_bytes(10);
+    constexpr int kSlot = P::stride(10);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     WStream<P::kWaves, kSlot> ws;
-    ws.init(a.blob, smem);
+    ws.init(a.blob, smem, 32 + NT_OUT);
     const int lane = ws.lane, c = lane & 31, h = lane >> 5;
     const long p_raw = ((long)blockIdx.x * P::kWaves + ws.wave) * 32 + c;
     const bool ok = p_raw < a.P;
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_f
     constexpr int C10 = P::chunk_bytes(10), C8 = P::chunk_bytes(8);
     const int est = save_h != nullptr ? 4 : 0;
     ws.all_issue = __any(ok);
-    ws.template start<C10>();
+    ws.start();
     dense<P, 10, 8, C8, true>(ws, X, 0, NoPre{}, relu_into(Y, 0), est);
     dense<P, 8, 8, C8, true>(ws, Y, 0, NoPre{}, relu_into(X, 1), est);
     dense<P, 8, 8, C8, true>(ws, X, 0, NoPre{}, relu_into(Y, 2), est);
@@ -91,7 +91,7 @@ int launch_rendernet_fwd(const VdnRenderNetArgs* args, void* stream_) {
     if (!(args->d_out == 96 || (args->d_out >= 1 && args->d_out <= 4))) return -2;
     const int ppw = P::kWaves * 32;
     const int grid = (args->P + ppw - 1) / ppw;
-    const size_t lds = 2 * P::chunk_bytes(10);
+    const size_t lds = 3 * P::stride(10);
     static bool once = (allow_big_lds(rendernet_fwd_kernel<P, 1>, lds), allow_big_lds(rendernet_fwd_kernel<P, 3>, lds), true);
     (void)once;
     if (args->d_out == 96)

@@ -20,10 +20,10 @@ namespace vdn {
 template <class P>
 __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_rbar_kernel(SdfRbarArgs a) {
     using ST = typename P::store_t;
-    constexpr int kSlot = P::chunk_bytes(9);
+    constexpr int kSlot = P::stride(9);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     WStream<P::kWaves, kSlot> ws;
-    ws.init(a.blob, smem);
+    ws.init(a.blob, smem, 63);        // hidden layers 0..7 of the forward stream
     const int lane = ws.lane, c = lane & 31, h = lane >> 5;
     const long p_raw = ((long)blockIdx.x * P::kWaves + ws.wave) * 32 + c;
     const bool ok = p_raw < a.P;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_rbar_ke
     };
     constexpr int C2 = P::chunk_bytes(2), C8 = P::chunk_bytes(8), C9 = P::chunk_bytes(9);
     ws.all_issue = __any(ok);
-    ws.template start<C2>();
+    ws.start();
     dense<P, 2, 8, C8, false>(ws, X, 0, ldSV(0), epi(Y, ub1, 256, 0), 8, 8);
     dense<P, 8, 8, C8, false>(ws, Y, 0, ldSV(1), epi(X, ub2, 256, 1), 8, 8);
     dense<P, 8, 8, C8, false>(ws, X, 0, ldSV(2), epi(Y, ub3, 256, 2), 8, 8);
@@ -127,10 +127,10 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_rbar_ke
 template <class P>
 __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_fbar_kernel(SdfFbarArgs a) {
     using ST = typename P::store_t;
-    constexpr int kSlot = P::chunk_bytes(9);
+    constexpr int kSlot = P::stride(9);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     WStream<P::kWaves, kSlot> ws;
-    ws.init(a.blob, smem);
+    ws.init(a.blob, smem, 65);
     const int lane = ws.lane, c = lane & 31, h = lane >> 5;
     const long p_raw = ((long)blockIdx.x * P::kWaves + ws.wave) * 32 + c;
     const bool ok = p_raw < a.P;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_fbar_ke
     };
     constexpr int C7 = P::chunk_bytes(7), C8 = P::chunk_bytes(8), C9 = P::chunk_bytes(9);
     ws.all_issue = __any(ok);
-    ws.template start<C9>();
+    ws.start();
     dense<P, 9, 8, C8, false>(ws, X, 0, ldSE(7), epi(Y, 7), 4, 8);     // W8^T
     dense<P, 8, 8, C8, false>(ws, Y, 0, ldSE(6), epi(X, 6), 4, 8);     // W7^T
     dense<P, 8, 8, C8, false>(ws, X, 0, ldSE(5), epi(Y, 5), 4, 8);     // W6^T
@@ -217,7 +217,7 @@ int launch_sdf_rbar(const VdnSdfRbarArgs* args, void* stream_) {
     if (!args || args->P <= 0 || !args->blob || !args->g_normals || !args->S || !args->V || !args->UB || !args->EX) return -1;
     if (!args->pts && (!args->rays_o || !args->rays_d || !args->z || args->n_per_ray <= 0 || args->z_ld < args->n_per_ray)) return -2;
     const int ppw = P::kWaves * 32;
-    const size_t lds = 2 * P::chunk_bytes(9);
+    const size_t lds = 3 * P::stride(9);
     static bool once = (allow_big_lds(sdf_rbar_kernel<P>, lds), true);
     (void)once;
     hipLaunchKernelGGL((sdf_rbar_kernel<P>), dim3((args->P + ppw - 1) / ppw), dim3(P::kWaves * 64), lds, stream, *args);
@@ -229,7 +229,7 @@ int launch_sdf_fbar(const VdnSdfFbarArgs* args, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!args || args->P <= 0 || !args->blob || !args->g_sdf || !args->g_feat || !args->S || !args->EX || !args->AB) return -1;
     const int ppw = P::kWaves * 32;
-    const size_t lds = 2 * P::chunk_bytes(9);
+    const size_t lds = 3 * P::stride(9);
     static bool once = (allow_big_lds(sdf_fbar_kernel<P>, lds), true);
     (void)once;
     hipLaunchKernelGGL((sdf_fbar_kernel<P>), dim3((args->P + ppw - 1) / ppw), dim3(P::kWaves * 64), lds, stream, *args);

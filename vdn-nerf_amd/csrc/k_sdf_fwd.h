@@ -14,10 +14,10 @@ namespace vdn {
 template <class P, int MODE, int NW>
 __global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(SdfArgs a) {
     using ST = typename P::store_t;
-    constexpr int kSlot = P::chunk_bytes(9);
+    constexpr int kSlot = P::stride(9);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     WStream<NW, kSlot> ws;
-    ws.init(a.blob, smem);
+    ws.init(a.blob, smem, MODE == 0 ? 64 : 131);       // chunks in the 'sdf' / 'full' stream
     const int lane = ws.lane, c = lane & 31, h = lane >> 5;
     const long p_raw = ((long)blockIdx.x * NW + ws.wave) * 32 + c;
     const bool ok = p_raw < a.P;
@@ -68,7 +68,11 @@ __global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(Sdf
                     hv[t] = a_;
                     sv[t] = b_;
                 } else {
+#if defined(VDN_ABLATE) && VDN_ABLATE == 1
+                    hv[t] = acc[t];
+#else
                     hv[t] = softplus100_fast(acc[t]);
+#endif
                 }
             }
             D.set(nt, hv);
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(Sdf
     const int est_h = SV ? (Hs != nullptr ? 8 : 4) : 0;     // stores per hidden-layer tile (S, and H when training)
     const int est_v = Vs != nullptr ? 4 : 0;                // stores per sweep tile (V when training)
     put_pe(0);
-    ws.template start<C2>();
+    ws.start();
     dense<P, 2, 8, C8, true>(ws, X, 0, NoPre{}, hidden(Y, 0), est_h);
     dense<P, 8, 8, C8, true>(ws, Y, 0, NoPre{}, hidden(X, 1), est_h);
     dense<P, 8, 8, C8, true>(ws, X, 0, NoPre{}, hidden(Y, 2), est_h);
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(Sdf
 
 template <class P, int MODE, int NW>
 void launch_sdf_nw(const VdnSdfArgs* args, hipStream_t stream) {
-    const size_t lds = 2 * P::chunk_bytes(9);
+    const size_t lds = 3 * P::stride(9);
     static bool once = (allow_big_lds(sdf_fwd_kernel<P, MODE, NW>, lds), true);
     (void)once;
     const int grid = (args->P + NW * 32 - 1) / (NW * 32);

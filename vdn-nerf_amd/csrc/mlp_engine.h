@@ -12,9 +12,9 @@
 //          k order in which a 32x32 accumulator tile converts to B fragments with no lane movement;
 //          HBM activations stored as bf16.
 //
-// Chunks of one kernel lie in global memory in the exact order the kernel consumes them, so weight
-// streaming is one linear walk: each chunk is fetched with global_load_lds (1 KiB per
-// wave-instruction) into one of two LDS slots while the previous chunk is being multiplied.
+// Chunks of one kernel lie in global memory in the exact order the kernel consumes them, at a uniform stride, so
+// weight streaming is one linear walk: each chunk is fetched with global_load_lds (1 KiB per wave-instruction)
+// into a ring of LDS slots, two chunk steps ahead of its use (WStream).
 #pragma once
 #include "vdn_common.h"
 
@@ -29,56 +29,75 @@ VDN_DEV unsigned pack_bf16x2(float a, float b) {
 VDN_DEV float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
 VDN_DEV float bf16_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
 
-template <int NWAVES, int SLOT_BYTES>
+// Weight stream: a ring of NSLOT LDS slots, each chunk fetched DEPTH = NSLOT-1 chunk steps before it is used
+// (measured: with a depth of 1 every step waited ~0.9 us for its chunk - the L2 -> LDS latency - which put a
+// 58 us floor under a 63-step forward chain whose MFMAs take 31 us). All chunks of a stream sit at one uniform
+// stride STRIDE (a multiple of NWAVES KiB, >= the largest chunk), so every wave issues exactly G = STRIDE/1024/NWAVES
+// global_load_lds instructions per chunk and the number of younger in-flight loads is known without tables.
+template <int NWAVES, int STRIDE, int NSLOT = 3>
 struct WStream {
+    static_assert(STRIDE % (1024 * NWAVES) == 0, "chunk stride must be a multiple of NWAVES KiB");
+    static constexpr int DEPTH = NSLOT - 1;
+    static constexpr int G = STRIDE / 1024 / NWAVES;
     const char* g;   // global cursor: first byte of the next chunk to fetch
-    char* lds;       // base of the two slots
-    int slot;        // slot holding the current chunk
+    char* lds;       // base of the ring
+    int cur;         // index of the chunk being consumed
+    int issued;      // chunks issued so far
+    int total;       // chunks in the stream
     int wave, lane;
     bool all_issue;  // set by the kernel: this wave has at least one in-range lane (so it issues every store)
 
-    VDN_DEV void init(const char* blob, char* smem) {
+    VDN_DEV void init(const char* blob, char* smem, int total_chunks) {
         g = blob;
         lds = smem;
-        slot = 1;
+        cur = -1;
+        issued = 0;
+        total = total_chunks;
         wave = threadIdx.x >> 6;
         lane = threadIdx.x & 63;
         all_issue = false;
     }
-    template <int BYTES>
-    VDN_DEV void issue(int s) {
-        static_assert(BYTES % 1024 == 0 && BYTES <= SLOT_BYTES, "chunk size");
-        constexpr int pieces = BYTES / 1024;
+    VDN_DEV void issue_next() {
+        char* dst = lds + (issued % NSLOT) * STRIDE;
 #pragma unroll
-        for (int i = 0; i < (pieces + NWAVES - 1) / NWAVES; ++i) {
+        for (int i = 0; i < G; ++i) {
             const int piece = wave + i * NWAVES;
-            if (piece < pieces) glds16(g + piece * 1024 + lane * 16, lds + s * SLOT_BYTES + piece * 1024);
+            glds16(g + piece * 1024 + lane * 16, dst + piece * 1024);
         }
-        g += BYTES;
+        g += STRIDE;
+        ++issued;
     }
-    template <int FIRST_BYTES>
-    VDN_DEV void start() { issue<FIRST_BYTES>(0); }
-    // Make the chunk issued last current (all waves), then start fetching the next one.
-    // YOUNGER = number of vector-memory instructions this wave has issued AFTER the glds of the chunk being
-    // acquired and that may still be in flight (the previous tile's epilogue stores). vmcnt counts loads,
-    // stores and LDS-DMA together in issue order, so vmcnt(YOUNGER) retires the chunk without draining those
-    // stores (draining them exposes a full HBM store latency at every chunk step). `all_issue` (member) must be
-    // false for a wave whose lanes are all out of range (it skips its stores, so only vmcnt(0) is safe for it).
-    template <int NEXT_BYTES>
+    VDN_DEV void start() {
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i)
+            if (issued < total) issue_next();
+    }
+    // Make the next chunk current (all waves), then start fetching the chunk DEPTH steps ahead.
+    // `younger` = vector-memory instructions this wave issued during the previous step that may stay in flight
+    // (epilogue stores + prefetched epilogue loads); the glds of the chunks still ahead are added here. vmcnt
+    // counts loads, stores and LDS-DMA together in issue order, so vmcnt(N) retires this chunk without draining
+    // them. `all_issue` must be false for a wave whose lanes are all out of range (it skips its stores).
     VDN_DEV const char* acquire(int younger = 0) {
+        ++cur;
         if (!all_issue) younger = 0;
-        switch (younger) {                       // wave-uniform
-            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-            case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-            case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        }
+        const int ahead = min(issued - cur - 1, DEPTH - 1);      // chunks after `cur` already in flight
+        wait_vm(younger + ahead * G);
+#if !defined(VDN_ABLATE) || VDN_ABLATE != 3
         __builtin_amdgcn_s_barrier();
+#endif
         asm volatile("" ::: "memory");
-        slot ^= 1;
-        if constexpr (NEXT_BYTES > 0) issue<NEXT_BYTES>(slot ^ 1);
-        return lds + slot * SLOT_BYTES;
+        if (issued < total) issue_next();
+        return lds + (cur % NSLOT) * STRIDE;
+    }
+    static VDN_DEV void wait_vm(int n) {   // wave-uniform n; s_waitcnt takes an immediate
+        switch (n) {
+#define VDN_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+            VDN_W(1) VDN_W(2) VDN_W(3) VDN_W(4) VDN_W(5) VDN_W(6) VDN_W(7) VDN_W(8) VDN_W(9) VDN_W(10) VDN_W(11) VDN_W(12)
+            VDN_W(13) VDN_W(14) VDN_W(15) VDN_W(16) VDN_W(17) VDN_W(18) VDN_W(19) VDN_W(20) VDN_W(21) VDN_W(22) VDN_W(23) VDN_W(24)
+            VDN_W(25) VDN_W(26) VDN_W(27) VDN_W(28) VDN_W(29) VDN_W(30) VDN_W(31) VDN_W(32)
+#undef VDN_W
+            default: if (n > 32) { asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); } else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } break;
+        }
     }
 };
 
@@ -91,6 +110,7 @@ struct F32 {
     static constexpr int kWaves = 4;
     static constexpr int kMinWavesPerEU = 1;
     static constexpr int chunk_bytes(int KT) { return KT * 4096 + 1024; }
+    static constexpr int stride(int KTMAX) { return (chunk_bytes(KTMAX) + 4095) / 4096 * 4096; }   // uniform chunk stride
     using store_t = float;
 
     template <int NT>
@@ -173,6 +193,7 @@ struct BF16 {
     static constexpr int kWaves = 4;
     static constexpr int kMinWavesPerEU = 2;
     static constexpr int chunk_bytes(int KT) { return KT * 2048 + 1024; }
+    static constexpr int stride(int KTMAX) { return (chunk_bytes(KTMAX) + 4095) / 4096 * 4096; }   // uniform chunk stride
     using store_t = unsigned short;   // bf16 bits
 
     template <int NT>
@@ -215,6 +236,10 @@ struct BF16 {
 #pragma unroll
             for (int t = 0; t < 16; ++t) acc[t] = 0.0f;
         }
+#if defined(VDN_ABLATE) && VDN_ABLATE == 2
+        (void)wa;
+        return acc;
+#endif
         static_for<KT * 2>([&](auto s_c) VDN_INL {
             constexpr int s = decltype(s_c)::value;
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[s * 64], X.r[x0 * 2 + s], acc, 0, 0, 0);
@@ -267,10 +292,9 @@ VDN_DEV void dense(WS& ws, const ActT& X, int x0, Pre&& pre, Epi&& epi, int epi_
     auto aux = pre(0);
     static_for<NT>([&](auto nt_c) VDN_INL {
         constexpr int nt = decltype(nt_c)::value;
-        // tile 0 follows another layer's epilogue (unknown store count): full drain there
+        // tile 0 follows another layer's epilogue (unknown store count): only the chunks ahead stay in flight
         const int yg = nt == 0 ? 0 : epi_stores + pre_loads;
-        const char* w = (nt + 1 < NT) ? ws.template acquire<P::chunk_bytes(KT)>(yg)
-                                      : ws.template acquire<NEXT_BYTES>(yg);
+        const char* w = ws.acquire(yg);
         auto aux_next = aux;
         if constexpr (nt + 1 < NT) aux_next = pre(nt + 1);
         const f32x16 acc = P::template mma<KT, BIAS>(w, X, x0, lane);

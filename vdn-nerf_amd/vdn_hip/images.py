@@ -21,6 +21,16 @@ def chunk_bytes(kt, fmt=FMT_F32):
     return kt * 4096 + 1024 if fmt == FMT_F32 else kt * 2048 + 1024
 
 
+def chunk_stride(kt_max, fmt=FMT_F32):
+    """Uniform distance between consecutive chunks of a stream (csrc/mlp_engine.h: P::stride): the largest
+    chunk rounded up to 4 KiB, so that every wave issues the same number of 1-KiB global_load_lds per chunk."""
+    return (chunk_bytes(kt_max, fmt) + 4095) // 4096 * 4096
+
+
+# largest contraction width (in 32-wide tiles) each kernel's stream is laid out for (must match the kernels)
+STREAM_KT_MAX = {"sdf": 9, "full": 9, "fbar": 9}
+
+
 def _pad32(n):
     return (n + 31) // 32 * 32
 
@@ -109,7 +119,10 @@ class NetImages:
         for sname, layers in streams.items():
             if sname.startswith("_"):
                 continue
-            total = sum(chunk_bytes(L.kt, fmt) * len(L.chunks) for L in layers)
+            kt_max = max(L.kt for L in layers)
+            kt_max = max(kt_max, STREAM_KT_MAX.get(sname, 0))
+            stride = chunk_stride(kt_max, fmt)
+            total = stride * sum(len(L.chunks) for L in layers)
             self.blobs[sname] = torch.zeros(total, dtype=torch.uint8, device=device)
             off = 0
             for L in layers:
@@ -123,7 +136,7 @@ class NetImages:
                         maps.append(np.asarray(rowmap, np.int32))
                         map_off += 32
                         chunk_rows.append((sname, off, mname, use_bias, k_off + 32 * kt0, n_off, L, kt0, ktc, pi == 0))
-                    off += chunk_bytes(L.kt, fmt)
+                    off += stride
         self.maps = torch.from_numpy(np.concatenate(maps)).to(device)
         self._chunk_rows = chunk_rows
         self._tables_key = None
