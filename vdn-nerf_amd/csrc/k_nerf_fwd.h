@@ -48,7 +48,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void nerf_fwd_ke
     typename P::template Act<9> Y;
     auto put_pe = [&](bool save) VDN_INL {
         float pe[84];
-        posenc<4, 10>(p4, pe);
+        posenc<4, 10, P::kAccurateTrig>(p4, pe);
 #pragma unroll
         for (int kt = 0; kt < 3; ++kt) {
             const f32x16 t16 = vals_tile<84>(pe, h, kt);
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void nerf_fwd_ke
     });
     {   // views_linears.0 on cat([feature, PE4(view)])  (fields.py:340-344)
         float pe[27];
-        posenc<3, 4>(dir, pe);
+        posenc<3, 4, P::kAccurateTrig>(dir, pe);
         const f32x16 t16 = vals_tile<27>(pe, h, 0);
         X.set(8, t16);
         if (a.save_vpe != nullptr) P::store_tile(reinterpret_cast<ST*>(a.save_vpe), p, 32, 0, h, t16, ok);

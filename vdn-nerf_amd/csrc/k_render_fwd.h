@@ -41,7 +41,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_f
             small[30 + d] = a.normals[p * 3 + d];
         }
         float pe[27];
-        posenc<3, 4>(dir, pe);
+        posenc<3, 4, P::kAccurateTrig>(dir, pe);
 #pragma unroll
         for (int i = 0; i < 27; ++i) small[3 + i] = pe[i];
 #pragma unroll

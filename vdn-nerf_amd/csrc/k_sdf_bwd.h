@@ -58,7 +58,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_rbar_ke
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
                 float sn, co;
-                sincosf(xin[d] * f, &sn, &co);
+                sincos_pe<P::kAccurateTrig>(xin[d] * f, sn, co);
                 ub39[3 + 6 * k + d] = f * co * gn[d];
                 ub39[3 + 6 * k + 3 + d] = -f * sn * gn[d];
             }

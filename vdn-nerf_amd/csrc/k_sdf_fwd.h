@@ -46,7 +46,7 @@ __global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(Sdf
     typename P::template Act<9> X, Y;
     auto put_pe = [&](int tile0) VDN_INL {
         float pe[39];
-        posenc<3, 6>(xin, pe);
+        posenc<3, 6, P::kAccurateTrig>(xin, pe);
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
             const f32x16 t16 = vals_tile<39>(pe, h, kt);
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(Sdf
 #pragma unroll
                 for (int d = 0; d < 3; ++d) {
                     float sn, co;
-                    sincosf(xin[d] * f, &sn, &co);
+                    sincos_pe<P::kAccurateTrig>(xin[d] * f, sn, co);
                     n[d] += f * (co * u[3 + 6 * k + d] - sn * u[3 + 6 * k + 3 + d]);
                 }
             }

@@ -109,6 +109,7 @@ struct NoPre {
 struct F32 {
     static constexpr int kWaves = 4;
     static constexpr int kMinWavesPerEU = 1;
+    static constexpr bool kAccurateTrig = true;     // ocml sincosf in the positional encoding
     static constexpr int chunk_bytes(int KT) { return KT * 4096 + 1024; }
     static constexpr int stride(int KTMAX) { return (chunk_bytes(KTMAX) + 4095) / 4096 * 4096; }   // uniform chunk stride
     using store_t = float;
@@ -192,6 +193,7 @@ struct BF16 {
     // chunk barriers independently, so one computes while the other waits on memory
     static constexpr int kWaves = 4;
     static constexpr int kMinWavesPerEU = 2;
+    static constexpr bool kAccurateTrig = false;    // hardware v_sin / v_cos (see vdn_common.h: sincos_pe)
     static constexpr int chunk_bytes(int KT) { return KT * 2048 + 1024; }
     static constexpr int stride(int KTMAX) { return (chunk_bytes(KTMAX) + 4095) / 4096 * 4096; }   // uniform chunk stride
     using store_t = unsigned short;   // bf16 bits
@@ -240,10 +242,27 @@ struct BF16 {
         (void)wa;
         return acc;
 #endif
-        static_for<KT * 2>([&](auto s_c) VDN_INL {
+        // Fragment reads are software-pipelined PRE deep under the MFMAs. Left to itself hipcc emits
+        // {2 x ds_read_b128, s_waitcnt lgkmcnt(0), 2 x MFMA} x 8 per tile - a full LDS round trip exposed eight
+        // times (measured ~1700 cycles per tile for 512 cycles of MFMA) - so the order is pinned with
+        // sched_group_barrier: PRE reads up front, then one read per MFMA, then the last PRE MFMAs.
+        constexpr int NS = KT * 2;
+        constexpr int PRE = NS < 6 ? NS : 6;
+        bf16x8 fr[NS];
+        static_for<NS>([&](auto s_c) VDN_INL {
             constexpr int s = decltype(s_c)::value;
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[s * 64], X.r[x0 * 2 + s], acc, 0, 0, 0);
+            fr[s] = wa[s * 64];
         });
+        static_for<NS>([&](auto s_c) VDN_INL {
+            constexpr int s = decltype(s_c)::value;
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[s], X.r[x0 * 2 + s], acc, 0, 0, 0);
+        });
+        __builtin_amdgcn_sched_group_barrier(0x100, PRE + (BIAS ? 2 : 0), 0);      // DS reads (bias rows + first fragments)
+        static_for<NS - PRE>([&](auto) VDN_INL {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                      // 1 DS read
+        });
+        __builtin_amdgcn_sched_group_barrier(0x008, PRE, 0);
         return acc;
     }
 

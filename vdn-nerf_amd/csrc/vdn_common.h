@@ -121,9 +121,24 @@ VDN_DEV void tiles_to_vals(const float* X, int h, float (&vals)[NF]) {
     }
 }
 
+// sin/cos for the positional encoding. ACCURATE: ocml sincosf (full range reduction; the fp32 parity path).
+// Otherwise the hardware v_sin_f32 / v_cos_f32 (argument in revolutions, |x| <= 256 rev): ~3e-6 abs error for the
+// SDF's octaves and ~3e-5 at 2^9 x (NeRF), far below the bf16 rounding the encoded value then receives - and ~100x
+// fewer VALU instructions, which matters because the bf16 kernels are VALU-issue-bound.
+template <bool ACCURATE>
+VDN_DEV void sincos_pe(float x, float& s, float& c) {
+    if constexpr (ACCURATE) {
+        sincosf(x, &s, &c);
+    } else {
+        const float r = x * 0.15915494309189535f;
+        s = __builtin_amdgcn_sinf(r);
+        c = __builtin_amdgcn_cosf(r);
+    }
+}
+
 // Positional encoding of a D-vector with L log-spaced octaves, reference order
 // [x, sin(2^0 x), cos(2^0 x), sin(2^1 x), ...] (embedder.py:27-36).
-template <int D, int L>
+template <int D, int L, bool ACCURATE = true>
 VDN_DEV void posenc(const float (&v)[D], float (&pe)[D * (1 + 2 * L)]) {
 #pragma unroll
     for (int d = 0; d < D; ++d) pe[d] = v[d];
@@ -133,7 +148,7 @@ VDN_DEV void posenc(const float (&v)[D], float (&pe)[D * (1 + 2 * L)]) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             float s, c;
-            sincosf(v[d] * f, &s, &c);
+            sincos_pe<ACCURATE>(v[d] * f, s, c);
             pe[D + 2 * D * k + d] = s;
             pe[D + 2 * D * k + D + d] = c;
         }
