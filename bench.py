@@ -169,6 +169,12 @@ def main():
             tk = time_kernel(lambda: rend.sdf_network._run(1, rays=(o, d, mid)))
         flops = (F_SDF + F_GRAD) * mid.numel()
         dtype = "f32" if args.precision == "fp32" else "bf16"
+        # HBM bytes per launch of that kernel from the L2 memory-side PMC counters (FETCH_SIZE / WRITE_SIZE in separate
+        # rocprofv3 --pmc passes, gfx950 x2 correction on FETCH_SIZE): collected by tools/collect_traffic.sh, not live
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r01_traffic_sdf_fwd_%s.json" % args.precision)
+        if os.path.exists(tf):
+            traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
         line = {
             "metric": "rays/sec (512-ray batch, 128 samples/ray)", "value": value, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -182,7 +188,7 @@ def main():
             "forward_only_rays_per_s": fwd_rays_per_s, "final_loss": loss_final,
             "roofline": {"bound": "mfma", "kernel": "sdf_fwd_kernel<%s,1> (fused PE + SDF MLP + gradient sweep, 65536 points)" % ("F32" if dtype == "f32" else "BF16"),
                          "achieved": flops / tk / 1e12, "peak": PEAK[dtype] / 1e12, "unit": "TFLOP/s",
-                         "frac": flops / tk / PEAK[dtype], "traffic": None, "kernel_ms": tk * 1e3},
+                         "frac": flops / tk / PEAK[dtype], "traffic": traffic, "kernel_ms": tk * 1e3},
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(B, seed)
