@@ -396,6 +396,24 @@ int vdn_loss_fwd_bwd(const VdnLossArgs* args_host, void* stream);
 int vdn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   float lr, float beta1, float beta2, float eps, int32_t step, void* stream);
 
+/* ---- on-device ray generator: poses.py:168-212 (fixed poses / intrinsics) + dataset.py:111-118 --------------
+ * p = K^-1 [x,y,1]; v = p/|p|; rays_d = R v; rays_o = t; colour / mask / feature gathered from images resident in HBM;
+ * near/far from the unit sphere. out row = [rays_o(3) rays_d(3) mask(1) rgb(3) feats(C)] exactly as gen_random_rays_at. */
+typedef struct {
+    const float* pixels_x;     /* [B] pixel coordinates (already integral-valued for random rays) */
+    const float* pixels_y;     /* [B] */
+    const float* intrinsic_inv;/* [3,3] row-major (upper-left of the 4x4) */
+    const float* pose;         /* [3,4] row-major c2w (upper 3 rows of the 4x4) */
+    const float* image;        /* [H,W,3] or NULL */
+    const float* mask;         /* [H,W,mask_ch] or NULL (then mask = 1) */
+    const float* feats;        /* [H,W,C] or NULL */
+    float* out;                /* [B, out_ld] */
+    float* near;               /* [B] or NULL */
+    float* far;                /* [B] or NULL */
+    int32_t B, H, W, C, mask_ch, out_ld;
+} VdnGenRaysArgs;
+int vdn_gen_rays(const VdnGenRaysArgs* args_host, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -212,3 +212,41 @@ def test_determinism(env, dev, golden):
     b = _render(rend, fx, dev, inject=False)
     for k in ("color_fine", "weights", "gradients"):
         assert torch.equal(a[k], b[k]), k
+
+
+def test_on_device_ray_generator(dev):
+    """vdn_train.rays.RaysGenerator against the formulas of poses.py:168-212 / dataset.py:111-118 (numpy, float64)."""
+    from vdn_train import synth
+    from vdn_train.rays import RaysGenerator
+    rng = np.random.RandomState(3)
+    n, H, W, C = 3, 40, 56, 5
+    images, masks, feats = rng.rand(n, H, W, 3).astype(np.float32), (rng.rand(n, H, W, 3) > 0.3).astype(np.float32), rng.rand(n, H, W, C).astype(np.float32)
+    cams = synth.make_cameras(3, n=n)
+    K = np.eye(4)
+    K[:3, :3] = np.linalg.inv(synth.intrinsics_inv(focal=60.0, h=H, w=W))
+    gen = RaysGenerator(images, masks, cams, K, depth_feats=feats, device=dev)
+    px, py = rng.randint(0, W, 64).astype(np.float32), rng.randint(0, H, 64).astype(np.float32)
+    out, near, far = gen.gen_random_rays_at(1, 64, pixels=(px, py), return_near_far=True)
+    out = out.cpu().numpy()
+    assert out.shape == (64, 10 + C)
+    p = np.stack([px, py, np.ones_like(px)], -1).astype(np.float64) @ np.linalg.inv(K[:3, :3]).T
+    v = p / np.linalg.norm(p, axis=-1, keepdims=True)
+    d = v @ cams[1][:3, :3].T
+    assert np.abs(out[:, 3:6] - d).max() < 1e-5 and np.abs(out[:, 0:3] - cams[1][:3, 3]).max() < 1e-6
+    yi, xi = py.astype(int), px.astype(int)
+    assert np.array_equal(out[:, 7:10], images[1][yi, xi]) and np.array_equal(out[:, 6], masks[1][yi, xi, 0])
+    assert np.array_equal(out[:, 10:], feats[1][yi, xi])
+    o64 = np.broadcast_to(cams[1][:3, 3], d.shape)
+    mid = -(o64 * d).sum(-1) / (d * d).sum(-1)
+    assert np.abs(near.cpu().numpy()[:, 0] - (mid - 1)).max() < 1e-5 and np.abs(far.cpu().numpy()[:, 0] - (mid + 1)).max() < 1e-5
+    rnd = gen.gen_random_rays_at(0, 128)
+    assert rnd.shape == (128, 10 + C) and float(rnd[:, 3:6].norm(dim=-1).sub(1).abs().max()) < 1e-5
+    o, v = gen.gen_rays_at(2, resolution_level=2)
+    assert o.shape == (H // 2, W // 2, 3) and v.shape == (H // 2, W // 2, 3)
+    tx, ty = np.linspace(0, W - 1, W // 2), np.linspace(0, H - 1, H // 2)
+    pp = np.array([tx[5], ty[7], 1.0]) @ np.linalg.inv(K[:3, :3]).T
+    dd = (pp / np.linalg.norm(pp)) @ cams[2][:3, :3].T
+    assert np.abs(v[7, 5].cpu().numpy() - dd).max() < 1e-5
+    # a render fed by the generator runs end to end
+    rend_rays = gen.gen_random_rays_at(0, 8)
+    assert torch.isfinite(rend_rays).all()

@@ -408,9 +408,61 @@ __global__ void eikonal_reduce_kernel(const float* partial, int B, float* out3) 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// ray generation (poses.py:168-212, dataset.py:111-118): one thread per ray, images resident in HBM
+// ------------------------------------------------------------------------------------------
+__global__ void gen_rays_kernel(GenRaysArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.B) return;
+    const float x = a.pixels_x[i], y = a.pixels_y[i];
+    const float* K = a.intrinsic_inv;
+    float p[3], v[3], d[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) p[r] = K[r * 3 + 0] * x + K[r * 3 + 1] * y + K[r * 3 + 2];
+    const float nrm = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) v[r] = p[r] / nrm;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) d[r] = a.pose[r * 4 + 0] * v[0] + a.pose[r * 4 + 1] * v[1] + a.pose[r * 4 + 2] * v[2];
+    float* o = a.out + (long)i * a.out_ld;
+    float org[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        org[r] = a.pose[r * 4 + 3];
+        o[r] = org[r];
+        o[3 + r] = d[r];
+    }
+    const int xi = min(max((int)x, 0), a.W - 1), yi = min(max((int)y, 0), a.H - 1);
+    const long pix = (long)yi * a.W + xi;
+    if (a.out_ld > 6) o[6] = a.mask ? a.mask[pix * a.mask_ch] : 1.0f;
+    if (a.image != nullptr && a.out_ld >= 10) {
+        o[7] = a.image[pix * 3];
+        o[8] = a.image[pix * 3 + 1];
+        o[9] = a.image[pix * 3 + 2];
+    }
+    if (a.feats != nullptr)
+        for (int ch = 0; ch < a.C; ++ch) o[10 + ch] = a.feats[pix * a.C + ch];
+    if (a.near != nullptr && a.far != nullptr) {          // dataset.py:111-118
+        const float aa = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+        const float bb = 2.0f * (org[0] * d[0] + org[1] * d[1] + org[2] * d[2]);
+        const float mid = 0.5f * (-bb) / aa;
+        a.near[i] = mid - 1.0f;
+        a.far[i] = mid + 1.0f;
+    }
+}
+
 }  // namespace vdn
 
 using namespace vdn;
+
+extern "C" int vdn_gen_rays(const VdnGenRaysArgs* a, void* stream) {
+    if (!a || a->B <= 0 || !a->pixels_x || !a->pixels_y || !a->intrinsic_inv || !a->pose || !a->out) return -1;
+    if (a->out_ld < 6 || a->H <= 0 || a->W <= 0) return -2;
+    if (a->feats && (a->C <= 0 || a->out_ld < 10 + a->C)) return -3;
+    if (a->mask && a->mask_ch <= 0) return -4;
+    hipLaunchKernelGGL(gen_rays_kernel, dim3((a->B + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a);
+    return (int)hipGetLastError();
+}
 
 extern "C" int vdn_coarse_z(const VdnCoarseArgs* a, void* stream) {
     if (!a || a->B <= 0 || !a->near || !a->far || !a->z || !a->lin_samples) return -1;
