@@ -1,0 +1,54 @@
+"""Train the shipped womsk_white configuration on the synthetic 800x800 scene and report loss / PSNR over time
+(the 'PSNR' half of BASELINE.json's metric). Usage: train_psnr.py [steps] [precision]"""
+import os, sys, time, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "vdn-nerf_amd"))
+import numpy as np, torch
+from vdn_train import synth, factory
+from vdn_train.trainer import Trainer
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+prec = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+B, seed = 512, 0
+# geometric init exactly as the reference constructs it (fields.py:45-63); no synthetic perturbation
+rend = factory.build_renderer(device=dev, precision=prec)
+# shortened schedule so that a few thousand steps cover warm-up and annealing
+tr = Trainer(rend, B, dev, conf=dict(warm_up_end=200, end_iter=steps, anneal_end=max(steps // 4, 1)))
+cams = synth.make_cameras(seed)
+g = lambda x: torch.tensor(x).to(dev)
+# validation rays: a fixed 64x64 grid of one held-out view
+vx, vy = np.meshgrid(np.linspace(190, 610, 64), np.linspace(190, 610, 64))
+vo, vd = synth.pixel_rays(cams[7], vx.reshape(-1), vy.reshape(-1))
+vn, vf = synth.near_far_from_sphere(vo, vd)
+ALBEDO = 0.5
+CROP = 420            # train on the central window where the object covers most pixels (object-centric capture)
+vt = g(synth.target_colors(vo, vd, ALBEDO))
+
+def validate():
+    with torch.no_grad():
+        cols = []
+        for i in range(0, vo.shape[0], 512):
+            out = rend.render(g(vo[i:i + 512]), g(vd[i:i + 512]), g(vn[i:i + 512]), g(vf[i:i + 512]), perturb_overwrite=0,
+                              background_rgb=torch.ones(1, 3, device=dev), cos_anneal_ratio=tr.cos_anneal_ratio())
+            cols.append(out["color_fine"])
+        c = torch.cat(cols)
+        return (20.0 * torch.log10(1.0 / ((c - vt) ** 2).mean().sqrt())).item()
+
+log = []
+t0 = time.time()
+for it in range(steps):
+    img = int(synth.uniform(seed, "trainperm", (steps,))[it] * 40) % 40
+    if img == 7:
+        img = 8                                   # view 7 is held out
+    o, d = synth.random_pixel_batch(seed, it, img, B, cams=cams, crop=CROP)
+    near, far = synth.near_far_from_sphere(o, d)
+    sc = tr.train_step(g(o), g(d), g(near), g(far), g(synth.target_colors(o, d, ALBEDO)))
+    if it % max(steps // 10, 1) == 0 or it == steps - 1:
+        s = sc.cpu().numpy()
+        log.append(dict(step=it, loss=float(s[0]), train_psnr=float(s[2]), eikonal=float(s[3]), val_psnr=validate(),
+                        inv_s=float(torch.exp(rend.deviation_network.variance * 10).item()), wall_s=time.time() - t0))
+        print(json.dumps(log[-1]), flush=True)
+print(json.dumps({"precision": prec, "steps": steps, "final_val_psnr": log[-1]["val_psnr"], "final_train_psnr": log[-1]["train_psnr"],
+                  "wall_s": time.time() - t0}))

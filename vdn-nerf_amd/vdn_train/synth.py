@@ -204,12 +204,17 @@ def pixel_rays(c2w, px, py, focal=FOCAL):
     return o.astype(np.float32).copy(), d.astype(np.float32).copy()
 
 
-def random_pixel_batch(seed, step, img_idx, batch, rank=0, cams=None):
-    """512 pixels uniform over one image (poses.py:193-194), keyed by (seed, step, rank)."""
+def random_pixel_batch(seed, step, img_idx, batch, rank=0, cams=None, crop=None):
+    """512 pixels uniform over one image (poses.py:193-194), keyed by (seed, step, rank). `crop` = side of a centred
+    square window to draw from (object-centric captures: the object fills most of the frame)."""
     cams = make_cameras(seed) if cams is None else cams
     tag = "pix/%d/%d" % (step, rank)
-    px = np.floor(uniform(seed, tag + "/x", (batch,)) * W_IMG)
-    py = np.floor(uniform(seed, tag + "/y", (batch,)) * H)
+    if crop is None:
+        px = np.floor(uniform(seed, tag + "/x", (batch,)) * W_IMG)
+        py = np.floor(uniform(seed, tag + "/y", (batch,)) * H)
+    else:
+        px = np.floor(uniform(seed, tag + "/x", (batch,)) * crop) + (W_IMG - crop) // 2
+        py = np.floor(uniform(seed, tag + "/y", (batch,)) * crop) + (H - crop) // 2
     return pixel_rays(cams[img_idx], px, py)
 
 
@@ -221,8 +226,9 @@ def near_far_from_sphere(rays_o, rays_d):
     return (mid - 1.0).astype(np.float32), (mid + 1.0).astype(np.float32)
 
 
-def target_colors(rays_o, rays_d):
-    """Procedural ground truth for PSNR runs: sphere r=0.5 with a view-dependent tint on white."""
+def target_colors(rays_o, rays_d, albedo=1.0):
+    """Procedural ground truth for PSNR runs: sphere r=0.5 with a view-dependent tint on white. `albedo` < 1 darkens
+    the object (with the default bright object an empty white scene is a strong local minimum of the L1 loss)."""
     o = rays_o.astype(np.float64)
     d = rays_d.astype(np.float64)
     b = (o * d).sum(-1)
@@ -234,7 +240,7 @@ def target_colors(rays_o, rays_d):
     n = p / 0.5
     base = 0.5 + 0.5 * n
     spec = np.clip(-(n * d).sum(-1), 0, 1)[:, None] ** 4
-    col = np.clip(0.8 * base + 0.2 * spec, 0, 1)
+    col = np.clip(0.8 * base + 0.2 * spec, 0, 1) * albedo
     return np.where(hit[:, None], col, 1.0).astype(np.float32)
 
 
