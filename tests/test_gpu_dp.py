@@ -1,0 +1,75 @@
+"""Data parallelism on the real kernels: 2 ranks (gloo over CUDA tensors - RCCL cannot place two ranks on the one GPU of
+the test box) each run Trainer.train_step on their own ray shard; the all-reduced flat gradient must equal the gradient a
+single process computes on the concatenated batch (eikonal term as a ratio of GLOBAL sums)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+B, SEED = 16, 23
+
+
+def _rays(rank):
+    from vdn_train import synth
+    cams = synth.make_cameras(SEED)
+    px = np.floor(synth.uniform(SEED, "dpg/x%d" % rank, (B,)) * 400) + 200
+    py = np.floor(synth.uniform(SEED, "dpg/y%d" % rank, (B,)) * 400) + 200
+    o, d = synth.pixel_rays(cams[0], px, py)
+    near, far = synth.near_far_from_sphere(o, d)
+    t1, t2 = synth.jitter(SEED, 0, B, rank=rank)
+    return [o, d, near, far, synth.target_colors(o, d), t1, t2]
+
+
+def _worker(rank, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "vdn-nerf_amd"))
+    import torch.distributed as dist
+    from vdn_train import synth, factory
+    from vdn_train.trainer import Trainer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    dev = torch.device("cuda:0")
+    rend = factory.build_renderer(device=dev, states=synth.make_all_states(SEED))
+    tr = Trainer(rend, B, dev, world_size=2, rank=rank)
+    g = lambda x: torch.tensor(x).to(dev)
+    o, d, near, far, rgb, t1, t2 = _rays(rank)
+    sc = tr.train_step(g(o), g(d), g(near), g(far), g(rgb), t_rand=g(t1), t_rand_out=g(t2))
+    torch.cuda.synchronize()
+    if rank == 0:
+        q.put((tr.engine.grad_flat.cpu().numpy(), float(sc[3].item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_equals_single_process_on_concatenated_batch():
+    import torch.multiprocessing as mp
+    from vdn_train import synth, factory
+    from vdn_train.trainer import Trainer
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    flat, eik = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    dev = torch.device("cuda:0")
+    rend = factory.build_renderer(device=dev, states=synth.make_all_states(SEED))
+    tr = Trainer(rend, 2 * B, dev)
+    g = lambda x: torch.tensor(x).to(dev)
+    parts = [_rays(0), _rays(1)]
+    cat = [np.concatenate([parts[0][i], parts[1][i]], 0) for i in range(7)]
+    sc = tr.train_step(g(cat[0]), g(cat[1]), g(cat[2]), g(cat[3]), g(cat[4]), t_rand=g(cat[5]), t_rand_out=g(cat[6]))
+    ref = tr.engine.grad_flat.cpu().numpy()
+    assert flat.shape == ref.shape == (1409087,)
+    assert abs(eik - float(sc[3].item())) < 1e-5 * abs(eik)                 # global eikonal term
+    assert np.abs(flat - ref).max() < 2e-5 * np.abs(ref).max()
