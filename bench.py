@@ -44,13 +44,12 @@ def time_kernel(fn, iters=10):
     return float(np.mean([a.elapsed_time(b) for a, b in zip(e0, e1)])) * 1e-3
 
 
-def cpu_baseline(B, seed, max_seconds=30.0):
+def cpu_baseline(B, seed, wdepth=False, max_seconds=30.0):
     """The oracle's training step (render forward + loss + autograd backward) on the host cores, same workload,
     bounded sample. Adam is excluded (negligible against the 8 s step)."""
     import oracle.neus_oracle as orc
     from vdn_train import synth
-    st = synth.make_all_states(seed, wdepth=False)
-    nets = orc.nets_from_numpy(st)
+    st = synth.make_all_states(seed, wdepth=wdepth)
     cams = synth.make_cameras(seed)
     o, d = synth.random_pixel_batch(seed, 0, 0, B, cams=cams)
     near, far = synth.near_far_from_sphere(o, d)
@@ -62,9 +61,10 @@ def cpu_baseline(B, seed, max_seconds=30.0):
     rgb = tt(synth.target_colors(o, d))
     params = [p for _, p in orc.all_params(nets)]
     cores = torch.get_num_threads()
+    lkw = dict(gt_feats=tt(synth.uniform(seed, "bench/feats", (B, 96)).astype(np.float32)), depth_ramp=0.5) if wdepth else {}
 
     def one():
-        lo = orc.loss_from_render(orc.render(*args, **kw), rgb)
+        lo = orc.loss_from_render(orc.render(*args, **kw), rgb, **lkw)
         torch.autograd.grad(lo["loss"], params, allow_unused=True)
     t0 = time.time()
     one()                                       # warm-up (first call pays allocator / thread-pool start)
@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", choices=["womsk_white", "womsk_white_wdepth"], default="womsk_white",
+                    help="womsk_white = BASELINE.json configs[1] (the headline); womsk_white_wdepth = configs[2] (VDN head + depth-feature loss)")
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16",
                     help="bf16 = BASELINE.json's headline config (bf16 MFMA, fp32 accumulate); fp32 = the parity path")
     args = ap.parse_args()
@@ -104,13 +106,18 @@ def main():
     from vdn_train import synth, factory
     from vdn_train.trainer import Trainer
     seed, B = 0, args.batch
-    st = synth.make_all_states(seed, wdepth=False)
-    rend = factory.build_renderer(wdepth=False, device=dev, states=st, precision=args.precision)
-    trainer = Trainer(rend, B, dev, world_size=world, rank=rank)
+    wdepth = args.config == "womsk_white_wdepth"
+    st = synth.make_all_states(seed, wdepth=wdepth)
+    rend = factory.build_renderer(wdepth=wdepth, device=dev, states=st, precision=args.precision)
+    # wdepth: the depth-feature loss is live from the first timed step (dpt_runner.py:236 with depth_start_iter behind us)
+    trainer = Trainer(rend, B, dev, conf=dict(extract_depth=True, depth_start_iter=-1) if wdepth else None, world_size=world, rank=rank)
+    gt_feats = None
     cams = synth.make_cameras(seed)
     perm = np.argsort(synth.uniform(seed, "perm", (len(cams),)))
     bg = torch.ones(1, 3, device=dev)
     g = lambda x: torch.tensor(x).to(dev)
+    if wdepth:
+        gt_feats = g(synth.uniform(seed, "bench/feats/%d" % rank, (B, 96)).astype(np.float32))
 
     def batch(step):
         o, d = synth.random_pixel_batch(seed, step, int(perm[step % len(perm)]), B, rank=rank, cams=cams)
@@ -121,7 +128,7 @@ def main():
 
     def step(i):
         # one iteration of dpt_runner.py:197-259: sample -> render -> loss -> backward -> (all-reduce) -> Adam
-        return trainer.train_step(*batches[i])
+        return trainer.train_step(*batches[i], gt_feats=gt_feats)
 
     for i in range(args.warmup):
         step(i)
@@ -161,37 +168,50 @@ def main():
     if rank == 0:
         rays = world * B * args.steps
         value = rays / dt
-        # dominant kernel: fused PE -> SDF MLP -> feature + analytic gradient sweep, 65 536 points
-        o, d, near, far = batches[0][:4]
-        with torch.no_grad():
-            z, _ = rend._sample(o, d, near.reshape(-1), far.reshape(-1), 0.0, None, None, None)
-            _, mid = rend._sections(z, z.shape[1], 2.0 / rend.n_samples)
-            tk = time_kernel(lambda: rend.sdf_network._run(1, rays=(o, d, mid)))
-        flops = (F_SDF + F_GRAD) * mid.numel()
+        flop_per_ray = FLOP_PER_RAY_TRAIN + (3 * (128 * F_VDN + 160 * (F_NERF_DPT - F_NERF)) if wdepth else 0)
+        # The fused SDF-MLP kernel (north-star kernel): PE -> 9 layers -> sdf/feature + analytic gradient sweep on the
+        # 65 536 render_core points, timed with HIP events exactly as it is launched inside the timed training step
+        # (training-mode activation saves included), so it agrees with the rocprofv3 average of the same command.
+        eng = trainer.engine
+        o, d = batches[0][0], batches[0][1]
+        tk = time_kernel(lambda: eng._sdf_forward(o, d))
+        flops = (F_SDF + F_GRAD) * eng.P
         dtype = "f32" if args.precision == "fp32" else "bf16"
-        # HBM bytes per launch of that kernel from the L2 memory-side PMC counters (FETCH_SIZE / WRITE_SIZE in separate
+        # the same kernel without the training saves (what render() launches under torch.no_grad())
+        with torch.no_grad():
+            tk_inf = time_kernel(lambda: rend.sdf_network._run(1, rays=(o, d, eng.w["mid_z"])))
+        # the longest kernel of the step: the batched weight-gradient GEMM, HBM-bound (every saved plane read once)
+        tdw = time_kernel(lambda: eng._launch_dw())
+        dw_bytes, dw_flops = eng.dw_bytes(), eng.dw_flops()
+        # HBM bytes per launch of the fused kernel from the L2 memory-side PMC counters (FETCH_SIZE / WRITE_SIZE in separate
         # rocprofv3 --pmc passes, gfx950 x2 correction on FETCH_SIZE): collected by tools/collect_traffic.sh, not live
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "r01_traffic_sdf_fwd_%s.json" % args.precision)
-        if os.path.exists(tf):
-            traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+        def traffic_of(tag):
+            tf = os.path.join(ROOT, "profiles", "r01_traffic_sdf_fwd_%s%s.json" % (args.precision, tag))
+            return json.load(open(tf)).get("hbm_bytes_per_launch") if os.path.exists(tf) else None
+        traffic, traffic_inf = traffic_of("_train"), traffic_of("")
         line = {
             "metric": "rays/sec (512-ray batch, 128 samples/ray)", "value": value, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": "training step of womsk_white (hierarchical sampling + render forward + backward + gradient "
-                                   "all-reduce + Adam): SDF 8x256 + colour 4x256 + NeRF 8x256, 512 rays x (64 coarse + 64 importance "
-                                   "+ 32 outside) per GPU per step",
+            "config": {"workload": "training step of %s (hierarchical sampling + render forward + backward + gradient "
+                                   "all-reduce + Adam): SDF 8x256 + colour 4x256 %s+ NeRF 8x256, 512 rays x (64 coarse + 64 importance "
+                                   "+ 32 outside) per GPU per step" % (args.config, "+ VDN head 4x256->96 " if wdepth else ""),
                        "rays_per_gpu": B, "samples_per_ray": 128, "outside_samples": 32, "parallelism": "dp%d" % world,
-                       "flop_per_ray": FLOP_PER_RAY_TRAIN, "allreduce_bytes": trainer.param_flat.numel() * 4},
-            "model_flops_per_s": value * FLOP_PER_RAY_TRAIN,
+                       "flop_per_ray": flop_per_ray, "allreduce_bytes": trainer.param_flat.numel() * 4},
+            "model_flops_per_s": value * flop_per_ray,
             "forward_only_rays_per_s": fwd_rays_per_s, "final_loss": loss_final,
-            "roofline": {"bound": "mfma", "kernel": "sdf_fwd_kernel<%s,1> (fused PE + SDF MLP + gradient sweep, 65536 points)" % ("F32" if dtype == "f32" else "BF16"),
+            "roofline": {"bound": "mfma", "kernel": "sdf_fwd_kernel<%s,1,4> (fused PE + SDF MLP + gradient sweep, 65536 points, "
+                                                   "training-mode launch of the timed step)" % ("F32" if dtype == "f32" else "BF16"),
                          "achieved": flops / tk / 1e12, "peak": PEAK[dtype] / 1e12, "unit": "TFLOP/s",
-                         "frac": flops / tk / PEAK[dtype], "traffic": traffic, "kernel_ms": tk * 1e3},
+                         "frac": flops / tk / PEAK[dtype], "traffic": traffic, "kernel_ms": tk * 1e3,
+                         "inference_launch": {"kernel_ms": tk_inf * 1e3, "achieved": flops / tk_inf / 1e12, "frac": flops / tk_inf / PEAK[dtype],
+                                              "traffic": traffic_inf}},
+            "roofline_dw_gemm": {"bound": "hbm", "kernel": "dw_gemm_%s_kernel (batched split-K weight-gradient GEMM, longest kernel of the step)" % dtype,
+                                 "achieved": dw_bytes / tdw / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": dw_bytes / tdw / 8e12,
+                                 "traffic": None, "kernel_ms": tdw * 1e3, "tflops": dw_flops / tdw / 1e12},
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(B, seed)
+            line["cpu_baseline"] = cpu_baseline(B, seed, wdepth)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

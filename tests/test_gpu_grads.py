@@ -273,3 +273,46 @@ def test_trainer_three_adam_steps_match_reference(golden):
     tr.param_flat.zero_()
     tr.load_checkpoint(ck)
     assert torch.equal(tr.param_flat, before) and tr.iter_step == 103
+
+
+def test_trainer_wdepth_mask_step_equals_autograd_path():
+    """Runner.train's loss with a real mask, mask_weight > 0 and the VDN depth term (dpt_runner.py:207-243): the fused loss kernel
+    + engine backward of the Trainer give the same scalars and the same gradient as render() + the reference's torch loss +
+    loss.backward() through the custom autograd node."""
+    import torch.nn.functional as F
+    from vdn_train import synth, factory
+    from vdn_train.trainer import Trainer
+    dev = torch.device("cuda:0")
+    B, seed = 128, 47
+    st = synth.make_all_states(seed, wdepth=True)
+    cams = synth.make_cameras(seed)
+    o, d = synth.random_pixel_batch(seed, 0, 2, B, cams=cams)
+    near, far = synth.near_far_from_sphere(o, d)
+    t1, t2 = synth.jitter(seed, 0, B)
+    o, d, near, far, t1, t2 = (g(x, dev) for x in (o, d, near, far, t1, t2))
+    rgb = g(synth.uniform(seed, "tm/rgb", (B, 3)), dev)
+    gtf = g(synth.uniform(seed, "tm/f", (B, 96)), dev)
+    mask = (g(synth.uniform(seed, "tm/m", (B, 1)), dev) > 0.35).float()
+    conf = dict(extract_depth=True, depth_start_iter=10, mask_weight=0.1, anneal_end=100)
+    tr = Trainer(factory.build_renderer(wdepth=True, device=dev, states=st), B, dev, conf=conf)
+    tr.iter_step, tr._adam_step_offset, tr.depth_iter = 40, 40, 1200
+    w_depth, cos = tr.depth_iter_weight(), tr.cos_anneal_ratio()
+    sc = tr.train_step(o, d, near, far, rgb, gt_feats=gtf, mask=mask, t_rand=t1, t_rand_out=t2).cpu().numpy()
+    got = tr.engine.param_grads()
+
+    rend = factory.build_renderer(wdepth=True, device=dev, states=st)
+    out = rend.render(o, d, near, far, background_rgb=torch.ones(1, 3, device=dev), cos_anneal_ratio=cos, t_rand=t1, t_rand_out=t2)
+    mask_sum = mask.sum() + 1e-5
+    color_loss = ((out["color_fine"] - rgb) * mask).abs().sum() / mask_sum
+    psnr = 20.0 * torch.log10(1.0 / (((out["color_fine"] - rgb) ** 2 * mask).sum() / (mask_sum * 3.0)).sqrt())
+    mask_loss = F.binary_cross_entropy(out["weight_sum"].clip(1e-3, 1.0 - 1e-3), mask)
+    depth_loss = ((out["render_feats"] - gtf) * mask).abs().sum() / mask_sum
+    loss = color_loss + out["gradient_error"] * 0.1 + mask_loss * 0.1 + depth_loss * w_depth
+    loss.backward()
+    want_sc = [x.item() for x in (loss, color_loss, psnr, out["gradient_error"], depth_loss, mask_loss)]
+    np.testing.assert_allclose(sc, want_sc, rtol=2e-5)
+    params = rend._all_parameters()
+    assert len(params) == len(got)
+    for i, (p, gr) in enumerate(zip(params, got)):
+        scale = p.grad.abs().max().item()
+        assert scale > 0 and (p.grad - gr).abs().max().item() <= 1e-5 * scale, (i, tuple(p.shape))

@@ -1,4 +1,4 @@
-"""Launch one kernel of the path repeatedly (for rocprofv3 --pmc runs).  usage: kernel_loop.py <sdf1|sdf0|nerf|color> [P] [precision] [iters]"""
+"""Launch one kernel of the path repeatedly (for rocprofv3 --pmc runs).  usage: kernel_loop.py <sdf1|sdf1t|sdf0|nerf|color> [P] [precision] [iters]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vdn-nerf_amd"))
@@ -15,9 +15,16 @@ near, far = synth.near_far_from_sphere(o, d)
 g = lambda x: torch.tensor(x).to(dev)
 o, d = g(o), g(d)
 z = (g(near) + (g(far) - g(near)) * torch.linspace(0, 1, 128, device=dev)[None, :]).contiguous()
+eng = None
+if which == "sdf1t":                      # the fused kernel as the training step launches it (saves S, H and the PE planes)
+    from vdn_train.trainer import Trainer
+    eng = Trainer(rend, batch_size=B, device=dev).engine
+    eng.w["mid_z"].copy_(z)
 with torch.no_grad():
     for i in range(iters):
-        if which == "sdf1":
+        if which == "sdf1t":
+            eng._sdf_forward(o, d)
+        elif which == "sdf1":
             sdf, feat, nrm = rend.sdf_network._run(1, rays=(o, d, z))
         elif which == "sdf0":
             rend.sdf_network._run(0, rays=(o, d, z))

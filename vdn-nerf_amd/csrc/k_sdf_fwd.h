@@ -206,11 +206,9 @@ int launch_sdf_fwd(int mode, const VdnSdfArgs* args, void* stream_) {
                                  args->z_ld < args->n_per_ray || args->sdf_ld < args->n_per_ray)) return -2;
     if (mode == 0) {
         if (args->sdf == nullptr) return -3;
-        // waves per workgroup so that the grid is >= 256 workgroups (one per CU) when the batch allows it
-        const int tiles = (args->P + 31) / 32;
-        if (tiles >= 4 * 256) launch_sdf_nw<P, 0, 4>(args, stream);
-        else if (tiles >= 2 * 256) launch_sdf_nw<P, 0, 2>(args, stream);
-        else launch_sdf_nw<P, 0, 1>(args, stream);
+        // Measured (profiles/README.md): 4 waves per workgroup share each weight chunk's DMA and beat
+        // 1- or 2-wave workgroups even when that leaves the grid below one workgroup per CU.
+        launch_sdf_nw<P, 0, 4>(args, stream);
     } else if (mode == 1) {
         if (!args->sdf || !args->feat || !args->normals || !args->S || !args->w8row) return -3;
         launch_sdf_nw<P, 1, P::kWaves>(args, stream);

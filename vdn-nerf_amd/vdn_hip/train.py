@@ -291,15 +291,7 @@ class TrainEngine:
             n.feat = w["bg_feat"].data_ptr() if w["bg_feat"] is not None else None
             n.save_h, n.save_pe, n.save_feature, n.save_vpe, n.save_hv = (w[k].data_ptr() for k in ("nf_h", "nf_pe", "nf_feature", "nf_vpe", "nf_hv"))
             lib.call("vdn_nerf_mlp_fwd" + self.sfx, n, st)
-        s = lib.VdnSdfArgs()
-        img = self.nets["sdf"].img
-        s.blob = img.blobs["full"].data_ptr()
-        s.rays_o, s.rays_d, s.z, s.n_per_ray, s.z_ld, s.sdf_ld = rays_o.data_ptr(), rays_d.data_ptr(), w["mid_z"].data_ptr(), N, N, N
-        s.P, s.scale = self.P, float(r.sdf_network.scale)
-        s.sdf, s.feat, s.normals, s.S = w["sdf"].data_ptr(), w["feat"].data_ptr(), w["normals"].data_ptr(), w["S"].data_ptr()
-        s.w8row = img.weff_view("lin8").data_ptr()
-        s.H, s.V, s.PE = w["H"].data_ptr(), w["V"].data_ptr(), w["PE"].data_ptr()
-        lib.call("vdn_sdf_mlp_fwd" + self.sfx, 1, s, st)
+        self._sdf_forward(rays_o, rays_d)
 
         def rnet(net, out, save_h, small, d_out, module):
             c = lib.VdnRenderNetArgs()
@@ -323,6 +315,38 @@ class TrainEngine:
         self._ctx = (rays_o, rays_d, background_rgb, cos_anneal_ratio, z)
         self.generation = getattr(self, "generation", 0) + 1
         return w
+
+    def _sdf_forward(self, rays_o, rays_d):
+        """The fused SDF kernel (PE -> 9 layers -> sdf / feature + gradient sweep) with the training-mode saves, on the
+        section mid-points currently in the workspace. Separate so that bench.py can time exactly this launch."""
+        r, w, N = self.r, self.w, self.N
+        s = lib.VdnSdfArgs()
+        img = self.nets["sdf"].img
+        s.blob = img.blobs["full"].data_ptr()
+        s.rays_o, s.rays_d, s.z, s.n_per_ray, s.z_ld, s.sdf_ld = rays_o.data_ptr(), rays_d.data_ptr(), w["mid_z"].data_ptr(), N, N, N
+        s.P, s.scale = self.P, float(r.sdf_network.scale)
+        s.sdf, s.feat, s.normals, s.S = w["sdf"].data_ptr(), w["feat"].data_ptr(), w["normals"].data_ptr(), w["S"].data_ptr()
+        s.w8row = img.weff_view("lin8").data_ptr()
+        s.H, s.V, s.PE = w["H"].data_ptr(), w["V"].data_ptr(), w["PE"].data_ptr()
+        lib.call("vdn_sdf_mlp_fwd" + self.sfx, 1, s, _stream())
+
+    def dw_bytes(self):
+        """Algorithmic HBM bytes of one weight-gradient GEMM launch: every operand plane read once + the slabs written."""
+        esz = 4 if self.precision == "fp32" else 2
+        total = 0
+        tab = np.frombuffer(self.dw_table.cpu().numpy().tobytes(), dtype=lib.struct_dtype("VdnDwDesc"))
+        for d in tab:
+            segs = 2 if d["A2"] else 1
+            total += segs * int(d["P"]) * 32 * (int(d["m_tiles"]) + int(d["n_tiles"])) * esz
+            total += int(d["splits"]) * int(d["m_tiles"]) * 32 * int(d["n_tiles"]) * 32 * 4
+        return total
+
+    def dw_flops(self):
+        tab = np.frombuffer(self.dw_table.cpu().numpy().tobytes(), dtype=lib.struct_dtype("VdnDwDesc"))
+        return sum(2.0 * (2 if d["A2"] else 1) * int(d["P"]) * int(d["m_tiles"]) * 32 * int(d["n_tiles"]) * 32 for d in tab)
+
+    def _launch_dw(self):
+        lib.call("vdn_dw_gemm" + self.sfx, lib.ptr(self.dw_table), self.n_dw, self.dw_total_wgs, _stream())
 
     def _composite_common(self, c, rays_o, rays_d, background_rgb, cos_anneal_ratio):
         w, r = self.w, self.r
@@ -409,7 +433,7 @@ class TrainEngine:
             nb.P = self.Q
             lib.call("vdn_nerf_mlp_bwd" + self.sfx, nb, st)
 
-        lib.call("vdn_dw_gemm" + self.sfx, lib.ptr(self.dw_table), self.n_dw, self.dw_total_wgs, st)
+        self._launch_dw()
         lib.call("vdn_dw_finalize", lib.ptr(self.fin_table), self.n_dw, self.fin_max_M, 0, st)
         lib.call("vdn_dw_finalize", lib.ptr(self.fin_table), self.n_dw, self.fin_max_M, 1, st)
         lib.call("vdn_weightnorm_bwd", lib.ptr(self.wn_table), self.n_wn, self.wn_max_rows, st)
