@@ -1,6 +1,6 @@
 """Measure the bf16 path against the fp32 oracle: stage errors, render PSNR, gradient agreement, step time."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "vdn-nerf_amd")); sys.path.insert(0, ROOT)
 import numpy as np
 import torch

@@ -1,5 +1,5 @@
 """bf16-MFMA throughput path (precision='bf16') against the fp32 oracle. bf16 operands carry 8 significant bits, so
-this path is NOT held to 1e-4: the bounds below are ~3x the errors measured on MI355X (tools/bf16_probe.py:
+this path is NOT held to 1e-4: the bounds below are ~3x the errors measured on MI355X (tests/probes/bf16_probe.py:
 sdf abs err max 5.5e-3 / mean 1e-3, colour PSNR 70 dB at inv_s 20 and 57 dB at inv_s 665, gradient cosine >= 0.9995).
 The fp32 path (tests/test_gpu_parity.py, test_gpu_grads.py) is the one that carries the 1e-4 parity claim."""
 import numpy as np
