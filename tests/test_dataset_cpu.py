@@ -1,0 +1,100 @@
+"""On-disk formats: cameras_sphere npz -> intrinsics / pose, PNG + mask / RGBA decoding with the reference's
+compositing and channel order, wavelet-feature normalisation. The reference's loader needs OpenCV (absent), so these pin the
+restatement by construction: projection matrices built from known K, R, c must decompose back to them."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from vdn_train import dataset, synth
+
+
+def _K(f=1111.0, w=80, h=60, skew=0.0):
+    return np.array([[f, skew, (w - 1) / 2.0], [0, 1.03 * f, (h - 1) / 2.0], [0, 0, 1.0]])
+
+
+@pytest.mark.parametrize("scale", [1.0, -2.5, 1e-3])
+def test_projection_matrix_decomposition_recovers_camera(scale):
+    cams = synth.make_cameras(3)
+    K = _K(skew=0.7)
+    for c2w in cams[:6]:
+        w2c = np.linalg.inv(c2w)
+        P = scale * (K @ w2c[:3, :4])
+        intr, pose = dataset.load_K_Rt_from_P(P)
+        np.testing.assert_allclose(intr[:3, :3], K, rtol=1e-9, atol=1e-7)
+        np.testing.assert_allclose(pose, c2w, rtol=0, atol=2e-6)            # pose is float32 like the reference's
+        assert intr.shape == (4, 4) and pose.dtype == np.float32 and abs(np.linalg.det(pose[:3, :3]) - 1) < 1e-5
+
+
+def _write_scene(root, rgba, with_depth, n=3, H=12, W=16):
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    os.makedirs(os.path.join(root, "image", "mask"), exist_ok=True)
+    os.makedirs(os.path.join(root, "image", "wavelet_feats", "0"), exist_ok=True)
+    cams = synth.make_cameras(1)[:n]
+    names = ["%03d" % i for i in range(n)]
+    K4 = np.eye(4)
+    K4[:3, :3] = _K(f=20.0, w=W, h=H)
+    scale_mat = np.diag([1.7, 1.7, 1.7, 1.0])
+    scale_mat[:3, 3] = [0.2, -0.1, 0.05]
+    world = [K4 @ np.linalg.inv(c) @ np.linalg.inv(scale_mat) for c in cams]      # so that world @ scale = K @ w2c
+    dataset.write_cameras_npz(os.path.join(root, "cameras_sphere.npz"), names, world, [scale_mat] * n)
+    raw = {}
+    for nm in names:
+        rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        m = (rng.random((H, W)) > 0.4).astype(np.uint8) * 255
+        if rgba:
+            Image.fromarray(np.concatenate([rgb, m[:, :, None]], 2), "RGBA").save(os.path.join(root, "image", nm + ".png"))
+        else:
+            Image.fromarray(rgb, "RGB").save(os.path.join(root, "image", nm + ".png"))
+            Image.fromarray(np.repeat(m[:, :, None], 3, 2), "RGB").save(os.path.join(root, "image", "mask", nm + ".png"))
+        f = rng.normal(0.3, 2.0, (1, 96, H // 2, W // 2)).astype(np.float32)
+        if with_depth:
+            np.save(os.path.join(root, "image", "wavelet_feats", "0", nm + ".npy"), f)
+        raw[nm] = (rgb, m, f)
+    return names, cams, K4, raw
+
+
+@pytest.mark.parametrize("rgba", [False, True])
+def test_scene_loader_matches_reference_semantics(tmp_path, rgba):
+    names, cams, K4, raw = _write_scene(str(tmp_path), rgba, with_depth=True)
+    sc = dataset.SceneData(str(tmp_path), with_depth=True)
+    assert sc.n_images == 3 and (sc.H, sc.W) == (12, 16) and sc.names == names
+    np.testing.assert_allclose(sc.pose_all, np.stack(cams), atol=3e-6)
+    np.testing.assert_allclose(sc.intrinsics_all[1], K4, rtol=1e-5, atol=1e-4)
+    assert abs(sc.focal - 20.0) < 1e-4
+    for i, nm in enumerate(names):
+        rgb, m, _ = raw[nm]
+        a = (m / 255.0)[:, :, None]
+        want = (rgb[:, :, ::-1] / 255.0) * a + (1 - a)               # BGR like cv.imread, composited on white (poses.py:117-127)
+        np.testing.assert_allclose(sc.images[i], want, atol=1e-6)
+        np.testing.assert_allclose(sc.masks[i][..., :1], a, atol=1e-6)
+    assert sc.masks.shape[-1] == (1 if rgba else 3)
+    # wavelet features: global statistics over the whole stack, sigmoid, bilinear x2 (poses.py:133-146)
+    stack = np.stack([raw[nm][2][0] for nm in names])
+    z = torch.sigmoid(torch.from_numpy((stack - stack.mean()) / stack.std()))
+    want = torch.nn.Upsample(size=(12, 16), mode="bilinear")(z).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(sc.depth_feats, want, atol=1e-6)
+    assert sc.depth_feats.shape == (3, 12, 16, 96)
+    np.testing.assert_allclose(sc.object_bbox_min, [-1.01] * 3, atol=1e-6)
+    assert sc.depth_from_sdf_path(2).endswith(os.path.join("image", "depth_from_sdf", "sdf_002.npy"))
+    gen = sc.rays_generator(device="cpu")                             # tensors only; launching needs the GPU
+    assert gen.images.shape == (3, 12, 16, 3) and gen.C == 96 and gen.intrin_inv.shape == (3, 3, 3)
+
+
+def test_scene_loader_errors(tmp_path):
+    with pytest.raises(FileNotFoundError):
+        dataset.SceneData(str(tmp_path))
+
+
+def test_image_metrics_formula():
+    from vdn_train import validate
+    rng = np.random.default_rng(0)
+    img, gt = rng.random((6, 5, 3)).astype(np.float32), rng.random((6, 5, 3)).astype(np.float32)
+    mask = (rng.random((6, 5, 1)) > 0.5).astype(np.float32)
+    l1, psnr = validate.image_metrics(img, gt, mask)
+    ms = mask.sum() + 1e-5
+    assert abs(l1 - np.abs((img - gt) * mask).sum() / ms) < 1e-6
+    assert abs(psnr - 20 * np.log10(1 / np.sqrt((((img - gt) ** 2) * mask).sum() / (ms * 3)))) < 1e-5
+    assert validate._resize(gt, 3, 2, 2).shape == (3, 2, 3)

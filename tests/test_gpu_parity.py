@@ -1,6 +1,8 @@
 """GPU parity: the HIP path (through the dpt_models boundary -> C ABI) against the oracle and the
 reference's golden vectors. Tolerances: 1e-5 rel single stages, 1e-4 rel per-ray end-to-end and
 per-sample with injected z (BASELINE north-star 1e-4 rel fp32)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -250,3 +252,46 @@ def test_on_device_ray_generator(dev):
     # a render fed by the generator runs end to end
     rend_rays = gen.gen_random_rays_at(0, 8)
     assert torch.isfinite(rend_rays).all()
+
+
+def test_val_img_over_a_scene_directory(tmp_path):
+    """Scene files -> SceneData -> on-device rays -> batched render of one camera (Runner.val_img, dpt_runner.py:417-474),
+    incl. the depth_from_sdf writer; the image equals direct render() calls on the same rays and jitter."""
+    from PIL import Image
+    from vdn_train import synth, factory, dataset, validate
+    dev = torch.device("cuda:0")
+    H, W, n = 24, 32, 2
+    root = str(tmp_path)
+    os.makedirs(os.path.join(root, "image", "mask"))
+    cams = synth.make_cameras(2)[:n]
+    K4 = np.eye(4)
+    K4[:3, :3] = [[30.0, 0, (W - 1) / 2.0], [0, 30.0, (H - 1) / 2.0], [0, 0, 1]]
+    names = ["%03d" % i for i in range(n)]
+    dataset.write_cameras_npz(os.path.join(root, "cameras_sphere.npz"), names, [K4 @ np.linalg.inv(c) for c in cams], [np.eye(4)] * n)
+    rng = np.random.default_rng(1)
+    for nm in names:
+        Image.fromarray(rng.integers(0, 256, (H, W, 3), dtype=np.uint8), "RGB").save(os.path.join(root, "image", nm + ".png"))
+        Image.fromarray(np.full((H, W, 3), 255, np.uint8), "RGB").save(os.path.join(root, "image", "mask", nm + ".png"))
+    scene = dataset.SceneData(root)
+    gen = scene.rays_generator(dev)
+    rend = factory.build_renderer(device=dev, states=synth.make_all_states(2))
+    torch.manual_seed(7)
+    l1, psnr, eik, img = validate.val_img(rend, scene, gen, 1, resolution_level=1, batch_size=512, cos_anneal_ratio=0.8,
+                                          gen_depth_for_finetune=True)
+    assert img.shape == (H, W, 3) and np.isfinite(img).all() and eik.shape == (2,)
+    want_l1, want_psnr = validate.image_metrics(img, scene.images[1])
+    assert abs(l1 - want_l1) < 1e-7 and abs(psnr - want_psnr) < 1e-6
+    depth = np.load(scene.depth_from_sdf_path(1))
+    assert depth.shape == (H, W, 1) and (depth > 0).all()
+    # the same rays / jitter through render() directly
+    torch.manual_seed(7)
+    o, d = gen.gen_rays_at(1)
+    o, d = o.reshape(-1, 3).contiguous(), d.reshape(-1, 3).contiguous()
+    with torch.no_grad():
+        for s in (0, 512):
+            near, far = gen.near_far_from_sphere(o[s:s + 512], d[s:s + 512])
+            out = rend.render(o[s:s + 512], d[s:s + 512], near, far, cos_anneal_ratio=0.8, background_rgb=torch.ones(1, 3, device=dev))
+            assert np.array_equal(out["color_fine"].cpu().numpy(), img.reshape(-1, 3)[s:s + 512])
+            w = out["weights"][:, :128] * out["inside_sphere"]
+            zd = out["z_vals"].gather(1, w.argmax(-1, keepdim=True)).cpu().numpy()
+            assert np.array_equal(zd, depth.reshape(-1, 1)[s:s + 512])
