@@ -16,7 +16,10 @@ __global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(Sdf
     using ST = typename P::store_t;
     constexpr int kSlot = P::stride(9);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    WStream<NW, kSlot> ws;
+#ifndef VDN_NSLOT
+#define VDN_NSLOT 3
+#endif
+    WStream<NW, kSlot, VDN_NSLOT> ws;
     ws.init(a.blob, smem, MODE == 0 ? 64 : 131);       // chunks in the 'sdf' / 'full' stream
     const int lane = ws.lane, c = lane & 31, h = lane >> 5;
     const long p_raw = ((long)blockIdx.x * NW + ws.wave) * 32 + c;
@@ -56,31 +59,32 @@ __global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(Sdf
             }
         }
     };
-    // hidden layer epilogue: D <- softplus100(acc); S <- softplus'(acc) (and H <- the activation) row-major
+    // hidden layer epilogue: D <- softplus100(acc); S <- softplus'(acc) (and H <- the activation). The softplus is the
+    // per-register part (runs under the next tile's MFMAs on the bf16 path), packing / stores the per-tile part.
+    struct HS { f32x16 hv, sv; };
     auto hidden = [&](auto& D, int l) VDN_INL {
-        return [&D, l, S, Hs, PS, p, ok, h](int nt, const f32x16& acc, int) VDN_INL {
-            f32x16 hv, sv;
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
+        return elem_epi<HS>(
+            [](int, int t, float acc, HS& o) VDN_INL {
                 if constexpr (SV) {
                     float a_, b_;
-                    softplus100_both(acc[t], a_, b_);
-                    hv[t] = a_;
-                    sv[t] = b_;
+                    softplus100_both(acc, a_, b_);
+                    o.hv[t] = a_;
+                    o.sv[t] = b_;
                 } else {
 #if defined(VDN_ABLATE) && VDN_ABLATE == 1
-                    hv[t] = acc[t];
+                    o.hv[t] = acc;
 #else
-                    hv[t] = softplus100_fast(acc[t]);
+                    o.hv[t] = softplus100_fast(acc);
 #endif
                 }
-            }
-            D.set(nt, hv);
-            if constexpr (SV) {
-                P::store_tile(S + l * PS, p, 256, nt, h, sv, ok);
-                if (Hs != nullptr) P::store_tile(Hs + l * PS, p, 256, nt, h, hv, ok);
-            }
-        };
+            },
+            [&D, l, S, Hs, PS, p, ok, h](int nt, const HS& o, int) VDN_INL {
+                D.set(nt, o.hv);
+                if constexpr (SV) {
+                    P::store_tile(S + l * PS, p, 256, nt, h, o.sv, ok);
+                    if (Hs != nullptr) P::store_tile(Hs + l * PS, p, 256, nt, h, o.hv, ok);
+                }
+            });
     };
     constexpr int C2 = P::chunk_bytes(2), C7 = P::chunk_bytes(7), C8 = P::chunk_bytes(8), C9 = P::chunk_bytes(9);
     const int est_h = SV ? (Hs != nullptr ? 8 : 4) : 0;     // stores per hidden-layer tile (S, and H when training)
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(Sdf
 
 template <class P, int MODE, int NW>
 void launch_sdf_nw(const VdnSdfArgs* args, hipStream_t stream) {
-    const size_t lds = 3 * P::stride(9);
+    const size_t lds = VDN_NSLOT * P::stride(9);
     static bool once = (allow_big_lds(sdf_fwd_kernel<P, MODE, NW>, lds), true);
     (void)once;
     const int grid = (args->P + NW * 32 - 1) / (NW * 32);

@@ -16,6 +16,7 @@
 // weight streaming is one linear walk: each chunk is fetched with global_load_lds (1 KiB per wave-instruction)
 // into a ring of LDS slots, two chunk steps ahead of its use (WStream).
 #pragma once
+#include <type_traits>
 #include "vdn_common.h"
 
 namespace vdn {
@@ -110,6 +111,7 @@ struct F32 {
     static constexpr int kWaves = 4;
     static constexpr int kMinWavesPerEU = 1;
     static constexpr bool kAccurateTrig = true;     // ocml sincosf in the positional encoding
+    static constexpr bool kOverlapEpilogue = false; // an f32 tile's MFMAs take 4x longer than its epilogue: nothing to hide
     static constexpr int chunk_bytes(int KT) { return KT * 4096 + 1024; }
     static constexpr int stride(int KTMAX) { return (chunk_bytes(KTMAX) + 4095) / 4096 * 4096; }   // uniform chunk stride
     using store_t = float;
@@ -194,6 +196,13 @@ struct BF16 {
     static constexpr int kWaves = 4;
     static constexpr int kMinWavesPerEU = 2;
     static constexpr bool kAccurateTrig = false;    // hardware v_sin / v_cos (see vdn_common.h: sincos_pe)
+    // A softplus tile epilogue is ~110 VALU instructions against 16 MFMAs: elementwise epilogues (ElemEpi) are issued in
+    // the shadow of the NEXT tile's MFMAs (mma_slots), one accumulator register per MFMA.
+    static constexpr bool kOverlapEpilogue = true;
+#ifndef VDN_SLOT_GROUP
+#define VDN_SLOT_GROUP 2
+#endif
+    static constexpr int kSlotGroup = VDN_SLOT_GROUP;
     static constexpr int chunk_bytes(int KT) { return KT * 2048 + 1024; }
     static constexpr int stride(int KTMAX) { return (chunk_bytes(KTMAX) + 4095) / 4096 * 4096; }   // uniform chunk stride
     using store_t = unsigned short;   // bf16 bits
@@ -266,6 +275,46 @@ struct BF16 {
         return acc;
     }
 
+    // mma() with the issue order written out by hand and fenced: PRE fragment reads ahead, then per MFMA one more read and
+    // slot(k) - a slice of independent VALU work that runs while the (dependent) MFMA chain occupies the matrix pipe.
+    // hipcc's scheduler does not produce this interleaving from sched_group_barrier hints (it keeps MFMAs and the epilogue
+    // in two blocks in two steps out of three), hence the sched_barrier(0) fences.
+    template <int KT, bool BIAS, class ActT, class Slot>
+    static VDN_DEV f32x16 mma_slots(const char* w, const ActT& X, int x0, int lane, Slot&& slot) {
+        const int h = lane >> 5;
+        const bf16x8* wa = reinterpret_cast<const bf16x8*>(w) + lane;
+        constexpr int NS = KT * 2;
+        constexpr int PRE = NS < 6 ? NS : 6;
+        f32x16 acc;
+        bf16x8 fr[NS];
+        static_for<PRE>([&](auto s_c) VDN_INL {
+            constexpr int s = decltype(s_c)::value;
+            fr[s] = wa[s * 64];
+        });
+        if constexpr (BIAS) {
+            const f32x4* bias = reinterpret_cast<const f32x4*>(w + KT * 2048);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b = bias[2 * q + h];
+                acc[4 * q + 0] = b[0]; acc[4 * q + 1] = b[1]; acc[4 * q + 2] = b[2]; acc[4 * q + 3] = b[3];
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[t] = 0.0f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<NS>([&](auto s_c) VDN_INL {
+            constexpr int s = decltype(s_c)::value;
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[s], X.r[x0 * 2 + s], acc, 0, 0, 0);
+            if constexpr (s + PRE < NS) fr[s + PRE] = wa[(s + PRE) * 64];
+            slot(s_c, std::integral_constant<int, NS>{});
+            // fence every kSlotGroup MFMAs: inside a group the scheduler interleaves that many independent epilogue
+            // chains (a lone softplus chain is 7 dependent instructions and would not fill its MFMA's shadow)
+            if constexpr ((s + 1) % kSlotGroup == 0 || s + 1 == NS) __builtin_amdgcn_sched_barrier(0);
+        });
+        return acc;
+    }
+
     // bf16 activation planes use the tile-blocked "PT32" layout: points in blocks of 32 (= one wave's tile),
     //   element (p, f) at  (p>>5)*(32*ld) + (f>>5)*1024 + ((f&31)>>3)*256 + ((f&7)>>2)*128 + (p&31)*4 + (f&3)
     // so that a wave's store/load of (tile, q) is ONE contiguous 512-byte run (64 lanes x 8 B) instead of 64
@@ -303,9 +352,67 @@ struct BF16 {
 // instructions in pre() per tile (their sum must be 0, 4, 8, 12 or 16; a lower bound is safe, 0 drains the queue
 // at every step). Both are younger than the glds of the chunk being acquired, so they may stay in flight across
 // the barrier: the prefetched loads then have two chunk steps to land.
+// An epilogue split into a per-register part and a per-tile part:
+//   elem(nt, t, acc_t, scratch)  pure VALU work on accumulator register t of tile nt (results into `scratch`)
+//   finish(nt, scratch, aux)     the rest (packing into the next layer's operand, stores)
+// Policies with kOverlapEpilogue run elem() of tile nt-1 in the MFMA shadow of tile nt; others call both in place.
+template <class ScratchT, class Elem, class Finish>
+struct ElemEpi {
+    using Scratch = ScratchT;
+    Elem elem;
+    Finish finish;
+    template <class Aux>
+    VDN_DEV void operator()(int nt, const f32x16& acc, const Aux& aux) const {
+        Scratch sc;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) elem(nt, t, acc[t], sc);
+        finish(nt, sc, aux);
+    }
+};
+template <class ScratchT, class Elem, class Finish>
+VDN_DEV ElemEpi<ScratchT, Elem, Finish> elem_epi(Elem e, Finish f) { return {e, f}; }
+template <class T> struct is_elem_epi : std::false_type {};
+template <class S, class E, class F> struct is_elem_epi<ElemEpi<S, E, F>> : std::true_type {};
+
 template <class P, int KT, int NT, int NEXT_BYTES, bool BIAS, class WS, class ActT, class Pre, class Epi>
 VDN_DEV void dense(WS& ws, const ActT& X, int x0, Pre&& pre, Epi&& epi, int epi_stores = 0, int pre_loads = 0) {
     const int lane = ws.lane;
+    using EpiT = std::remove_cv_t<std::remove_reference_t<Epi>>;
+    if constexpr (P::kOverlapEpilogue && is_elem_epi<EpiT>::value) {
+        // Software pipeline over the output tiles: step s acquires chunk s and issues tile s's MFMAs with elem() of tile
+        // s-1 in their shadow (epi never writes X, so the order is free), then finish(s-1); step NT drains the last tile.
+        // In-flight accounting at acquire(s): younger than chunk s's DMA are at least the loads of pre(s-1) and, from
+        // s = 2 on, the stores of finish(s-2) (the chunk ahead is added inside acquire).
+        f32x16 acc_prev;
+        decltype(pre(0)) aux_prev{};
+        static_for<NT + 1>([&](auto s_c) VDN_INL {
+            constexpr int s = decltype(s_c)::value;
+            typename EpiT::Scratch sc;
+            if constexpr (s < NT) {
+                const int yg = s == 0 ? 0 : (s == 1 ? pre_loads : epi_stores + pre_loads);
+                const char* w = ws.acquire(yg);
+                auto aux_cur = pre(s);
+                const f32x16 acc_cur = P::template mma_slots<KT, BIAS>(w, X, x0, lane, [&](auto k_c, auto ns_c) VDN_INL {
+                    if constexpr (s > 0) {
+                        constexpr int k = decltype(k_c)::value, NS = decltype(ns_c)::value;
+                        static_for<(k + 1) * 16 / NS - k * 16 / NS>([&](auto j_c) VDN_INL {
+                            constexpr int t = k * 16 / NS + decltype(j_c)::value;
+                            epi.elem(s - 1, t, acc_prev[t], sc);
+                        });
+                    }
+                });
+                if constexpr (s > 0) epi.finish(s - 1, sc, aux_prev);
+                acc_prev = acc_cur;
+                aux_prev = aux_cur;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) epi.elem(s - 1, t, acc_prev[t], sc);
+                epi.finish(s - 1, sc, aux_prev);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        return;
+    }
     // pre(nt) (HBM loads feeding tile nt's epilogue) is issued one chunk step ahead of its use, so a full
     // step of MFMA + epilogue work hides its latency; tile 0's is issued before the layer's first barrier.
     auto aux = pre(0);
