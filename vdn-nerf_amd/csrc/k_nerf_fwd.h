@@ -61,7 +61,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void nerf_fwd_ke
         return [&D, t0, save, ld, p, ok, h](int nt, const f32x16& acc, int) VDN_INL {
             f32x16 o;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) o[t] = fmaxf(acc[t], 0.0f);
+            for (int t = 0; t < 16; ++t) o[t] = relu0(acc[t]);
             D.set(t0 + nt, o);
             if (save != nullptr) P::store_tile(save, p, ld, nt, h, o, ok);
         };

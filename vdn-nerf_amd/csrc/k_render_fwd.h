@@ -55,7 +55,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_f
         return [&D, l, save_h, PS, p, ok, h](int nt, const f32x16& acc, int) VDN_INL {
             f32x16 o;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) o[t] = fmaxf(acc[t], 0.0f);
+            for (int t = 0; t < 16; ++t) o[t] = relu0(acc[t]);
             D.set(nt, o);
             if (save_h != nullptr) P::store_tile(save_h + l * PS, p, 256, nt, h, o, ok);
         };
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_f
     dense<P, 8, NT_OUT, 0, true>(ws, X, 0, NoPre{}, [&](int nt, const f32x16& acc, int) VDN_INL {
         f32x16 o;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) o[t] = a.squeeze_out ? sigmoidf_(acc[t]) : fmaxf(acc[t], 0.0f);
+        for (int t = 0; t < 16; ++t) o[t] = a.squeeze_out ? sigmoidf_(acc[t]) : relu0(acc[t]);
         if constexpr (NT_OUT == 1) {
             if (ok && h == 0) {
                 for (int j = 0; j < a.d_out && j < 4; ++j) a.out[p * a.d_out + j] = o[j];

@@ -56,18 +56,26 @@ VDN_DEV float hw_log(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559
 //   t = a * 100 log2(e);  e = 2^-|t|;  L = log2(1 + e)                      (no overflow for any a)
 //   softplus = max(a, 0) + L * ln2/100      (equals the thresholded form to < 1e-10 beyond 100 a > 20)
 //   sigmoid(100 a) = a >= 0 ? 1/(1+e) : e/(1+e)
+// max(a, 0) in ONE instruction: fmaxf() on an MFMA result costs two (hipcc first canonicalises the operand with
+// v_max_f32 x, x, x because it cannot prove it is not a signalling NaN). As signed integers, negative floats (and -0)
+// are negative and non-negative floats keep their order, so v_max_i32 against 0 is the same clamp.
+// (Not inline asm: the hazard recognizer does not see inside it, and a VALU read right behind an MFMA needs wait states.)
+VDN_DEV float relu0(float a) {
+    const int i = __builtin_bit_cast(int, a);
+    return __builtin_bit_cast(float, i > 0 ? i : 0);
+}
 VDN_DEV void softplus100_both(float a, float& hval, float& sval) {
     const float t = a * 144.26950408889634f;
     const float e = __builtin_amdgcn_exp2f(-fabsf(t));
     const float u = 1.0f + e;
-    hval = fmaf(__builtin_amdgcn_logf(u), 0.0069314718055994529f, fmaxf(a, 0.0f));
+    hval = fmaf(__builtin_amdgcn_logf(u), 0.0069314718055994529f, relu0(a));
     const float r = __builtin_amdgcn_rcpf(u);
     sval = a >= 0.0f ? r : e * r;
 }
 VDN_DEV float softplus100_fast(float a) {
     const float t = a * 144.26950408889634f;
     const float e = __builtin_amdgcn_exp2f(-fabsf(t));
-    return fmaf(__builtin_amdgcn_logf(1.0f + e), 0.0069314718055994529f, fmaxf(a, 0.0f));
+    return fmaf(__builtin_amdgcn_logf(1.0f + e), 0.0069314718055994529f, relu0(a));
 }
 
 VDN_DEV float softplus100(float a) {
