@@ -295,3 +295,38 @@ def test_val_img_over_a_scene_directory(tmp_path):
             w = out["weights"][:, :128] * out["inside_sphere"]
             zd = out["z_vals"].gather(1, w.argmax(-1, keepdim=True)).cpu().numpy()
             assert np.array_equal(zd, depth.reshape(-1, 1)[s:s + 512])
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_full_size_batch_properties(dev, precision):
+    """BASELINE.json's full size (512 rays x 128 + 32 samples), where the oracle is too slow: size-independent properties.
+    Rays are independent, so rendering the batch in two halves or in a permuted order gives the same per-ray outputs;
+    weights are a sub-probability distribution per ray; z is sorted."""
+    from vdn_train import synth, factory
+    B = 512
+    rend = factory.build_renderer(wdepth=True, device=dev, states=synth.make_all_states(0, wdepth=True), precision=precision)
+    cams = synth.make_cameras(0)
+    o, d = synth.random_pixel_batch(0, 0, 0, B, cams=cams, crop=420)
+    near, far = synth.near_far_from_sphere(o, d)
+    t1, t2 = synth.jitter(0, 0, B)
+    o, d, near, far, t1, t2 = (g(x, dev) for x in (o, d, near, far, t1, t2))
+    bg = torch.ones(1, 3, device=dev)
+    run = lambda idx: rend.render(o[idx], d[idx], near[idx], far[idx], background_rgb=bg, cos_anneal_ratio=0.5,
+                                  t_rand=t1[idx], t_rand_out=t2[idx])
+    keys = ("color_fine", "render_feats", "weights", "weight_sum", "weight_max", "gradients", "z_vals", "cdf_fine", "inside_sphere")
+    with torch.no_grad():
+        full = run(torch.arange(B, device=dev))
+        lo, hi = run(torch.arange(0, 256, device=dev)), run(torch.arange(256, B, device=dev))
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(3)).to(dev)
+        pf = run(perm)
+    for k in keys:
+        assert torch.equal(full[k], torch.cat([lo[k], hi[k]])), k
+        assert torch.equal(full[k][perm], pf[k]), k
+    w = full["weights"]
+    assert (w >= 0).all() and (w.sum(-1) <= 1 + 1e-4).all()      # (1 - alpha + 1e-7) factors: up to 160e-7 above 1
+    assert torch.allclose(full["weight_sum"][:, 0], w.sum(-1), atol=1e-6)
+    assert torch.equal(full["weight_max"][:, 0], w.max(-1).values)
+    assert (full["z_vals"][:, 1:] >= full["z_vals"][:, :-1]).all()
+    col = full["color_fine"]
+    assert torch.isfinite(col).all()          # not range-bound: the NeRF++ background colour has no sigmoid (fields.py:349)
+    assert torch.isfinite(full["gradients"]).all() and float(full["gradient_error"]) >= 0
