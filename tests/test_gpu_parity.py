@@ -330,3 +330,17 @@ def test_full_size_batch_properties(dev, precision):
     col = full["color_fine"]
     assert torch.isfinite(col).all()          # not range-bound: the NeRF++ background colour has no sigmoid (fields.py:349)
     assert torch.isfinite(full["gradients"]).all() and float(full["gradient_error"]) >= 0
+
+
+def test_render_on_a_non_default_stream(env, dev, golden):
+    """The C ABI takes the hipStream_t as a 64-bit handle: launching from a side stream gives the same bits as the default one."""
+    fx = golden("white_v03_c0")
+    rend, _, _ = env(int(fx["seed"]), False, 0.3)
+    a = _render(rend, fx, dev, inject=False)
+    s = torch.cuda.Stream(device=dev)
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        b = _render(rend, fx, dev, inject=False)
+    s.synchronize()
+    for k in ("color_fine", "weights", "gradients"):
+        assert torch.equal(a[k], b[k]), k

@@ -23,7 +23,7 @@ def _strip_comments(text):
 
 
 def parse_header(path=HEADER):
-    """-> (structs: {name: [(field, ctype)]}, functions: {name: n_args})"""
+    """-> (structs: {name: [(field, ctype)]}, functions: {name: [argument ctypes]})"""
     text = _strip_comments(open(path).read())
     structs = {}
     for m in re.finditer(r"typedef\s+struct\s*\{(.*?)\}\s*(\w+)\s*;", text, flags=re.S):
@@ -43,7 +43,13 @@ def parse_header(path=HEADER):
     funcs = {}
     for m in re.finditer(r"\bint\s+(vdn_\w+)\s*\((.*?)\)\s*;", text, flags=re.S):
         args = m.group(2).strip()
-        funcs[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
+        types = []
+        for a in ([] if args in ("", "void") else args.split(",")):
+            if "*" in a:
+                types.append(ctypes.c_void_p)          # struct pointers, device pointers and the hipStream_t handle
+            else:
+                types.append(next(t for n, t in _SCALARS.items() if re.search(r"\b%s\b" % n, a)))
+        funcs[m.group(1)] = types
     return structs, funcs
 
 
@@ -79,10 +85,10 @@ def load():
         raise VdnError("HIP kernel library %s not built. Run `python -m vdn_hip.build` (or "
                        "__graft_entry__.build()); there is no fallback path." % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
-    for fn in FUNCTIONS:
+    for fn, argtypes in FUNCTIONS.items():
         f = getattr(lib, fn)       # AttributeError here = header/library mismatch
         f.restype = ctypes.c_int
-    lib.vdn_adam_step.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int64] + [ctypes.c_float] * 4 + [ctypes.c_int32, ctypes.c_void_p]
+        f.argtypes = argtypes      # from the header: a 64-bit stream handle must not be narrowed to a C int
     if lib.vdn_abi_version() != int(re.search(r"#define\s+VDN_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1)):
         raise VdnError("libvdn_render.so ABI version does not match include/vdn_render.h; rebuild")
     _lib = lib

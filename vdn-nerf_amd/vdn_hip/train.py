@@ -8,6 +8,8 @@ activation the adjoint needs kept in HBM; backward() runs
   -> one batched weight-gradient GEMM -> finalize/scatter -> weight-norm backward
 and returns d loss / d parameter for every parameter, in module.parameters() order.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -58,6 +60,11 @@ class TrainEngine:
         self.P = B * self.N
         self.Q = B * self.T
         self.wdepth = renderer.depth_network is not None
+        use_side = os.environ.get("VDN_SIDE_STREAM", "1") != "0" and torch.device(dev).type == "cuda"
+        self._side = torch.cuda.Stream(device=dev) if use_side else None
+        self._ev_fork = torch.cuda.Event() if use_side else None
+        self._ev_join = torch.cuda.Event() if use_side else None
+        self._pending = False
         precs = {m.precision for m in (renderer.nerf, renderer.sdf_network, renderer.color_network, renderer.depth_network) if m is not None}
         if len(precs) != 1:
             raise ValueError("all networks of a renderer must share one precision, got %s" % sorted(precs))
@@ -290,7 +297,11 @@ class TrainEngine:
             n.density, n.rgb = w["bg_density"].data_ptr(), w["bg_rgb"].data_ptr()
             n.feat = w["bg_feat"].data_ptr() if w["bg_feat"] is not None else None
             n.save_h, n.save_pe, n.save_feature, n.save_vpe, n.save_hv = (w[k].data_ptr() for k in ("nf_h", "nf_pe", "nf_feature", "nf_vpe", "nf_hv"))
-            lib.call("vdn_nerf_mlp_fwd" + self.sfx, n, st)
+            # the NeRF++ background is independent of the SDF / colour path until compositing: run it on the side stream
+            # so the two kernel families fill each other's tail rounds (81 920 background points = 1.25 rounds of the CUs)
+            self._fork()
+            lib.call("vdn_nerf_mlp_fwd" + self.sfx, n, self._side_handle(st))
+            self._side_done()
         self._sdf_forward(rays_o, rays_d)
 
         def rnet(net, out, save_h, small, d_out, module):
@@ -311,10 +322,30 @@ class TrainEngine:
         c.eik_partial, c.eik_out = w["eik_partial"].data_ptr(), w["eik"].data_ptr()
         if self.wdepth:
             c.feat_out = w["feat_out"].data_ptr()
+        self._join()
         lib.call("vdn_alpha_composite_fwd", c, st)
         self._ctx = (rays_o, rays_d, background_rgb, cos_anneal_ratio, z)
         self.generation = getattr(self, "generation", 0) + 1
         return w
+
+    # ---- side stream for the background network (VDN_SIDE_STREAM=0 keeps everything on the caller's stream)
+    def _fork(self):
+        if self._side is not None:
+            self._ev_fork.record(torch.cuda.current_stream())
+            self._side.wait_event(self._ev_fork)
+
+    def _side_handle(self, main_handle):
+        return main_handle if self._side is None else self._side.cuda_stream
+
+    def _side_done(self):
+        if self._side is not None:
+            self._ev_join.record(self._side)
+            self._pending = True
+
+    def _join(self):
+        if self._side is not None and self._pending:
+            torch.cuda.current_stream().wait_event(self._ev_join)
+            self._pending = False
 
     def _sdf_forward(self, rays_o, rays_d):
         """The fused SDF kernel (PE -> 9 layers -> sdf / feature + gradient sweep) with the training-mode saves, on the
@@ -393,6 +424,17 @@ class TrainEngine:
         c.d_var_partial = w["d_var_partial"].data_ptr()
         c.d_variance = self.grad_views[id(r.deviation_network.variance)].data_ptr()
         lib.call("vdn_alpha_composite_bwd", c, st)
+        if r.n_outside > 0:                      # NeRF backward on the side stream, beside the heads' and the SDF backward
+            nb = lib.VdnNerfBwdArgs()
+            nb.blob = self.nets["nerf"].img.blobs["bwd"].data_ptr()
+            nb.g_density, nb.g_rgb = w["d_bg_density"].data_ptr(), w["d_bg_rgb"].data_ptr()
+            nb.g_feat = w["d_bg_feat"].data_ptr() if self.wdepth else None
+            nb.save_h, nb.save_hv = w["nf_h"].data_ptr(), w["nf_hv"].data_ptr()
+            nb.delta_o, nb.delta_v, nb.delta_head, nb.delta_h = (w[k].data_ptr() for k in ("nf_do", "nf_dv", "nf_dhead", "nf_dh"))
+            nb.P = self.Q
+            self._fork()
+            lib.call("vdn_nerf_mlp_bwd" + self.sfx, nb, self._side_handle(st))
+            self._side_done()
 
         def rnet_bwd(net, g_out, out, save_h, dout, dh, d_out, module, accumulate):
             b = lib.VdnRenderNetBwdArgs()
@@ -423,16 +465,7 @@ class TrainEngine:
         fb.P, fb.scale = self.P, float(r.sdf_network.scale)
         lib.call("vdn_sdf_bwd_fbar" + self.sfx, fb, st)
 
-        if r.n_outside > 0:
-            nb = lib.VdnNerfBwdArgs()
-            nb.blob = self.nets["nerf"].img.blobs["bwd"].data_ptr()
-            nb.g_density, nb.g_rgb = w["d_bg_density"].data_ptr(), w["d_bg_rgb"].data_ptr()
-            nb.g_feat = w["d_bg_feat"].data_ptr() if self.wdepth else None
-            nb.save_h, nb.save_hv = w["nf_h"].data_ptr(), w["nf_hv"].data_ptr()
-            nb.delta_o, nb.delta_v, nb.delta_head, nb.delta_h = (w[k].data_ptr() for k in ("nf_do", "nf_dv", "nf_dhead", "nf_dh"))
-            nb.P = self.Q
-            lib.call("vdn_nerf_mlp_bwd" + self.sfx, nb, st)
-
+        self._join()
         self._launch_dw()
         lib.call("vdn_dw_finalize", lib.ptr(self.fin_table), self.n_dw, self.fin_max_M, 0, st)
         lib.call("vdn_dw_finalize", lib.ptr(self.fin_table), self.n_dw, self.fin_max_M, 1, st)
