@@ -189,6 +189,8 @@ def main():
             tf = os.path.join(ROOT, "profiles", "r01_traffic_sdf_fwd_%s%s.json" % (args.precision, tag))
             return json.load(open(tf)).get("hbm_bytes_per_launch") if os.path.exists(tf) else None
         traffic, traffic_inf = traffic_of("_train"), traffic_of("")
+        tdwf = os.path.join(ROOT, "profiles", "r01_traffic_dw_gemm_%s.json" % dtype)
+        traffic_dw = json.load(open(tdwf)).get("hbm_bytes_per_launch") if (os.path.exists(tdwf) and not wdepth) else None
         line = {
             "metric": "rays/sec (512-ray batch, 128 samples/ray)", "value": value, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -208,7 +210,7 @@ def main():
                                               "traffic": traffic_inf}},
             "roofline_dw_gemm": {"bound": "hbm", "kernel": "dw_gemm_%s_kernel (batched split-K weight-gradient GEMM, longest kernel of the step)" % dtype,
                                  "achieved": dw_bytes / tdw / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": dw_bytes / tdw / 8e12,
-                                 "traffic": None, "kernel_ms": tdw * 1e3, "tflops": dw_flops / tdw / 1e12},
+                                 "traffic": traffic_dw, "kernel_ms": tdw * 1e3, "tflops": dw_flops / tdw / 1e12},
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(B, seed, wdepth)

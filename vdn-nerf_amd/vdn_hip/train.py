@@ -60,7 +60,9 @@ class TrainEngine:
         self.P = B * self.N
         self.Q = B * self.T
         self.wdepth = renderer.depth_network is not None
-        use_side = os.environ.get("VDN_SIDE_STREAM", "1") != "0" and torch.device(dev).type == "cuda"
+        # opt-in (VDN_SIDE_STREAM=1): measured gain 0.4 % - both kernel families already fill the CUs - and concurrent kernels
+        # blur the per-kernel rocprof durations the roofline numbers are checked against
+        use_side = os.environ.get("VDN_SIDE_STREAM", "0") == "1" and torch.device(dev).type == "cuda"
         self._side = torch.cuda.Stream(device=dev) if use_side else None
         self._ev_fork = torch.cuda.Event() if use_side else None
         self._ev_join = torch.cuda.Event() if use_side else None
@@ -297,8 +299,8 @@ class TrainEngine:
             n.density, n.rgb = w["bg_density"].data_ptr(), w["bg_rgb"].data_ptr()
             n.feat = w["bg_feat"].data_ptr() if w["bg_feat"] is not None else None
             n.save_h, n.save_pe, n.save_feature, n.save_vpe, n.save_hv = (w[k].data_ptr() for k in ("nf_h", "nf_pe", "nf_feature", "nf_vpe", "nf_hv"))
-            # the NeRF++ background is independent of the SDF / colour path until compositing: run it on the side stream
-            # so the two kernel families fill each other's tail rounds (81 920 background points = 1.25 rounds of the CUs)
+            # the NeRF++ background is independent of the SDF / colour path until compositing: it may run on a side stream
+            # (81 920 background points = 1.25 rounds of the CUs; the tail round could overlap the SDF kernels)
             self._fork()
             lib.call("vdn_nerf_mlp_fwd" + self.sfx, n, self._side_handle(st))
             self._side_done()
@@ -328,7 +330,7 @@ class TrainEngine:
         self.generation = getattr(self, "generation", 0) + 1
         return w
 
-    # ---- side stream for the background network (VDN_SIDE_STREAM=0 keeps everything on the caller's stream)
+    # ---- optional side stream for the background network (VDN_SIDE_STREAM=1; default: everything on the caller's stream)
     def _fork(self):
         if self._side is not None:
             self._ev_fork.record(torch.cuda.current_stream())
