@@ -204,7 +204,7 @@ class TrainEngine:
             K = e["Pn"] * (2 if e.get("A2") is not None else 1)
             splits = max(1, (K + PTS_PER_SPLIT - 1) // PTS_PER_SPLIT)
             if e.get("A2") is not None:
-                splits += splits % 2          # bf16 GEMM: first half of the splits = segment 1, second half = segment 2
+                splits += splits % 2          # first half of the splits = segment 1, second half = segment 2
             lay.append((mt, nt, splits, slab_elems, cs_elems, moff, wg))
             all_maps.append(np.asarray(e["rmap"], np.int32))
             moff_r = moff
@@ -215,7 +215,7 @@ class TrainEngine:
             slab_elems += splits * mt * 32 * nt * 32
             cs_elems += splits * mt * 32
             ntile = ((mt + 3) // 4) * max((nt + 3) // 4, 1)
-            wg += (8 * ((splits + 7) // 8) * ntile) if self.precision == "bf16" else ntile * splits     # bf16: XCD-aware id space
+            wg += 8 * ((splits + 7) // 8) * ntile          # XCD-aware id space (see train_dw_bf16.hip)
         self.dw_total_wgs = wg
         self.maps = torch.from_numpy(np.concatenate(all_maps)).to(dev)
         self.slab = torch.empty(max(slab_elems, 1), dtype=torch.float32, device=dev)
