@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VDN_ABI_VERSION 1
+#define VDN_ABI_VERSION 2
 
 int vdn_abi_version(void);
 
@@ -413,6 +413,28 @@ typedef struct {
     int32_t B, H, W, C, mask_ch, out_ld;
 } VdnGenRaysArgs;
 int vdn_gen_rays(const VdnGenRaysArgs* args_host, void* stream);
+
+/* ---- iso-surface of the lattice u = -sdf (device marching tetrahedra) ---------------------------------------------
+ * Stands in for mcubes.marching_cubes(u, threshold) of renderer.py:36 (PyMCubes is third-party and not part of the
+ * reference tree): every lattice cube is cut into the 6 Kuhn tetrahedra (path 000 -> +e_a -> +e_b -> 111 for the 6
+ * axis orders), which is translation invariant, so neighbouring cubes agree on their shared faces and the surface is
+ * watertight. "Inside" = u > threshold. Two passes around a prefix sum the caller does:
+ *   vdn_mesh_count: counts[cube] = triangles of that cube          (cube = (x*(R-1) + y)*(R-1) + z)
+ *   vdn_mesh_emit:  triangle t of a cube -> tri_pos[offset[cube]+t][3 corners][xyz] in lattice index coordinates and
+ *                   tri_key[..][3] = a * R^3 + b, the (ordered, a < b) lattice-vertex pair of the cut edge: equal keys
+ *                   are the same vertex (bit-identical position), which is how the caller welds the soup.
+ * Triangles are wound so that their normal points from inside (u > threshold) to outside. u is [R][R][R] fp32. */
+typedef struct {
+    const float* u;
+    float threshold;
+    int32_t R;
+    int32_t* counts;           /* [(R-1)^3]   (count pass) */
+    const int64_t* offsets;    /* [(R-1)^3] exclusive prefix sum of counts   (emit pass) */
+    float* tri_pos;            /* [n_tri][3][3] */
+    int64_t* tri_key;          /* [n_tri][3] */
+} VdnMeshArgs;
+int vdn_mesh_count(const VdnMeshArgs* args_host, void* stream);
+int vdn_mesh_emit(const VdnMeshArgs* args_host, void* stream);
 
 #ifdef __cplusplus
 }

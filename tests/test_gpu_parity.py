@@ -344,3 +344,85 @@ def test_render_on_a_non_default_stream(env, dev, golden):
     s.synchronize()
     for k in ("color_fine", "weights", "gradients"):
         assert torch.equal(a[k], b[k]), k
+
+
+def _mesh_stats(V, F):
+    from collections import Counter
+    d = Counter()
+    for a, b in ((0, 1), (1, 2), (2, 0)):
+        for e in zip(F[:, a].tolist(), F[:, b].tolist()):
+            d[e] += 1
+    und = Counter()
+    for (a, b), c in d.items():
+        und[(min(a, b), max(a, b))] += c
+    return max(d.values()), set(und.values()), len(V) - len(und) + len(F)
+
+
+def test_marching_tets_kernel_equals_oracle(dev):
+    """vdn_mesh_count / vdn_mesh_emit against the numpy restatement on a small smooth field: the same triangles, in the same
+    order, bit for bit (positions and edge keys)."""
+    from oracle import marching_tets as omt
+    from vdn_hip import lib, mesh
+    R = 13
+    rng = np.random.default_rng(4)
+    gx = np.linspace(-1, 1, R)
+    X, Y, Z = np.meshgrid(gx, gx, gx, indexing="ij")
+    u = (0.55 - np.sqrt(X * X + 0.8 * Y * Y + 1.3 * Z * Z) + 0.15 * np.sin(3 * X) * np.cos(2 * Y) + 0.02 * rng.standard_normal(X.shape)).astype(np.float32)
+    want_pos, want_key = omt.marching_tets(u, 0.03)
+    ud = torch.tensor(u, device=dev)
+    n = (R - 1) ** 3
+    counts = torch.empty(n, dtype=torch.int32, device=dev)
+    a = lib.VdnMeshArgs()
+    a.u, a.threshold, a.R, a.counts = ud.data_ptr(), 0.03, R, counts.data_ptr()
+    st = torch.cuda.current_stream().cuda_stream
+    lib.call("vdn_mesh_count", a, st)
+    incl = torch.cumsum(counts, 0, dtype=torch.int64)
+    assert int(incl[-1]) == len(want_pos) > 100
+    off = (incl - counts).contiguous()
+    pos = torch.empty(len(want_pos), 3, 3, device=dev)
+    key = torch.empty(len(want_pos), 3, dtype=torch.int64, device=dev)
+    a.offsets, a.tri_pos, a.tri_key = off.data_ptr(), pos.data_ptr(), key.data_ptr()
+    lib.call("vdn_mesh_emit", a, st)
+    assert np.array_equal(key.cpu().numpy(), want_key)
+    np.testing.assert_allclose(pos.cpu().numpy(), want_pos, rtol=0, atol=2e-6)     # fma contraction: within 1 ulp of the lattice scale
+    V, F = mesh.marching_tets(ud, 0.03)
+    Vo, Fo = omt.weld(want_pos, want_key)
+    assert np.array_equal(F.cpu().numpy(), Fo)
+    np.testing.assert_allclose(V.cpu().numpy(), Vo, rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("shape,chi", [("sphere", 2), ("torus", 0)])
+def test_marching_tets_surface_properties(dev, shape, chi):
+    """Size-independent properties at a larger lattice: closed (every edge in exactly two triangles), consistently oriented
+    (every directed edge once), right Euler characteristic, vertices on the level set, normals pointing outwards."""
+    from vdn_hip import mesh
+    R = 72
+    g1 = torch.linspace(-1, 1, R, device=dev)
+    X, Y, Z = torch.meshgrid(g1, g1, g1, indexing="ij")
+    if shape == "sphere":
+        sdf = torch.sqrt(X * X + Y * Y + Z * Z) - 0.7
+    else:
+        sdf = torch.sqrt((torch.sqrt(X * X + Y * Y) - 0.6) ** 2 + Z * Z) - 0.22
+    V, F = mesh.marching_tets(-sdf, 0.0)
+    V, F = V.cpu().numpy().astype(np.float64), F.cpu().numpy()
+    dmax, uses, euler = _mesh_stats(V, F)
+    assert dmax == 1 and uses == {2} and euler == chi
+    h = 2.0 / (R - 1)
+    P = V * h - 1.0
+    if shape == "sphere":
+        r = np.linalg.norm(P, axis=1)
+        assert np.abs(r - 0.7).max() < 0.6 * h * h / 0.7 + 1e-6            # linear interpolation of a curved field: O(h^2)
+        nrm = np.cross(P[F[:, 1]] - P[F[:, 0]], P[F[:, 2]] - P[F[:, 0]])
+        assert (np.sum(nrm * P[F].mean(1), axis=1) > 0).all()
+        area = 0.5 * np.linalg.norm(nrm, axis=1).sum()
+        assert abs(area - 4 * np.pi * 0.49) < 0.01 * 4 * np.pi * 0.49
+
+
+def test_extract_geometry_without_pymcubes(env, dev):
+    rend, _, _ = env(3, True, 0.3)
+    V, F = rend.extract_geometry(torch.tensor([-1.0, -1.0, -1.0]), torch.tensor([1.0, 1.0, 1.0]), resolution=40, threshold=0.0)
+    assert V.shape[1] == 3 and F.shape[1] == 3 and len(F) > 100 and F.max() == len(V) - 1
+    sdf = rend.sdf_network.sdf(torch.tensor(V, dtype=torch.float32, device=dev)).cpu().numpy()
+    assert np.abs(sdf).max() < 2e-2                                        # vertices sit on the network's zero level set
+    dmax, uses, _ = _mesh_stats(V, F)
+    assert dmax == 1 and uses <= {1, 2}                                    # closed except where the surface leaves the box

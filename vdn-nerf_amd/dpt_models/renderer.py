@@ -17,8 +17,8 @@ from vdn_hip import lib
 from dpt_models.fields import _require_gpu, _stream
 
 
-def extract_fields(bound_min, bound_max, resolution, query_func, device=None):
-    """SDF lattice in 64^3 blocks (renderer.py:10-30); `query_func` maps [P,3] device points -> values."""
+def extract_fields_device(bound_min, bound_max, resolution, query_func, device=None):
+    """SDF lattice in 64^3 blocks (renderer.py:10-30), kept on the device; `query_func` maps [P,3] device points -> values."""
     N = 64
     device = device or (bound_min.device if torch.is_tensor(bound_min) and bound_min.is_cuda else torch.device("cuda"))
     lo = [float(v) for v in bound_min]
@@ -26,31 +26,34 @@ def extract_fields(bound_min, bound_max, resolution, query_func, device=None):
     X = torch.linspace(lo[0], hi[0], resolution).split(N)
     Y = torch.linspace(lo[1], hi[1], resolution).split(N)
     Z = torch.linspace(lo[2], hi[2], resolution).split(N)
-    u = np.zeros([resolution, resolution, resolution], dtype=np.float32)
+    u = torch.zeros([resolution, resolution, resolution], dtype=torch.float32, device=device)
     with torch.no_grad():
         for xi, xs in enumerate(X):
             for yi, ys in enumerate(Y):
                 for zi, zs in enumerate(Z):
                     xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
                     pts = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], dim=-1).to(device)
-                    val = query_func(pts).reshape(len(xs), len(ys), len(zs)).cpu().numpy()
+                    val = query_func(pts).reshape(len(xs), len(ys), len(zs))
                     u[xi * N: xi * N + len(xs), yi * N: yi * N + len(ys), zi * N: zi * N + len(zs)] = val
     return u
 
 
+def extract_fields(bound_min, bound_max, resolution, query_func, device=None):
+    """renderer.py:10-30: the lattice as a numpy array, like the reference returns it."""
+    return extract_fields_device(bound_min, bound_max, resolution, query_func, device).cpu().numpy()
+
+
 def extract_geometry(bound_min, bound_max, resolution, threshold, query_func):
-    """renderer.py:33-41. Marching cubes itself is the third-party PyMCubes (not part of this path)."""
-    u = extract_fields(bound_min, bound_max, resolution, query_func)
-    try:
-        import mcubes
-    except ImportError as e:
-        raise RuntimeError("extract_geometry needs PyMCubes for marching cubes (as the reference does); "
-                           "use extract_fields() for the SDF lattice alone") from e
-    vertices, triangles = mcubes.marching_cubes(u, threshold)
+    """renderer.py:33-41 -> (vertices [V,3] float64 in world coordinates, triangles [F,3]). The reference triangulates with
+    the third-party PyMCubes; here the iso-surface is extracted on the device by marching tetrahedra (vdn_hip.mesh): the
+    same level set as a closed, consistently oriented, welded mesh, with a different (finer) triangulation."""
+    from vdn_hip import mesh
+    u = extract_fields_device(bound_min, bound_max, resolution, query_func)
+    vertices, triangles = mesh.marching_tets(u, threshold)
     b_max_np = np.asarray([float(v) for v in bound_max])
     b_min_np = np.asarray([float(v) for v in bound_min])
-    vertices = vertices / (resolution - 1.0) * (b_max_np - b_min_np)[None, :] + b_min_np[None, :]
-    return vertices, triangles
+    vertices = vertices.cpu().numpy().astype(np.float64) / (resolution - 1.0) * (b_max_np - b_min_np)[None, :] + b_min_np[None, :]
+    return vertices, triangles.cpu().numpy()
 
 
 class _RenderCoreFn(torch.autograd.Function):

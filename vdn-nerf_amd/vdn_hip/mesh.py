@@ -1,0 +1,37 @@
+"""Iso-surface of a device lattice through vdn_mesh_count / vdn_mesh_emit (marching tetrahedra, include/vdn_render.h);
+the stand-in for mcubes.marching_cubes of reference renderer.py:36. The prefix sum and the vertex welding are torch ops
+on the device; nothing runs on the host."""
+import torch
+
+from . import lib
+
+
+def marching_tets(u, threshold=0.0):
+    """u [R,R,R] fp32 CUDA tensor -> (vertices [V,3] fp32 in lattice index coordinates, triangles [F,3] int64)."""
+    if not (torch.is_tensor(u) and u.is_cuda and u.dim() == 3 and u.shape[0] == u.shape[1] == u.shape[2]):
+        raise ValueError("marching_tets needs a cubic [R,R,R] CUDA tensor")
+    u = u.contiguous().float()
+    R = u.shape[0]
+    if R < 2:
+        raise ValueError("lattice resolution must be at least 2")
+    st = torch.cuda.current_stream().cuda_stream
+    n = (R - 1) ** 3
+    counts = torch.empty(n, dtype=torch.int32, device=u.device)
+    a = lib.VdnMeshArgs()
+    a.u, a.threshold, a.R, a.counts = u.data_ptr(), float(threshold), R, counts.data_ptr()
+    lib.call("vdn_mesh_count", a, st)
+    incl = torch.cumsum(counts, 0, dtype=torch.int64)
+    n_tri = int(incl[-1].item())
+    if n_tri == 0:
+        return torch.zeros(0, 3, device=u.device), torch.zeros(0, 3, dtype=torch.int64, device=u.device)
+    offsets = (incl - counts).contiguous()
+    pos = torch.empty(n_tri, 3, 3, dtype=torch.float32, device=u.device)
+    key = torch.empty(n_tri, 3, dtype=torch.int64, device=u.device)
+    a.offsets, a.tri_pos, a.tri_key = offsets.data_ptr(), pos.data_ptr(), key.data_ptr()
+    lib.call("vdn_mesh_emit", a, st)
+    # weld: one vertex per cut lattice edge
+    uniq, inv = torch.unique(key.reshape(-1), return_inverse=True)
+    first = torch.full((uniq.numel(),), n_tri * 3, dtype=torch.int64, device=u.device)
+    first.scatter_reduce_(0, inv, torch.arange(n_tri * 3, device=u.device), reduce="amin")
+    vertices = pos.reshape(-1, 3)[first]
+    return vertices, inv.reshape(n_tri, 3)
