@@ -197,7 +197,12 @@ __global__ __launch_bounds__(kRayWaves * 64) void merge_kernel(MergeArgs a) {
     for (int j = lane; j < K; j += 64) zb[j] = a.new_z[(long)r * a.K + j];
     __builtin_amdgcn_wave_barrier();
     const bool has_sdf = a.sdf != nullptr;
-    // stable ranks: old elements precede equal new ones (position in the concatenation decides ties)
+    // The old row is sorted in every call render() makes (coarse z, earlier merges), so an old element's rank among the
+    // old ones is its index and a new element's is a binary search; an unsorted row (possible through z_vals_inject)
+    // takes the counting path. Both give the stable ranks of cat + sort: old elements precede equal new ones.
+    bool sorted_here = true;
+    for (int i = lane; i + 1 < M; i += 64) sorted_here &= za[i] <= za[i + 1];
+    const bool old_sorted = __all(sorted_here);
     float oz[kEPL], os[kEPL];
     int opos[kEPL];
 #pragma unroll
@@ -206,8 +211,11 @@ __global__ __launch_bounds__(kRayWaves * 64) void merge_kernel(MergeArgs a) {
         opos[e] = -1;
         if (i < M) {
             const float v = za[i];
-            int cnt = 0;
-            for (int k = 0; k < M; ++k) cnt += (za[k] < v) | ((za[k] == v) & (k < i));
+            int cnt = i;
+            if (!old_sorted) {
+                cnt = 0;
+                for (int k = 0; k < M; ++k) cnt += (za[k] < v) | ((za[k] == v) & (k < i));
+            }
             for (int j = 0; j < K; ++j) cnt += zb[j] < v;
             opos[e] = cnt;
             oz[e] = v;
@@ -219,7 +227,16 @@ __global__ __launch_bounds__(kRayWaves * 64) void merge_kernel(MergeArgs a) {
     if (lane < K) {
         const float v = zb[lane];
         int cnt = 0;
-        for (int k = 0; k < M; ++k) cnt += za[k] <= v;
+        if (old_sorted) {
+            int lo = 0, hi = M;                       // first index with za[idx] > v  ==  #(za <= v)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (za[mid] <= v) lo = mid + 1; else hi = mid;
+            }
+            cnt = lo;
+        } else {
+            for (int k = 0; k < M; ++k) cnt += za[k] <= v;
+        }
         for (int j = 0; j < K; ++j) cnt += (zb[j] < v) | ((zb[j] == v) & (j < lane));
         npos = cnt;
         nz = v;
