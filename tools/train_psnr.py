@@ -38,8 +38,9 @@ def validate():
 
 log = []
 t0 = time.time()
+order = (synth.uniform(seed, "trainperm", (steps,)) * 40).astype(np.int64) % 40
 for it in range(steps):
-    img = int(synth.uniform(seed, "trainperm", (steps,))[it] * 40) % 40
+    img = int(order[it])
     if img == 7:
         img = 8                                   # view 7 is held out
     o, d = synth.random_pixel_batch(seed, it, img, B, cams=cams, crop=CROP)
