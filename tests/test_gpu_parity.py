@@ -426,3 +426,19 @@ def test_extract_geometry_without_pymcubes(env, dev):
     assert np.abs(sdf).max() < 2e-2                                        # vertices sit on the network's zero level set
     dmax, uses, _ = _mesh_stats(V, F)
     assert dmax == 1 and uses <= {1, 2}                                    # closed except where the surface leaves the box
+
+
+def test_smoke_entry_and_library_loaded_before_torch():
+    """The driver's smoke() hook, and a fresh process that loads the kernel library before it ever imports torch itself
+    (the library must still bind to torch's HIP runtime)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import __graft_entry__ as g
+    g.smoke()
+    code = ("import sys; sys.path.insert(0, %r); from vdn_hip import lib; lib.load(); import torch; "
+            "from vdn_train import synth, factory; r = factory.build_renderer(device=torch.device('cuda:0'), states=synth.make_all_states(0)); "
+            "print(tuple(r.sdf_network.sdf(torch.zeros(4, 3, device='cuda:0')).shape))" % os.path.join(root, "vdn-nerf_amd"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "(4, 1)" in out.stdout, out.stderr[-2000:]

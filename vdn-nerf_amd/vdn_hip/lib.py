@@ -81,6 +81,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: the library must bind to the HIP runtime torch has loaded (its own copy of libamdhip64); loaded the other
+    # way round the process ends up with two runtimes and every launch fails with hipErrorNoDevice
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise VdnError("HIP kernel library %s not built. Run `python -m vdn_hip.build` (or "
                        "__graft_entry__.build()); there is no fallback path." % LIB_PATH)
