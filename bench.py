@@ -202,8 +202,8 @@ def main():
                        "flop_per_ray": flop_per_ray, "allreduce_bytes": trainer.param_flat.numel() * 4},
             "model_flops_per_s": value * flop_per_ray,
             "forward_only_rays_per_s": fwd_rays_per_s, "final_loss": loss_final,
-            "roofline": {"bound": "mfma", "kernel": "sdf_fwd_kernel<%s,1,4> (fused PE + SDF MLP + gradient sweep, 65536 points, "
-                                                   "training-mode launch of the timed step)" % ("F32" if dtype == "f32" else "BF16"),
+            "roofline": {"bound": "mfma", "kernel": "sdf_fwd_kernel<%s> (fused PE + SDF MLP + gradient sweep, 65536 points, "
+                                                   "training-mode launch of the timed step)" % ("F32,1,4,false" if dtype == "f32" else "BF16,1,4,true"),
                          "achieved": flops / tk / 1e12, "peak": PEAK[dtype] / 1e12, "unit": "TFLOP/s",
                          "frac": flops / tk / PEAK[dtype], "traffic": traffic, "kernel_ms": tk * 1e3,
                          "inference_launch": {"kernel_ms": tk_inf * 1e3, "achieved": flops / tk_inf / 1e12, "frac": flops / tk_inf / PEAK[dtype],

@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VDN_ABI_VERSION 2
+#define VDN_ABI_VERSION 3
 
 int vdn_abi_version(void);
 
@@ -71,7 +71,9 @@ typedef struct {
     float* sdf;                /* out, see sdf_ld */
     void* feat;               /* [P,256] out (mode 1) */
     float* normals;            /* [P,3] out (mode 1) */
-    void* S;                  /* [8,P,256] workspace: softplus'(pre-activation) per hidden layer (mode 1) */
+    void* S;                  /* [8,P,256] workspace: softplus'(pre-activation) per hidden layer (mode 1). The bf16 entry point
+                               * leaves it untouched when H is given: softplus' is then re-derived from H (1 - exp(-100 h)),
+                               * here and - via s_from_h - in the backward chains, which saves writing 8 planes */
     const float* w8row;        /* [256] row 0 of the last layer's effective weight (mode 1) */
     /* training-mode saves (mode 1), all optional (NULL = not saved): */
     void* H;                  /* [8,P,256] H[l] = softplus output of layer l (= input of layer l+1) */
@@ -277,10 +279,11 @@ typedef struct {
     int32_t P;
     float scale;
     const float* g_normals;    /* [P,3] d loss / d (d sdf/d x) */
-    const void* S;            /* [8,P,256] from the forward */
+    const void* S;            /* [8,P,256] from the forward: softplus' planes, or - with s_from_h - the saved activations H */
     const void* V;            /* [8,P,256] from the forward */
     void* UB;                 /* out, see above */
     void* EX;                 /* out */
+    int32_t s_from_h;          /* 1: S points at the H planes; softplus' = 1 - exp(-100 h) is evaluated in the kernel */
 } VdnSdfRbarArgs;
 int vdn_sdf_bwd_rbar_f32(const VdnSdfRbarArgs* args_host, void* stream);
 int vdn_sdf_bwd_rbar_bf16(const VdnSdfRbarArgs* args_host, void* stream);   /* bf16-MFMA variant: bf16 chunk blob, bf16 activation workspaces */
@@ -289,11 +292,12 @@ typedef struct {
     const char* blob;          /* 'fbar' stream: W8^T, W7^T .. W1^T */
     const float* g_sdf;        /* [P] */
     const void* g_feat;       /* [P,256] */
-    const void* S;            /* [8,P,256] */
+    const void* S;            /* [8,P,256] softplus' planes, or - with s_from_h - the saved activations H */
     const void* EX;           /* [8,P,256] from rbar */
     void* AB;                 /* out, see above */
     int32_t P;
     float scale;
+    int32_t s_from_h;          /* as in VdnSdfRbarArgs */
 } VdnSdfFbarArgs;
 int vdn_sdf_bwd_fbar_f32(const VdnSdfFbarArgs* args_host, void* stream);
 int vdn_sdf_bwd_fbar_bf16(const VdnSdfFbarArgs* args_host, void* stream);   /* bf16-MFMA variant: bf16 chunk blob, bf16 activation workspaces */

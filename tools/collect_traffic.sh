@@ -19,7 +19,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 # counters are in KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B => x2 (guide, section HBM)
 out = {"kernel": "sdf_fwd_kernel<%s,1> 65536 points" % prec, "fetch_kib_raw": res["FETCH_SIZE"], "write_kib_raw": res["WRITE_SIZE"],
        "hbm_bytes_per_launch": (2.0 * res["FETCH_SIZE"] + res["WRITE_SIZE"]) * 1024.0,
-       "note": "FETCH_SIZE doubled per the gfx950 correction; " + ("training-mode launch (saves S, H, PE planes)" if which == "sdf1t" else "inference-mode launch (S workspace only)")}
+       "note": "FETCH_SIZE doubled per the gfx950 correction; " + ("training-mode launch (saves H, V, PE planes; fp32 also S)" if which == "sdf1t" else "inference-mode launch (S workspace only)")}
 print(json.dumps(out))
 open("gpurun_out/traffic_%s%s.json" % (prec, "_train" if which == "sdf1t" else ""), "w").write(json.dumps(out))
 PY

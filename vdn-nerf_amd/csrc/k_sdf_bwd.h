@@ -30,6 +30,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_rbar_ke
     const long p = ok ? p_raw : (long)a.P - 1;
     const long Pn = P::rows(a.P), PS = Pn * 256;
     const ST* S = reinterpret_cast<const ST*>(a.S);
+    const bool from_h = a.s_from_h != 0;
     const ST* V = reinterpret_cast<const ST*>(a.V);
     ST* EX = reinterpret_cast<ST*>(a.EX);
 
@@ -93,12 +94,13 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_rbar_ke
     };
     // epilogue of layer l: ub_{l+1} = vb * s_l -> D (registers) and dst (HBM); ex_l -> EX[l]
     auto epi = [&](auto& D, ST* dst, int ld, int l) VDN_INL {
-        return [&D, dst, ld, l, EX, PS, p, ok, h](int nt, const f32x16& acc, const SV& sv) VDN_INL {
+        return [&D, dst, ld, l, EX, PS, p, ok, h, from_h](int nt, const f32x16& acc, const SV& sv) VDN_INL {
             f32x16 ub, ex;
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-                ub[t] = acc[t] * sv.s[t];
-                ex[t] = 100.0f * acc[t] * sv.v[t] * (1.0f - sv.s[t]);
+                const float s = sprime(sv.s[t], from_h);
+                ub[t] = acc[t] * s;
+                ex[t] = 100.0f * acc[t] * sv.v[t] * (1.0f - s);
             }
             D.set(nt, ub);
             P::store_tile(dst, p, ld, nt, h, ub, ok);
@@ -137,6 +139,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_fbar_ke
     const long p = ok ? p_raw : (long)a.P - 1;
     const long Pn = P::rows(a.P), PS = Pn * 256;
     const ST* S = reinterpret_cast<const ST*>(a.S);
+    const bool from_h = a.s_from_h != 0;
     const ST* EX = reinterpret_cast<const ST*>(a.EX);
     const ST* g_feat = reinterpret_cast<const ST*>(a.g_feat);
     ST* ab8 = reinterpret_cast<ST*>(a.AB);
@@ -167,10 +170,10 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_fbar_ke
     };
     auto epi = [&](auto& D, int l) VDN_INL {       // ab_l = hb_{l+1} * s_l + ex_l
         ST* dst = ab(l);
-        return [&D, dst, p, ok, h](int nt, const f32x16& acc, const SE& se) VDN_INL {
+        return [&D, dst, p, ok, h, from_h](int nt, const f32x16& acc, const SE& se) VDN_INL {
             f32x16 o;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) o[t] = acc[t] * se.s[t] + se.e[t];
+            for (int t = 0; t < 16; ++t) o[t] = acc[t] * sprime(se.s[t], from_h) + se.e[t];
             D.set(nt, o);
             P::store_tile(dst, p, 256, nt, h, o, ok);
         };
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_fbar_ke
                 if (nt < 7) {
                     f32x16 o;
 #pragma unroll
-                    for (int t = 0; t < 16; ++t) o[t] = acc[t] * se.s[t] + se.e[t];
+                    for (int t = 0; t < 16; ++t) o[t] = acc[t] * sprime(se.s[t], from_h) + se.e[t];
                     Y.set(nt, o);
                     P::store_tile(dst, p, 256, nt, h, o, ok);
                 }

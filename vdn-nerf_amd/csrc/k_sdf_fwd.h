@@ -11,7 +11,8 @@ namespace vdn {
 
 // MODE 0: sdf only; 1: sdf + feature + normals (+ training saves). NW = waves per workgroup (32 points each):
 // small launches use fewer waves per workgroup so that the grid still covers the 256 CUs.
-template <class P, int MODE, int NW>
+// DERIVE (bf16 training launch only): softplus' is not stored but re-derived from the saved activations.
+template <class P, int MODE, int NW, bool DERIVE = false>
 __global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(SdfArgs a) {
     using ST = typename P::store_t;
     constexpr int kSlot = P::stride(9);
@@ -43,6 +44,9 @@ __global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(Sdf
     constexpr bool SV = (MODE == 1);
     ST* S = reinterpret_cast<ST*>(a.S);
     ST* Hs = reinterpret_cast<ST*>(a.H);
+    // bf16 training launch: softplus' is re-derived from the saved activations instead of being stored (mlp_engine.h)
+    constexpr bool derive = DERIVE;
+    const ST* Ssrc = derive ? Hs : S;
     ST* Vs = reinterpret_cast<ST*>(a.V);
     const long PS = P::plane(a.P, 256);
 
@@ -78,16 +82,16 @@ __global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(Sdf
 #endif
                 }
             },
-            [&D, l, S, Hs, PS, p, ok, h](int nt, const HS& o, int) VDN_INL {
+            [&D, l, S, Hs, PS, p, ok, h, derive](int nt, const HS& o, int) VDN_INL {
                 D.set(nt, o.hv);
                 if constexpr (SV) {
-                    P::store_tile(S + l * PS, p, 256, nt, h, o.sv, ok);
+                    if (!derive) P::store_tile(S + l * PS, p, 256, nt, h, o.sv, ok);
                     if (Hs != nullptr) P::store_tile(Hs + l * PS, p, 256, nt, h, o.hv, ok);
                 }
             });
     };
     constexpr int C2 = P::chunk_bytes(2), C7 = P::chunk_bytes(7), C8 = P::chunk_bytes(8), C9 = P::chunk_bytes(9);
-    const int est_h = SV ? (Hs != nullptr ? 8 : 4) : 0;     // stores per hidden-layer tile (S, and H when training)
+    const int est_h = SV ? (Hs != nullptr && !derive ? 8 : 4) : 0;     // stores per hidden-layer tile (S and / or H)
     const int est_v = Vs != nullptr ? 4 : 0;                // stores per sweep tile (V when training)
     put_pe(0);
     ws.start();
@@ -123,21 +127,21 @@ __global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(Sdf
 #pragma unroll
         for (int kt = 0; kt < 8; ++kt) {
             const f32x16 w8 = F32::load_tile(a.w8row, 0, 0, kt, h);
-            const f32x16 s7 = P::load_tile(S + 7 * PS, p, 256, kt, h);
+            const f32x16 s7 = P::load_tile(Ssrc + 7 * PS, p, 256, kt, h);
             f32x16 v7;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) v7[t] = w8[t] * inv_scale * s7[t];
+            for (int t = 0; t < 16; ++t) v7[t] = w8[t] * inv_scale * sprime(s7[t], derive);
             Y.set(kt, v7);
             if (Vs != nullptr) P::store_tile(Vs + 7 * PS, p, 256, kt, h, v7, ok);
         }
         auto loadS = [&](int layer) VDN_INL {
-            return [=](int nt) VDN_INL { return P::load_tile(S + layer * PS, p, 256, nt, h); };
+            return [=](int nt) VDN_INL { return P::load_tile(Ssrc + layer * PS, p, 256, nt, h); };
         };
         auto mulInto = [&](auto& D, int layer) VDN_INL {     // D <- v_layer = u (.) s_layer; optionally kept for the backward
-            return [&D, layer, Vs, PS, p, ok, h](int nt, const f32x16& acc, const f32x16& sv) VDN_INL {
+            return [&D, layer, Vs, PS, p, ok, h, derive](int nt, const f32x16& acc, const f32x16& sv) VDN_INL {
                 f32x16 v;
 #pragma unroll
-                for (int t = 0; t < 16; ++t) v[t] = acc[t] * sv[t];
+                for (int t = 0; t < 16; ++t) v[t] = acc[t] * sprime(sv[t], derive);
                 D.set(nt, v);
                 if (Vs != nullptr) P::store_tile(Vs + layer * PS, p, 256, nt, h, v, ok);
             };
@@ -166,12 +170,12 @@ __global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(Sdf
         {   // W4^T: 9 output tiles = [h4 part (7 tiles) | PE part (2 tiles)]
             f32x16 UPE[2];
             dense<P, 8, 9, C7, false>(ws, X, 0,
-                [&](int nt) VDN_INL { return nt < 7 ? P::load_tile(S + 3 * PS, p, 256, nt, h) : f32x16{}; },
+                [&](int nt) VDN_INL { return nt < 7 ? P::load_tile(Ssrc + 3 * PS, p, 256, nt, h) : f32x16{}; },
                 [&](int nt, const f32x16& acc, const f32x16& sv) VDN_INL {
                     if (nt < 7) {
                         f32x16 v;
 #pragma unroll
-                        for (int t = 0; t < 16; ++t) v[t] = acc[t] * sv[t];
+                        for (int t = 0; t < 16; ++t) v[t] = acc[t] * sprime(sv[t], derive);
                         Y.set(nt, v);
                         if (Vs != nullptr) P::store_tile(Vs + 3 * PS, p, 256, nt, h, v, ok);
                     } else {
@@ -193,13 +197,13 @@ __global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(Sdf
     }
 }
 
-template <class P, int MODE, int NW>
+template <class P, int MODE, int NW, bool DERIVE = false>
 void launch_sdf_nw(const VdnSdfArgs* args, hipStream_t stream) {
     const size_t lds = VDN_NSLOT * P::stride(9);
-    static bool once = (allow_big_lds(sdf_fwd_kernel<P, MODE, NW>, lds), true);
+    static bool once = (allow_big_lds(sdf_fwd_kernel<P, MODE, NW, DERIVE>, lds), true);
     (void)once;
     const int grid = (args->P + NW * 32 - 1) / (NW * 32);
-    hipLaunchKernelGGL((sdf_fwd_kernel<P, MODE, NW>), dim3(grid), dim3(NW * 64), lds, stream, *args);
+    hipLaunchKernelGGL((sdf_fwd_kernel<P, MODE, NW, DERIVE>), dim3(grid), dim3(NW * 64), lds, stream, *args);
 }
 
 template <class P>
@@ -215,7 +219,12 @@ int launch_sdf_fwd(int mode, const VdnSdfArgs* args, void* stream_) {
         launch_sdf_nw<P, 0, 4>(args, stream);
     } else if (mode == 1) {
         if (!args->sdf || !args->feat || !args->normals || !args->S || !args->w8row) return -3;
-        launch_sdf_nw<P, 1, P::kWaves>(args, stream);
+        if constexpr (P::kDeriveS) {
+            if (args->H != nullptr) launch_sdf_nw<P, 1, P::kWaves, true>(args, stream);
+            else launch_sdf_nw<P, 1, P::kWaves, false>(args, stream);
+        } else {
+            launch_sdf_nw<P, 1, P::kWaves, false>(args, stream);
+        }
     } else {
         return -4;
     }

@@ -102,6 +102,11 @@ struct WStream {
     }
 };
 
+// softplus' from a loaded plane value: the value itself, or 1 - exp(-100 h) when the plane holds h = softplus(a)
+VDN_DEV float sprime(float raw, bool from_h) {
+    return from_h ? 1.0f - __builtin_amdgcn_exp2f(-144.26950408889634f * raw) : raw;
+}
+
 struct NoPre {
     VDN_DEV int operator()(int) const { return 0; }
 };
@@ -112,6 +117,7 @@ struct F32 {
     static constexpr int kMinWavesPerEU = 1;
     static constexpr bool kAccurateTrig = true;     // ocml sincosf in the positional encoding
     static constexpr bool kOverlapEpilogue = false; // an f32 tile's MFMAs take 4x longer than its epilogue: nothing to hide
+    static constexpr bool kDeriveS = false;         // the parity path keeps softplus' exactly as the forward computed it
     static constexpr int chunk_bytes(int KT) { return KT * 4096 + 1024; }
     static constexpr int stride(int KTMAX) { return (chunk_bytes(KTMAX) + 4095) / 4096 * 4096; }   // uniform chunk stride
     using store_t = float;
@@ -199,6 +205,10 @@ struct BF16 {
     // A softplus tile epilogue is ~110 VALU instructions against 16 MFMAs: elementwise epilogues (ElemEpi) are issued in
     // the shadow of the NEXT tile's MFMAs (mma_slots), one accumulator register per MFMA.
     static constexpr bool kOverlapEpilogue = true;
+    // training: softplus' is not stored; consumers re-derive it from the saved activation h = softplus(a):
+    // sigma(100 a) = 1 - exp(-100 h). From a bf16 h this is at least as accurate as a bf16-rounded sigma (the relative
+    // error of h carries over for small h and is damped by exp(-100 h) for large h) and saves writing 8 planes per step.
+    static constexpr bool kDeriveS = true;
 #ifndef VDN_SLOT_GROUP
 #define VDN_SLOT_GROUP 2
 #endif

@@ -459,12 +459,16 @@ class TrainEngine:
         rb.blob = img.blobs["full"].data_ptr()
         rb.rays_o, rb.rays_d, rb.z, rb.n_per_ray, rb.z_ld = rays_o.data_ptr(), rays_d.data_ptr(), w["mid_z"].data_ptr(), self.N, self.N
         rb.P, rb.scale = self.P, float(r.sdf_network.scale)
-        rb.g_normals, rb.S, rb.V, rb.UB, rb.EX = w["d_normals"].data_ptr(), w["S"].data_ptr(), w["V"].data_ptr(), w["UB"].data_ptr(), w["EX"].data_ptr()
+        # bf16: the forward did not store softplus'; the chains re-derive it from the saved activations (mlp_engine.h: kDeriveS)
+        s_from_h = int(self.precision == "bf16")
+        s_planes = w["H"] if s_from_h else w["S"]
+        rb.g_normals, rb.S, rb.V, rb.UB, rb.EX = w["d_normals"].data_ptr(), s_planes.data_ptr(), w["V"].data_ptr(), w["UB"].data_ptr(), w["EX"].data_ptr()
+        rb.s_from_h = s_from_h
         lib.call("vdn_sdf_bwd_rbar" + self.sfx, rb, st)
         fb = lib.VdnSdfFbarArgs()
         fb.blob = img.blobs["fbar"].data_ptr()
-        fb.g_sdf, fb.g_feat, fb.S, fb.EX, fb.AB = w["d_sdf"].data_ptr(), w["d_featvec"].data_ptr(), w["S"].data_ptr(), w["EX"].data_ptr(), w["AB"].data_ptr()
-        fb.P, fb.scale = self.P, float(r.sdf_network.scale)
+        fb.g_sdf, fb.g_feat, fb.S, fb.EX, fb.AB = w["d_sdf"].data_ptr(), w["d_featvec"].data_ptr(), s_planes.data_ptr(), w["EX"].data_ptr(), w["AB"].data_ptr()
+        fb.P, fb.scale, fb.s_from_h = self.P, float(r.sdf_network.scale), s_from_h
         lib.call("vdn_sdf_bwd_fbar" + self.sfx, fb, st)
 
         self._join()
