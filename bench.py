@@ -199,7 +199,11 @@ def main():
                                    "all-reduce + Adam): SDF 8x256 + colour 4x256 %s+ NeRF 8x256, 512 rays x (64 coarse + 64 importance "
                                    "+ 32 outside) per GPU per step" % (args.config, "+ VDN head 4x256->96 " if wdepth else ""),
                        "rays_per_gpu": B, "samples_per_ray": 128, "outside_samples": 32, "parallelism": "dp%d" % world,
-                       "flop_per_ray": flop_per_ray, "allreduce_bytes": trainer.param_flat.numel() * 4},
+                       "flop_per_ray": flop_per_ray, "allreduce_bytes": trainer.param_flat.numel() * 4,
+                       # flop_per_ray is SURVEY.md 8d's algorithmic count (all 160 background samples per ray); background
+                       # samples that render_core multiplies by zero (inside the unit sphere) are not evaluated
+                       "background_points_evaluated_last_step": int(eng.w["bg_active"][1].item()),
+                       "background_points_total": eng.Q},
             "model_flops_per_s": value * flop_per_ray,
             "forward_only_rays_per_s": fwd_rays_per_s, "final_loss": loss_final,
             "roofline": {"bound": "mfma", "kernel": "sdf_fwd_kernel<%s> (fused PE + SDF MLP + gradient sweep, 65536 points, "

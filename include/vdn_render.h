@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VDN_ABI_VERSION 3
+#define VDN_ABI_VERSION 4
 
 int vdn_abi_version(void);
 
@@ -125,6 +125,11 @@ typedef struct {
     void* save_hv;            /* [P,128] views_linears.0 output (post-ReLU) */
     int32_t n_per_ray;
     int32_t P;
+    /* Optional active-point list (vdn_background_active): only points active_idx[0 .. *n_active) are evaluated; density /
+     * rgb / feat are written at their dense positions (the others keep their previous, finite contents - the compositor
+     * multiplies them by zero), the training saves are written in COMPACT order (row q holds point active_idx[q]). */
+    const int32_t* active_idx; /* [P] or NULL = all points */
+    const int32_t* n_active;   /* device scalar */
 } VdnNerfArgs;
 int vdn_nerf_mlp_fwd_f32(const VdnNerfArgs* args_host, void* stream);
 int vdn_nerf_mlp_fwd_bf16(const VdnNerfArgs* args_host, void* stream);   /* bf16-MFMA variant: bf16 chunk blob, bf16 activation workspaces */
@@ -256,6 +261,9 @@ typedef struct {
     void* delta_head;         /* [P,288] delta of [feature_linear (256) | alpha_linear (1)] */
     void* delta_h;            /* [8,P,256] deltas of pts_linears.0..7 */
     int32_t P;
+    /* as in VdnNerfArgs: g_* are read at the dense positions, saves and deltas are in compact order */
+    const int32_t* active_idx;
+    const int32_t* n_active;
 } VdnNerfBwdArgs;
 int vdn_nerf_mlp_bwd_f32(const VdnNerfBwdArgs* args_host, void* stream);
 int vdn_nerf_mlp_bwd_bf16(const VdnNerfBwdArgs* args_host, void* stream);   /* bf16-MFMA variant: bf16 chunk blob, bf16 activation workspaces */
@@ -316,6 +324,7 @@ typedef struct {
     int32_t _pad;
     float* slab;                          /* [splits, m_tiles*32, n_tiles*32] partial products */
     float* colsum;                        /* [splits, m_tiles*32] partial column sums of A1, or NULL */
+    const int32_t* P_dev;                 /* optional device scalar: contract over the first min(P, *P_dev) rows only */
 } VdnDwDesc;
 int vdn_dw_gemm_f32(const VdnDwDesc* descs_dev, int n_desc, int total_wgs, void* stream);
 /* bf16 variant: A/B are bf16 row-major; with two segments `splits` must be even (first half = segment 1). */
@@ -417,6 +426,24 @@ typedef struct {
     int32_t B, H, W, C, mask_ch, out_ld;
 } VdnGenRaysArgs;
 int vdn_gen_rays(const VdnGenRaysArgs* args_host, void* stream);
+
+/* ---- background samples that can reach the image -------------------------------------------------------------------
+ * render_core blends the NeRF++ background into the first N (inside) samples with weight (1 - inside_sphere)
+ * (renderer.py:284-299): where the section mid-point lies inside the unit sphere the background network's output is
+ * multiplied by exactly zero, forward and backward. This kernel lists the other points - sample s < N of ray r is active
+ * iff |rays_o + rays_d * mid_z[r,s]| >= 1 (the compositor's own test, same arithmetic), samples s >= N always - in
+ * ascending dense order p = r*T + s (deterministic), so the background network can skip the rest without changing one
+ * bit of render()'s outputs or gradients. */
+typedef struct {
+    const float* rays_o;       /* [B,3] */
+    const float* rays_d;       /* [B,3] */
+    const float* mid_z;        /* [B,N] section mid-points of the inside samples */
+    int32_t B, N, T;
+    int32_t* active_idx;       /* [B*T] out */
+    int32_t* n_active;         /* [1] out */
+    int32_t* ray_counts;       /* [B] scratch */
+} VdnBackgroundActiveArgs;
+int vdn_background_active(const VdnBackgroundActiveArgs* args_host, void* stream);
 
 /* ---- iso-surface of the lattice u = -sdf (device marching tetrahedra) ---------------------------------------------
  * Stands in for mcubes.marching_cubes(u, threshold) of renderer.py:36 (PyMCubes is third-party and not part of the

@@ -442,3 +442,40 @@ def test_smoke_entry_and_library_loaded_before_torch():
             "print(tuple(r.sdf_network.sdf(torch.zeros(4, 3, device='cuda:0')).shape))" % os.path.join(root, "vdn-nerf_amd"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "(4, 1)" in out.stdout, out.stderr[-2000:]
+
+
+def test_background_active_list_and_bitwise_equivalence(env, dev, golden, monkeypatch):
+    """The NeRF++ background network skips the samples render_core multiplies by (1 - inside_sphere) = 0
+    (renderer.py:284-299). (1) The device list is exactly {inside samples outside the unit sphere} + {outside samples}, in
+    ascending order. (2) Rendering with and without the skip gives bit-identical outputs and parameter gradients."""
+    from dpt_models.renderer import background_active
+    fx = golden("wdepth_v03_c05")
+    rend, _, _ = env(int(fx["seed"]), True, 0.3)
+    o, d, near, far = (g(fx[k], dev) for k in ("rays_o", "rays_d", "near", "far"))
+    kw = dict(background_rgb=torch.ones(1, 3, device=dev), cos_anneal_ratio=0.5, t_rand=g(fx["t_rand"], dev), t_rand_out=g(fx["t_rand_out"], dev))
+
+    def run():
+        for p in rend._all_parameters():
+            p.grad = None
+        out = rend.render(o, d, near, far, **kw)
+        (out["color_fine"].sum() + out["render_feats"].sum() + 0.1 * out["gradient_error"]).backward()
+        return out, [p.grad.clone() for p in rend._all_parameters()]
+
+    out1, g1 = run()
+    monkeypatch.setenv("VDN_BG_COMPACT", "0")
+    out0, g0 = run()
+    for k in ("color_fine", "render_feats", "weights", "weight_sum", "gradient_error"):
+        assert torch.equal(out1[k], out0[k]), k
+    # dW sums run over fewer rows in a different split partition: equal up to fp32 summation order
+    for a, b in zip(g1, g0):
+        assert (a - b).abs().max() <= 1e-5 * b.abs().max() + 1e-12
+    # the list itself
+    B, N, T = o.shape[0], 128, 160
+    inside = out1["inside_sphere"].cpu().numpy()
+    with torch.no_grad():
+        z, _ = rend._sample(o, d, near.reshape(-1), far.reshape(-1), rend.perturb, kw["t_rand"], kw["t_rand_out"], None)
+        _, mid_z = rend._sections(z.contiguous(), N, 2.0 / rend.n_samples)
+        idx, n = background_active(o, d, mid_z, T)
+    want = [r * T + s for r in range(B) for s in range(T) if s >= N or inside[r, s] == 0.0]
+    assert int(n) == len(want) and idx[:int(n)].cpu().tolist() == want
+    assert 32 * B <= len(want) < B * T          # something was skipped, the outside samples never are

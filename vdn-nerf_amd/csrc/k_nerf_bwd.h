@@ -14,9 +14,13 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void nerf_bwd_ke
     WStream<P::kWaves, kSlot> ws;
     ws.init(a.blob, smem, 80);
     const int lane = ws.lane, c = lane & 31, h = lane >> 5;
+    // p = row in the (possibly compacted) work list = row of the saves and deltas; pd = dense point id of the upstream grads
+    const long n_rows = a.active_idx != nullptr ? (long)*a.n_active : (long)a.P;
+    if ((long)blockIdx.x * P::kWaves * 32 >= n_rows) return;
     const long p_raw = ((long)blockIdx.x * P::kWaves + ws.wave) * 32 + c;
-    const bool ok = p_raw < a.P;
-    const long p = ok ? p_raw : (long)a.P - 1;
+    const bool ok = p_raw < n_rows;
+    const long p = ok ? p_raw : n_rows - 1;
+    const long pd = a.active_idx != nullptr ? (long)a.active_idx[p] : p;
     const long PS = P::plane(a.P, 256);
     constexpr int KO = DPT ? 4 : 1;
     constexpr int LDO = DPT ? 128 : 32;
@@ -32,14 +36,14 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void nerf_bwd_ke
     {   // delta of [rgb (tile 0, rows 0..2) | dpt (tiles 1..3)]: no activation on these heads
         float g3[3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) g3[d] = a.g_rgb[p * 3 + d];
+        for (int d = 0; d < 3; ++d) g3[d] = a.g_rgb[pd * 3 + d];
         const f32x16 t16 = vals_tile<3>(g3, h, 0);
         X.set(0, t16);
         P::store_tile(delta_o, p, LDO, 0, h, t16, ok);
         if constexpr (DPT) {
 #pragma unroll
             for (int kt = 0; kt < 3; ++kt) {
-                const f32x16 g = F32::load_tile(a.g_feat, p, 96, kt, h);
+                const f32x16 g = F32::load_tile(a.g_feat, pd, 96, kt, h);
                 X.set(kt + 1, g);
                 P::store_tile(delta_o, p, LDO, kt + 1, h, g, ok);
             }
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void nerf_bwd_ke
         }
     });
     {   // head delta = [d feature (256) | d density at row 256]
-        float g1[1] = {a.g_density[p]};
+        float g1[1] = {a.g_density[pd]};
         const f32x16 t16 = vals_tile<1>(g1, h, 0);
         X.set(8, t16);
         P::store_tile(delta_head, p, 288, 8, h, t16, ok);

@@ -17,9 +17,13 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void nerf_fwd_ke
     WStream<P::kWaves, kSlot> ws;
     ws.init(a.blob, smem, 64 + 9 + 4 + (DPT ? 4 : 1));
     const int lane = ws.lane, c = lane & 31, h = lane >> 5;
-    const long p_raw = ((long)blockIdx.x * P::kWaves + ws.wave) * 32 + c;
-    const bool ok = p_raw < a.P;
-    const long p = ok ? p_raw : (long)a.P - 1;
+    // q = row of this lane in the (possibly compacted) work list = row of its training saves; p = its dense point id
+    const long n_rows = a.active_idx != nullptr ? (long)*a.n_active : (long)a.P;
+    if ((long)blockIdx.x * P::kWaves * 32 >= n_rows) return;          // whole workgroup beyond the active list
+    const long q_raw = ((long)blockIdx.x * P::kWaves + ws.wave) * 32 + c;
+    const bool ok = q_raw < n_rows;
+    const long q = ok ? q_raw : n_rows - 1;
+    const long p = a.active_idx != nullptr ? (long)a.active_idx[q] : q;
     const long r = p / a.n_per_ray;
     ST* save_h = reinterpret_cast<ST*>(a.save_h);
     const long PS = P::plane(a.P, 256);
@@ -53,17 +57,17 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void nerf_fwd_ke
         for (int kt = 0; kt < 3; ++kt) {
             const f32x16 t16 = vals_tile<84>(pe, h, kt);
             X.set(kt, t16);
-            if (save && a.save_pe != nullptr) P::store_tile(reinterpret_cast<ST*>(a.save_pe), p, 96, kt, h, t16, ok);
+            if (save && a.save_pe != nullptr) P::store_tile(reinterpret_cast<ST*>(a.save_pe), q, 96, kt, h, t16, ok);
         }
     };
     // D tile (t0 + nt) <- relu(acc); optionally kept row-major for the backward
     auto relu_into = [&](auto& D, int t0, ST* save, int ld) VDN_INL {
-        return [&D, t0, save, ld, p, ok, h](int nt, const f32x16& acc, int) VDN_INL {
+        return [&D, t0, save, ld, q, ok, h](int nt, const f32x16& acc, int) VDN_INL {
             f32x16 o;
 #pragma unroll
             for (int t = 0; t < 16; ++t) o[t] = relu0(acc[t]);
             D.set(t0 + nt, o);
-            if (save != nullptr) P::store_tile(save, p, ld, nt, h, o, ok);
+            if (save != nullptr) P::store_tile(save, q, ld, nt, h, o, ok);
         };
     };
     auto sv = [&](int l) VDN_INL { return save_h ? save_h + l * PS : (ST*)nullptr; };
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void nerf_fwd_ke
     dense<P, 8, 9, C9, true>(ws, Y, 0, NoPre{}, [&](int nt, const f32x16& acc, int) VDN_INL {
         if (nt < 8) {
             X.set(nt, acc);
-            if (a.save_feature != nullptr) P::store_tile(reinterpret_cast<ST*>(a.save_feature), p, 256, nt, h, acc, ok);
+            if (a.save_feature != nullptr) P::store_tile(reinterpret_cast<ST*>(a.save_feature), q, 256, nt, h, acc, ok);
         } else {
             if (ok && h == 0) a.density[p] = acc[0];
         }
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void nerf_fwd_ke
         posenc<3, 4, P::kAccurateTrig>(dir, pe);
         const f32x16 t16 = vals_tile<27>(pe, h, 0);
         X.set(8, t16);
-        if (a.save_vpe != nullptr) P::store_tile(reinterpret_cast<ST*>(a.save_vpe), p, 32, 0, h, t16, ok);
+        if (a.save_vpe != nullptr) P::store_tile(reinterpret_cast<ST*>(a.save_vpe), q, 32, 0, h, t16, ok);
     }
     dense<P, 9, 4, C4, true>(ws, X, 0, NoPre{}, relu_into(Y, 0, reinterpret_cast<ST*>(a.save_hv), 128));
     // rgb_linear (image tile 0, rows 0..2) and dpt_linear (image tiles 1..3)

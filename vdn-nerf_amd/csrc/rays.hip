@@ -505,6 +505,58 @@ extern "C" int vdn_merge_sorted(const VdnMergeArgs* a, void* stream) {
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// background samples whose NeRF++ output the compositor does not multiply by zero (see include/vdn_render.h):
+// the inside test is the compositor's own (composite_kernel above, same expression, same -ffp-contract=off file)
+// ------------------------------------------------------------------------------------------
+VDN_DEV bool bg_sample_active(const VdnBackgroundActiveArgs& a, int r, int s, const float (&o)[3], const float (&d)[3]) {
+    if (s >= a.N) return true;
+    const float mz = a.mid_z[(long)r * a.N + s];
+    const float x = o[0] + d[0] * mz, y = o[1] + d[1] * mz, w = o[2] + d[2] * mz;
+    const float pn = sqrtf(x * x + y * y + w * w);
+    return !(pn < 1.0f);
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(kRayWaves * 64) void background_active_kernel(VdnBackgroundActiveArgs a) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * kRayWaves + wave;
+    if (r >= a.B) return;
+    float o[3], d[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        o[k] = a.rays_o[r * 3 + k];
+        d[k] = a.rays_d[r * 3 + k];
+    }
+    int base = 0;
+    if (FILL) {      // offset of this ray = sum of the counts of the rays before it (ascending dense order, deterministic)
+        int acc = 0;
+        for (int i = lane; i < r; i += 64) acc += a.ray_counts[i];
+        base = (int)wave_sum((double)acc);
+    }
+    int n = 0;
+    for (int s0 = 0; s0 < a.T; s0 += 64) {
+        const int s = s0 + lane;
+        const bool act = s < a.T && bg_sample_active(a, r, s, o, d);
+        const unsigned long long m = __ballot(act);
+        if (FILL && act) a.active_idx[base + n + __popcll(m & ((1ull << lane) - 1ull))] = r * a.T + s;
+        n += __popcll(m);
+    }
+    if (lane == 0) {
+        if (!FILL) a.ray_counts[r] = n;
+        else if (r == a.B - 1) a.n_active[0] = base + n;
+    }
+}
+
+extern "C" int vdn_background_active(const VdnBackgroundActiveArgs* a, void* stream) {
+    if (!a || a->B <= 0 || a->N < 0 || a->T < a->N || !a->rays_o || !a->rays_d || (a->N > 0 && !a->mid_z) ||
+        !a->active_idx || !a->n_active || !a->ray_counts) return -1;
+    const dim3 grid((a->B + kRayWaves - 1) / kRayWaves), block(kRayWaves * 64);
+    hipLaunchKernelGGL(background_active_kernel<false>, grid, block, 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(background_active_kernel<true>, grid, block, 0, (hipStream_t)stream, *a);
+    return (int)hipGetLastError();
+}
+
 extern "C" int vdn_sections(const VdnSectionArgs* a, void* stream) {
     if (!a || a->B <= 0 || a->n <= 0 || !a->z || !a->dists || !a->mid_z || a->ld < a->n) return -1;
     const int n = a->B * a->n;

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256, 2) void dw_gemm_f32_kernel(const DwDesc* descs
     const int seg_splits = two ? d.splits / 2 : d.splits;       // two segments: first half of the splits = segment 1
     const bool seg2 = two && split >= seg_splits;
     const int s_in = seg2 ? split - seg_splits : split;
-    const long P = d.P;
+    const long P = d.P_dev != nullptr ? min((long)d.P, (long)*d.P_dev) : (long)d.P;
     long per = (P + seg_splits - 1) / seg_splits;
     per = (per + kF32StagePts - 1) / kF32StagePts * kF32StagePts;
     const long k_begin = (long)s_in * per, k_end = min(k_begin + per, P);

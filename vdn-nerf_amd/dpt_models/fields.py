@@ -281,7 +281,9 @@ class NeRF(_HipNet):
     def _streams(self):
         return images.nerf_streams(**self.conf)
 
-    def _run(self, pts4=None, dirs=None, rays=None):
+    def _run(self, pts4=None, dirs=None, rays=None, active=None):
+        """`active` = (idx int32 [P], n int32 [1]) from vdn_background_active: only those points are evaluated, the other
+        outputs stay zero (render_core multiplies them by zero)."""
         img = self._images()
         a = lib.VdnNerfArgs()
         a.blob = img.blobs["fwd"].data_ptr()
@@ -292,10 +294,13 @@ class NeRF(_HipNet):
         else:
             P, dev = pts4.shape[0], pts4.device
             a.pts4, a.dirs, a.n_per_ray = pts4.data_ptr(), dirs.data_ptr(), 1
-        density = torch.empty(P, dtype=torch.float32, device=dev)
-        rgb = torch.empty(P, 3, dtype=torch.float32, device=dev)
-        feat = torch.empty(P, 96, dtype=torch.float32, device=dev) if self.gen_depth_feats else None
+        alloc = torch.empty if active is None else torch.zeros
+        density = alloc(P, dtype=torch.float32, device=dev)
+        rgb = alloc(P, 3, dtype=torch.float32, device=dev)
+        feat = alloc(P, 96, dtype=torch.float32, device=dev) if self.gen_depth_feats else None
         a.density, a.rgb, a.feat, a.P = density.data_ptr(), rgb.data_ptr(), (feat.data_ptr() if feat is not None else None), P
+        if active is not None:
+            a.active_idx, a.n_active = active[0].data_ptr(), active[1].data_ptr()
         lib.call("vdn_nerf_mlp_fwd" + self._sfx(), a, _stream())
         return density, rgb, feat
 

@@ -56,6 +56,29 @@ def extract_geometry(bound_min, bound_max, resolution, threshold, query_func):
     return vertices, triangles.cpu().numpy()
 
 
+def bg_compaction():
+    """VDN_BG_COMPACT=0 evaluates every background sample as the reference does (A/B switch for the parity tests)."""
+    import os
+    return os.environ.get("VDN_BG_COMPACT", "1") != "0"
+
+
+def background_active(rays_o, rays_d, mid_z, T, out=None):
+    """The background samples render_core does not multiply by zero (vdn_background_active, include/vdn_render.h):
+    -> (idx int32 [B*T], n int32 [1]) on the device. Inside-sphere samples get weight (1 - inside_sphere) = 0 for the
+    NeRF++ output (renderer.py:284-299), so the background network skips them - same outputs, same gradients."""
+    B, N = mid_z.shape
+    dev = mid_z.device
+    if out is None:
+        out = (torch.empty(B * T, dtype=torch.int32, device=dev), torch.empty(1, dtype=torch.int32, device=dev),
+               torch.empty(B, dtype=torch.int32, device=dev))
+    a = lib.VdnBackgroundActiveArgs()
+    a.rays_o, a.rays_d, a.mid_z = rays_o.data_ptr(), rays_d.data_ptr(), mid_z.data_ptr()
+    a.B, a.N, a.T = B, N, T
+    a.active_idx, a.n_active, a.ray_counts = out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr()
+    lib.call("vdn_background_active", a, _stream())
+    return out[0], out[1]
+
+
 class _RenderCoreFn(torch.autograd.Function):
     """Differentiable part of render() (render_core_outside + render_core at detached z) as one autograd
     node: forward and backward are the hand-written kernels driven by vdn_hip.train.TrainEngine."""
@@ -221,7 +244,8 @@ class NeuSRenderer:
             m.B, m.M, m.K, m.ld, m.ld_out = B, N, O, z.stride(0), T
             lib.call("vdn_merge_sorted", m, st)
             bg_dists, bg_mid = self._sections(z_feed, T, sample_dist)
-            bg_density, bg_rgb, bg_feat = self.nerf._run(rays=(rays_o, rays_d, bg_mid))
+            active = background_active(rays_o, rays_d, mid_z, T) if bg_compaction() else None
+            bg_density, bg_rgb, bg_feat = self.nerf._run(rays=(rays_o, rays_d, bg_mid), active=active)
 
         ws = {}
         sdf, feat, normals = self.sdf_network._run(1, rays=(rays_o, rays_d, mid_z), workspace=ws)   # renderer.py:239-243

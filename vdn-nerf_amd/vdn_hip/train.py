@@ -90,8 +90,11 @@ class TrainEngine:
             w["vdn_out"], w["vdn_h"], w["vdn_small"] = f(P, 96), fs(4, Pp, 256), fs(Pp, 64)
         if O > 0:
             w["z_feed"], w["bg_dists"], w["bg_mid"] = f(B, T), f(B, T), f(B, T)
-            w["bg_density"], w["bg_rgb"] = f(Q), f(Q, 3)
-            w["bg_feat"] = f(Q, 96) if self.wdepth else None
+            # zero-initialised: points the active list skips keep finite values (the compositor multiplies them by zero)
+            w["bg_density"], w["bg_rgb"] = torch.zeros(Q, device=dev), torch.zeros(Q, 3, device=dev)
+            w["bg_feat"] = torch.zeros(Q, 96, device=dev) if self.wdepth else None
+            w["bg_active"] = (torch.zeros(Q, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev),
+                              torch.zeros(B, dtype=torch.int32, device=dev))
             w["nf_h"], w["nf_pe"], w["nf_feature"], w["nf_vpe"], w["nf_hv"] = fs(8, Qp, 256), fs(Qp, 96), fs(Qp, 256), fs(Qp, 32), fs(Qp, 128)
         w["weights"], w["alpha"], w["cdf"], w["inside"] = f(B, T), f(B, T), f(B, N), f(B, N)
         w["color"], w["wsum"], w["wmax"], w["s_val"] = f(B, 3), f(B, 1), f(B, 1), f(B, 1)
@@ -230,6 +233,8 @@ class TrainEngine:
             if e.get("A2") is not None:
                 d["A2"], d["lda2"], d["B2"], d["ldb2"] = P4(e["A2"]), e["A2"][3], P4(e["B2"]), e["B2"][3]
             d["P"], d["m_tiles"], d["n_tiles"], d["splits"], d["wg_begin"] = e["Pn"], mt, nt, splits, wg0
+            if e["net"] == "nerf":
+                d["P_dev"] = w["bg_active"][1].data_ptr()       # rows of the compact background list (device scalar)
             d["slab"] = self.slab.data_ptr() + 4 * so
             want_cs = e["bias"] or e.get("extra_row0")
             d["colsum"] = self.colsum.data_ptr() + 4 * co if want_cs else 0
@@ -299,6 +304,14 @@ class TrainEngine:
             n.density, n.rgb = w["bg_density"].data_ptr(), w["bg_rgb"].data_ptr()
             n.feat = w["bg_feat"].data_ptr() if w["bg_feat"] is not None else None
             n.save_h, n.save_pe, n.save_feature, n.save_vpe, n.save_hv = (w[k].data_ptr() for k in ("nf_h", "nf_pe", "nf_feature", "nf_vpe", "nf_hv"))
+            # only the background samples the compositor does not multiply by zero (saves are in compact order)
+            from dpt_models.renderer import background_active, bg_compaction
+            self._bg_compact = bg_compaction()
+            if self._bg_compact:
+                background_active(rays_o, rays_d, w["mid_z"], T, out=w["bg_active"])
+                n.active_idx, n.n_active = w["bg_active"][0].data_ptr(), w["bg_active"][1].data_ptr()
+            else:
+                w["bg_active"][1].fill_(self.Q)           # the dW GEMM's device-side row count
             # the NeRF++ background is independent of the SDF / colour path until compositing: it may run on a side stream
             # (81 920 background points = 1.25 rounds of the CUs; the tail round could overlap the SDF kernels)
             self._fork()
@@ -368,15 +381,19 @@ class TrainEngine:
         esz = 4 if self.precision == "fp32" else 2
         total = 0
         tab = np.frombuffer(self.dw_table.cpu().numpy().tobytes(), dtype=lib.struct_dtype("VdnDwDesc"))
+        n_bg = int(self.w["bg_active"][1].item()) if "bg_active" in self.w else 0
         for d in tab:
             segs = 2 if d["A2"] else 1
-            total += segs * int(d["P"]) * 32 * (int(d["m_tiles"]) + int(d["n_tiles"])) * esz
+            rows = min(int(d["P"]), n_bg) if d["P_dev"] else int(d["P"])     # background operands: the compact list of the last forward
+            total += segs * rows * 32 * (int(d["m_tiles"]) + int(d["n_tiles"])) * esz
             total += int(d["splits"]) * int(d["m_tiles"]) * 32 * int(d["n_tiles"]) * 32 * 4
         return total
 
     def dw_flops(self):
         tab = np.frombuffer(self.dw_table.cpu().numpy().tobytes(), dtype=lib.struct_dtype("VdnDwDesc"))
-        return sum(2.0 * (2 if d["A2"] else 1) * int(d["P"]) * int(d["m_tiles"]) * 32 * int(d["n_tiles"]) * 32 for d in tab)
+        n_bg = int(self.w["bg_active"][1].item()) if "bg_active" in self.w else 0
+        rows = lambda d: min(int(d["P"]), n_bg) if d["P_dev"] else int(d["P"])
+        return sum(2.0 * (2 if d["A2"] else 1) * rows(d) * int(d["m_tiles"]) * 32 * int(d["n_tiles"]) * 32 for d in tab)
 
     def _launch_dw(self):
         lib.call("vdn_dw_gemm" + self.sfx, lib.ptr(self.dw_table), self.n_dw, self.dw_total_wgs, _stream())
@@ -434,6 +451,8 @@ class TrainEngine:
             nb.save_h, nb.save_hv = w["nf_h"].data_ptr(), w["nf_hv"].data_ptr()
             nb.delta_o, nb.delta_v, nb.delta_head, nb.delta_h = (w[k].data_ptr() for k in ("nf_do", "nf_dv", "nf_dhead", "nf_dh"))
             nb.P = self.Q
+            if self._bg_compact:
+                nb.active_idx, nb.n_active = w["bg_active"][0].data_ptr(), w["bg_active"][1].data_ptr()
             self._fork()
             lib.call("vdn_nerf_mlp_bwd" + self.sfx, nb, self._side_handle(st))
             self._side_done()
