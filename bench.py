@@ -175,6 +175,10 @@ def main():
         eng = trainer.engine
         o, d = batches[0][0], batches[0][1]
         tk = time_kernel(lambda: eng._sdf_forward(o, d))
+        # the training step's launch covers the foreground work list of the last step (inside samples within the relaxed
+        # sphere; the others enter the loss through exact zeros), the inference launch all 65 536 points
+        fg_rows = int(eng.w["fg_active"][1].item())
+        flops_train = (F_SDF + F_GRAD) * fg_rows
         flops = (F_SDF + F_GRAD) * eng.P
         dtype = "f32" if args.precision == "fp32" else "bf16"
         # the same kernel without the training saves (what render() launches under torch.no_grad())
@@ -189,6 +193,8 @@ def main():
             tf = os.path.join(ROOT, "profiles", "r01_traffic_sdf_fwd_%s%s.json" % (args.precision, tag))
             return json.load(open(tf)).get("hbm_bytes_per_launch") if os.path.exists(tf) else None
         traffic, traffic_inf = traffic_of("_train"), traffic_of("")
+        if traffic is not None:
+            traffic *= fg_rows / float(eng.P)        # PMC figure is for a 65 536-point launch; bytes scale with the rows
         tdwf = os.path.join(ROOT, "profiles", "r01_traffic_dw_gemm_%s.json" % dtype)
         traffic_dw = json.load(open(tdwf)).get("hbm_bytes_per_launch") if (os.path.exists(tdwf) and not wdepth) else None
         line = {
@@ -203,13 +209,14 @@ def main():
                        # flop_per_ray is SURVEY.md 8d's algorithmic count (all 160 background samples per ray); background
                        # samples that render_core multiplies by zero (inside the unit sphere) are not evaluated
                        "background_points_evaluated_last_step": int(eng.w["bg_active"][1].item()),
-                       "background_points_total": eng.Q},
+                       "background_points_total": eng.Q,
+                       "foreground_points_evaluated_last_step": fg_rows, "foreground_points_total": eng.P},
             "model_flops_per_s": value * flop_per_ray,
             "forward_only_rays_per_s": fwd_rays_per_s, "final_loss": loss_final,
-            "roofline": {"bound": "mfma", "kernel": "sdf_fwd_kernel<%s> (fused PE + SDF MLP + gradient sweep, 65536 points, "
-                                                   "training-mode launch of the timed step)" % ("F32,1,4,false" if dtype == "f32" else "BF16,1,4,true"),
-                         "achieved": flops / tk / 1e12, "peak": PEAK[dtype] / 1e12, "unit": "TFLOP/s",
-                         "frac": flops / tk / PEAK[dtype], "traffic": traffic, "kernel_ms": tk * 1e3,
+            "roofline": {"bound": "mfma", "kernel": "sdf_fwd_kernel<%s> (fused PE + SDF MLP + gradient sweep, "
+                                                   "training-mode launch of the timed step over its foreground work list)" % ("F32,1,4,false" if dtype == "f32" else "BF16,1,4,true"),
+                         "achieved": flops_train / tk / 1e12, "peak": PEAK[dtype] / 1e12, "unit": "TFLOP/s",
+                         "frac": flops_train / tk / PEAK[dtype], "traffic": traffic, "kernel_ms": tk * 1e3, "points": fg_rows,
                          "inference_launch": {"kernel_ms": tk_inf * 1e3, "achieved": flops / tk_inf / 1e12, "frac": flops / tk_inf / PEAK[dtype],
                                               "traffic": traffic_inf}},
             "roofline_dw_gemm": {"bound": "hbm", "kernel": "dw_gemm_%s_kernel (batched split-K weight-gradient GEMM, longest kernel of the step)" % dtype,

@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VDN_ABI_VERSION 4
+#define VDN_ABI_VERSION 5
 
 int vdn_abi_version(void);
 
@@ -79,6 +79,10 @@ typedef struct {
     void* H;                  /* [8,P,256] H[l] = softplus output of layer l (= input of layer l+1) */
     void* V;                  /* [8,P,256] V[l] = sweep value v_l = u_{l+1} * softplus'(a_l) */
     void* PE;                 /* [P,64] positional encoding of the point (39 valid) */
+    /* optional work list (vdn_foreground_active; same contract as VdnNerfArgs.active_idx): per-point inputs / outputs
+     * are addressed by the dense point id, training saves and deltas by the compact row */
+    const int32_t* active_idx;
+    const int32_t* n_active;
 } VdnSdfArgs;
 int vdn_sdf_mlp_fwd_f32(int mode, const VdnSdfArgs* args_host, void* stream);
 /* bf16-MFMA variant: blob holds bf16 chunks (fmt 1); feat / S / H / V / PE are bf16 arrays; sdf / normals stay f32. */
@@ -102,6 +106,10 @@ typedef struct {
     int32_t P;
     int32_t d_out;             /* 1..4 or 96 */
     int32_t squeeze_out;       /* 1: sigmoid (fields.py:170-171), 0: relu */
+    /* optional work list (vdn_foreground_active; same contract as VdnNerfArgs.active_idx): per-point inputs / outputs
+     * are addressed by the dense point id, training saves and deltas by the compact row */
+    const int32_t* active_idx;
+    const int32_t* n_active;
 } VdnRenderNetArgs;
 int vdn_rendernet_fwd_f32(const VdnRenderNetArgs* args_host, void* stream);
 int vdn_rendernet_fwd_bf16(const VdnRenderNetArgs* args_host, void* stream);   /* bf16-MFMA variant: bf16 chunk blob, bf16 activation workspaces */
@@ -244,6 +252,10 @@ typedef struct {
     int32_t P;
     int32_t d_out;
     int32_t squeeze_out;
+    /* optional work list (vdn_foreground_active; same contract as VdnNerfArgs.active_idx): per-point inputs / outputs
+     * are addressed by the dense point id, training saves and deltas by the compact row */
+    const int32_t* active_idx;
+    const int32_t* n_active;
 } VdnRenderNetBwdArgs;
 int vdn_rendernet_bwd_f32(const VdnRenderNetBwdArgs* args_host, void* stream);
 int vdn_rendernet_bwd_bf16(const VdnRenderNetBwdArgs* args_host, void* stream);   /* bf16-MFMA variant: bf16 chunk blob, bf16 activation workspaces */
@@ -292,6 +304,10 @@ typedef struct {
     void* UB;                 /* out, see above */
     void* EX;                 /* out */
     int32_t s_from_h;          /* 1: S points at the H planes; softplus' = 1 - exp(-100 h) is evaluated in the kernel */
+    /* optional work list (vdn_foreground_active; same contract as VdnNerfArgs.active_idx): per-point inputs / outputs
+     * are addressed by the dense point id, training saves and deltas by the compact row */
+    const int32_t* active_idx;
+    const int32_t* n_active;
 } VdnSdfRbarArgs;
 int vdn_sdf_bwd_rbar_f32(const VdnSdfRbarArgs* args_host, void* stream);
 int vdn_sdf_bwd_rbar_bf16(const VdnSdfRbarArgs* args_host, void* stream);   /* bf16-MFMA variant: bf16 chunk blob, bf16 activation workspaces */
@@ -306,6 +322,10 @@ typedef struct {
     int32_t P;
     float scale;
     int32_t s_from_h;          /* as in VdnSdfRbarArgs */
+    /* optional work list (vdn_foreground_active; same contract as VdnNerfArgs.active_idx): per-point inputs / outputs
+     * are addressed by the dense point id, training saves and deltas by the compact row */
+    const int32_t* active_idx;
+    const int32_t* n_active;
 } VdnSdfFbarArgs;
 int vdn_sdf_bwd_fbar_f32(const VdnSdfFbarArgs* args_host, void* stream);
 int vdn_sdf_bwd_fbar_bf16(const VdnSdfFbarArgs* args_host, void* stream);   /* bf16-MFMA variant: bf16 chunk blob, bf16 activation workspaces */
@@ -444,6 +464,23 @@ typedef struct {
     int32_t* ray_counts;       /* [B] scratch */
 } VdnBackgroundActiveArgs;
 int vdn_background_active(const VdnBackgroundActiveArgs* args_host, void* stream);
+
+/* Foreground counterpart, used by the training step only: inside sample s of ray r is active iff
+ * |rays_o + rays_d * mid_z[r,s]| < radius. With radius 1.2 the skipped points have inside_sphere = 0 AND
+ * relax_inside_sphere = 0 (renderer.py:284-286): their sdf / normal / colour enter the loss only through factors that are
+ * exactly zero, so the SDF, colour and VDN networks skip them in the training step (render() itself still evaluates them:
+ * it returns `gradients` for every sample). Dense ids p = r*N + s, ascending. */
+typedef struct {
+    const float* rays_o;
+    const float* rays_d;
+    const float* mid_z;        /* [B,N] */
+    int32_t B, N;
+    float radius;
+    int32_t* active_idx;       /* [B*N] out */
+    int32_t* n_active;         /* [1] out */
+    int32_t* ray_counts;       /* [B] scratch */
+} VdnForegroundActiveArgs;
+int vdn_foreground_active(const VdnForegroundActiveArgs* args_host, void* stream);
 
 /* ---- iso-surface of the lattice u = -sdf (device marching tetrahedra) ---------------------------------------------
  * Stands in for mcubes.marching_cubes(u, threshold) of renderer.py:36 (PyMCubes is third-party and not part of the

@@ -316,3 +316,38 @@ def test_trainer_wdepth_mask_step_equals_autograd_path():
     for i, (p, gr) in enumerate(zip(params, got)):
         scale = p.grad.abs().max().item()
         assert scale > 0 and (p.grad - gr).abs().max().item() <= 1e-5 * scale, (i, tuple(p.shape))
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_trainer_work_lists_do_not_change_the_step(monkeypatch, precision):
+    """The Trainer skips foreground samples beyond the relaxed sphere and background samples inside the unit sphere (they
+    enter the loss only through exact zeros, renderer.py:284-299): same scalars bit for bit, same gradient up to the
+    summation order of the weight-gradient GEMM, as evaluating every sample."""
+    from vdn_train import synth, factory
+    from vdn_train.trainer import Trainer
+    dev = torch.device("cuda:0")
+    B, seed = 256, 53
+    st = synth.make_all_states(seed, wdepth=True)
+    cams = synth.make_cameras(seed)
+    o, d = synth.random_pixel_batch(seed, 0, 4, B, cams=cams)            # full frame: many samples outside both spheres
+    near, far = synth.near_far_from_sphere(o, d)
+    t1, t2 = synth.jitter(seed, 0, B)
+    o, d, near, far, t1, t2 = (g(x, dev) for x in (o, d, near, far, t1, t2))
+    rgb = g(synth.uniform(seed, "wl/rgb", (B, 3)), dev)
+    gtf = g(synth.uniform(seed, "wl/f", (B, 96)), dev)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("VDN_FG_COMPACT", mode)
+        monkeypatch.setenv("VDN_BG_COMPACT", mode)
+        tr = Trainer(factory.build_renderer(wdepth=True, device=dev, states=st, precision=precision), B, dev,
+                     conf=dict(extract_depth=True, depth_start_iter=-1))
+        tr.iter_step = 10
+        sc = tr.train_step(o, d, near, far, rgb, gt_feats=gtf, t_rand=t1, t_rand_out=t2).cpu().numpy().copy()
+        eng = tr.engine
+        res[mode] = (sc, [x.clone() for x in eng.param_grads()], int(eng.w["fg_active"][1]), int(eng.w["bg_active"][1]))
+    sc1, g1, nfg1, nbg1 = res["1"]
+    sc0, g0, nfg0, nbg0 = res["0"]
+    assert nfg0 == B * 128 and nbg0 == B * 160 and 0 < nfg1 < nfg0 and 32 * B <= nbg1 < nbg0
+    assert np.array_equal(sc1, sc0)
+    for a, b in zip(g1, g0):
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-12

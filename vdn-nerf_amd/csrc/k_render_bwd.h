@@ -16,9 +16,10 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_b
     WStream<P::kWaves, kSlot> ws;
     ws.init(a.blob, smem, 42);
     const int lane = ws.lane, c = lane & 31, h = lane >> 5;
-    const long p_raw = ((long)blockIdx.x * P::kWaves + ws.wave) * 32 + c;
-    const bool ok = p_raw < a.P;
-    const long p = ok ? p_raw : (long)a.P - 1;
+    const WorkRow wr = work_row(a.active_idx, a.n_active, a.P, P::kWaves, ws.wave, c);
+    if (wr.none) return;
+    const bool ok = wr.ok;
+    const long p = wr.row, pd = wr.point;          // p: row of saves / deltas / d_feat; pd: dense point id
     const long PS = P::plane(a.P, 256);
     const ST* save_h = reinterpret_cast<const ST*>(a.save_h);
     ST* delta_h = reinterpret_cast<ST*>(a.delta_h);
@@ -32,7 +33,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_b
         for (int j = 0; j < 4; ++j) {
             dl[j] = 0.0f;
             if (j < a.d_out) {
-                const float o = a.out[p * a.d_out + j], g = a.g_out[p * a.d_out + j];
+                const float o = a.out[pd * a.d_out + j], g = a.g_out[pd * a.d_out + j];
                 dl[j] = a.squeeze_out ? g * o * (1.0f - o) : (o > 0.0f ? g : 0.0f);
             }
         }
@@ -42,8 +43,8 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_b
     } else {
 #pragma unroll
         for (int kt = 0; kt < 3; ++kt) {
-            const f32x16 o = F32::load_tile(a.out, p, 96, kt, h);
-            const f32x16 g = F32::load_tile(a.g_out, p, 96, kt, h);
+            const f32x16 o = F32::load_tile(a.out, pd, 96, kt, h);
+            const f32x16 g = F32::load_tile(a.g_out, pd, 96, kt, h);
             f32x16 dl;
 #pragma unroll
             for (int t = 0; t < 16; ++t) dl[t] = a.squeeze_out ? g[t] * o[t] * (1.0f - o[t]) : (o[t] > 0.0f ? g[t] : 0.0f);
@@ -88,8 +89,8 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_b
     if (ok && h == 0) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            const float prev = a.acc_normals ? a.d_normals[p * 3 + d] : 0.0f;
-            a.d_normals[p * 3 + d] = prev + small[30 + d];
+            const float prev = a.acc_normals ? a.d_normals[pd * 3 + d] : 0.0f;
+            a.d_normals[pd * 3 + d] = prev + small[30 + d];
         }
     }
 }

@@ -17,10 +17,11 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_f
     WStream<P::kWaves, kSlot> ws;
     ws.init(a.blob, smem, 32 + NT_OUT);
     const int lane = ws.lane, c = lane & 31, h = lane >> 5;
-    const long p_raw = ((long)blockIdx.x * P::kWaves + ws.wave) * 32 + c;
-    const bool ok = p_raw < a.P;
-    const long p = ok ? p_raw : (long)a.P - 1;
-    const long r = p / a.n_per_ray;
+    const WorkRow wr = work_row(a.active_idx, a.n_active, a.P, P::kWaves, ws.wave, c);
+    if (wr.none) return;
+    const bool ok = wr.ok;
+    const long p = wr.row, pd = wr.point;          // p: row of feat and of the saves; pd: dense point id
+    const long r = pd / a.n_per_ray;
     const ST* feat = reinterpret_cast<const ST*>(a.feat);
     ST* save_h = reinterpret_cast<ST*>(a.save_h);
     ST* save_small = reinterpret_cast<ST*>(a.save_small);
@@ -33,12 +34,12 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_f
     {
         float small[33];
         float dir[3];
-        const float z = a.pts ? 0.0f : a.z[p];
+        const float z = a.pts ? 0.0f : a.z[pd];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            dir[d] = a.dirs ? a.dirs[p * 3 + d] : a.rays_d[r * 3 + d];
-            small[d] = a.pts ? a.pts[p * 3 + d] : a.rays_o[r * 3 + d] + a.rays_d[r * 3 + d] * z;   // renderer.py:233
-            small[30 + d] = a.normals[p * 3 + d];
+            dir[d] = a.dirs ? a.dirs[pd * 3 + d] : a.rays_d[r * 3 + d];
+            small[d] = a.pts ? a.pts[pd * 3 + d] : a.rays_o[r * 3 + d] + a.rays_d[r * 3 + d] * z;   // renderer.py:233
+            small[30 + d] = a.normals[pd * 3 + d];
         }
         float pe[27];
         posenc<3, 4, P::kAccurateTrig>(dir, pe);
@@ -74,10 +75,10 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_f
         for (int t = 0; t < 16; ++t) o[t] = a.squeeze_out ? sigmoidf_(acc[t]) : relu0(acc[t]);
         if constexpr (NT_OUT == 1) {
             if (ok && h == 0) {
-                for (int j = 0; j < a.d_out && j < 4; ++j) a.out[p * a.d_out + j] = o[j];
+                for (int j = 0; j < a.d_out && j < 4; ++j) a.out[pd * a.d_out + j] = o[j];
             }
         } else {
-            F32::store_tile(a.out, p, 96, nt, h, o, ok);      // network outputs feed the per-ray kernels: always f32
+            F32::store_tile(a.out, pd, 96, nt, h, o, ok);      // network outputs feed the per-ray kernels: always f32
         }
     });
 }

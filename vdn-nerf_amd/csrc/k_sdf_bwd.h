@@ -25,9 +25,10 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_rbar_ke
     WStream<P::kWaves, kSlot> ws;
     ws.init(a.blob, smem, 63);        // hidden layers 0..7 of the forward stream
     const int lane = ws.lane, c = lane & 31, h = lane >> 5;
-    const long p_raw = ((long)blockIdx.x * P::kWaves + ws.wave) * 32 + c;
-    const bool ok = p_raw < a.P;
-    const long p = ok ? p_raw : (long)a.P - 1;
+    const WorkRow wr = work_row(a.active_idx, a.n_active, a.P, P::kWaves, ws.wave, c);
+    if (wr.none) return;
+    const bool ok = wr.ok;
+    const long p = wr.row, pd = wr.point;          // p: row of the saves / adjoint planes; pd: dense point id
     const long Pn = P::rows(a.P), PS = Pn * 256;
     const ST* S = reinterpret_cast<const ST*>(a.S);
     const bool from_h = a.s_from_h != 0;
@@ -37,10 +38,10 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_rbar_ke
     float xin[3];
     if (a.pts != nullptr) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) xin[d] = a.pts[p * 3 + d] * a.scale;
+        for (int d = 0; d < 3; ++d) xin[d] = a.pts[pd * 3 + d] * a.scale;
     } else {
-        const long r = p / a.n_per_ray;
-        const float z = a.z[r * a.z_ld + (p - r * a.n_per_ray)];
+        const long r = pd / a.n_per_ray;
+        const float z = a.z[r * a.z_ld + (pd - r * a.n_per_ray)];
 #pragma unroll
         for (int d = 0; d < 3; ++d) xin[d] = (a.rays_o[r * 3 + d] + a.rays_d[r * 3 + d] * z) * a.scale;
     }
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_rbar_ke
         float gn[3];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            gn[d] = a.g_normals[p * 3 + d] * a.scale;
+            gn[d] = a.g_normals[pd * 3 + d] * a.scale;
             ub39[d] = gn[d];
         }
 #pragma unroll
@@ -134,9 +135,10 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_fbar_ke
     WStream<P::kWaves, kSlot> ws;
     ws.init(a.blob, smem, 65);
     const int lane = ws.lane, c = lane & 31, h = lane >> 5;
-    const long p_raw = ((long)blockIdx.x * P::kWaves + ws.wave) * 32 + c;
-    const bool ok = p_raw < a.P;
-    const long p = ok ? p_raw : (long)a.P - 1;
+    const WorkRow wr = work_row(a.active_idx, a.n_active, a.P, P::kWaves, ws.wave, c);
+    if (wr.none) return;
+    const bool ok = wr.ok;
+    const long p = wr.row, pd = wr.point;          // p: row of the saves / adjoint planes; pd: dense point id
     const long Pn = P::rows(a.P), PS = Pn * 256;
     const ST* S = reinterpret_cast<const ST*>(a.S);
     const bool from_h = a.s_from_h != 0;
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_fbar_ke
         if (kt < 8) {
             t16 = P::load_tile(g_feat, p, 256, kt, h);
         } else {
-            float g1[1] = {a.g_sdf[p] / a.scale};
+            float g1[1] = {a.g_sdf[pd] / a.scale};
             t16 = vals_tile<1>(g1, h, 0);
         }
         X.set(kt, t16);

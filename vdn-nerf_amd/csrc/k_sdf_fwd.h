@@ -23,19 +23,20 @@ __global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(Sdf
     WStream<NW, kSlot, VDN_NSLOT> ws;
     ws.init(a.blob, smem, MODE == 0 ? 64 : 131);       // chunks in the 'sdf' / 'full' stream
     const int lane = ws.lane, c = lane & 31, h = lane >> 5;
-    const long p_raw = ((long)blockIdx.x * NW + ws.wave) * 32 + c;
-    const bool ok = p_raw < a.P;
-    const long p = ok ? p_raw : (long)a.P - 1;
+    const WorkRow wr = work_row(a.active_idx, a.n_active, a.P, NW, ws.wave, c);
+    if (wr.none) return;
+    const bool ok = wr.ok;
+    const long p = wr.row, pd = wr.point;          // p: row of the saves (and of feat); pd: dense point id
     ws.all_issue = __any(ok);
 
     float xin[3];
-    long sdf_idx = p;
+    long sdf_idx = pd;
     if (a.pts != nullptr) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) xin[d] = a.pts[p * 3 + d] * a.scale;
+        for (int d = 0; d < 3; ++d) xin[d] = a.pts[pd * 3 + d] * a.scale;
     } else {
-        const long r = p / a.n_per_ray;
-        const long sidx = p - r * a.n_per_ray;
+        const long r = pd / a.n_per_ray;
+        const long sidx = pd - r * a.n_per_ray;
         const float z = a.z[r * a.z_ld + sidx];
         sdf_idx = r * a.sdf_ld + sidx;
 #pragma unroll
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(Sdf
         pe_backward(U0);
         if (ok && h == 0) {
 #pragma unroll
-            for (int d = 0; d < 3; ++d) a.normals[p * 3 + d] = n[d] * a.scale;
+            for (int d = 0; d < 3; ++d) a.normals[pd * 3 + d] = n[d] * a.scale;
         }
     }
 }

@@ -107,6 +107,25 @@ VDN_DEV float sprime(float raw, bool from_h) {
     return from_h ? 1.0f - __builtin_amdgcn_exp2f(-144.26950408889634f * raw) : raw;
 }
 
+// Row bookkeeping of the MLP kernels: lane c of wave w of workgroup b works on row b*waves*32 + w*32 + c of the work
+// list. Without a list the row is the point; with one (vdn_background_active / vdn_foreground_active) `row` addresses
+// the training saves and `point` = active_idx[row] the per-point inputs and outputs. `none` = the whole workgroup lies
+// beyond the list (it must return before its first barrier).
+struct WorkRow {
+    long row, point;
+    bool ok, none;
+};
+VDN_DEV WorkRow work_row(const int32_t* active_idx, const int32_t* n_active, long P, int waves, int wave, int c) {
+    WorkRow w;
+    const long n_rows = active_idx != nullptr ? (long)*n_active : P;
+    w.none = (long)blockIdx.x * waves * 32 >= n_rows;
+    const long raw = ((long)blockIdx.x * waves + wave) * 32 + c;
+    w.ok = raw < n_rows;
+    w.row = w.ok ? raw : (n_rows > 0 ? n_rows - 1 : 0);
+    w.point = active_idx != nullptr ? (long)active_idx[w.row] : w.row;
+    return w;
+}
+
 struct NoPre {
     VDN_DEV int operator()(int) const { return 0; }
 };

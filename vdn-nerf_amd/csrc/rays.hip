@@ -506,19 +506,32 @@ extern "C" int vdn_merge_sorted(const VdnMergeArgs* a, void* stream) {
 }
 
 // ------------------------------------------------------------------------------------------
-// background samples whose NeRF++ output the compositor does not multiply by zero (see include/vdn_render.h):
-// the inside test is the compositor's own (composite_kernel above, same expression, same -ffp-contract=off file)
+// work lists (see include/vdn_render.h): background samples whose NeRF++ output the compositor does not multiply by
+// zero, and - for the training step - foreground samples inside the relaxed sphere. The norm test is the compositor's
+// own (composite_kernel above: same expression, same -ffp-contract=off file).
 // ------------------------------------------------------------------------------------------
-VDN_DEV bool bg_sample_active(const VdnBackgroundActiveArgs& a, int r, int s, const float (&o)[3], const float (&d)[3]) {
+struct ActiveJob {
+    const float* rays_o;
+    const float* rays_d;
+    const float* mid_z;     // [B,N]
+    int B, N, T;            // T samples listed per ray; samples s >= N are always active (background mode)
+    float radius;           // background: active iff !(norm < 1); foreground (T == N): active iff norm < radius
+    bool background;
+    int32_t* active_idx;
+    int32_t* n_active;
+    int32_t* ray_counts;
+};
+
+VDN_DEV bool sample_active(const ActiveJob& a, int r, int s, const float (&o)[3], const float (&d)[3]) {
     if (s >= a.N) return true;
     const float mz = a.mid_z[(long)r * a.N + s];
     const float x = o[0] + d[0] * mz, y = o[1] + d[1] * mz, w = o[2] + d[2] * mz;
     const float pn = sqrtf(x * x + y * y + w * w);
-    return !(pn < 1.0f);
+    return a.background ? !(pn < 1.0f) : pn < a.radius;
 }
 
 template <bool FILL>
-__global__ __launch_bounds__(kRayWaves * 64) void background_active_kernel(VdnBackgroundActiveArgs a) {
+__global__ __launch_bounds__(kRayWaves * 64) void active_list_kernel(ActiveJob a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = blockIdx.x * kRayWaves + wave;
     if (r >= a.B) return;
@@ -537,7 +550,7 @@ __global__ __launch_bounds__(kRayWaves * 64) void background_active_kernel(VdnBa
     int n = 0;
     for (int s0 = 0; s0 < a.T; s0 += 64) {
         const int s = s0 + lane;
-        const bool act = s < a.T && bg_sample_active(a, r, s, o, d);
+        const bool act = s < a.T && sample_active(a, r, s, o, d);
         const unsigned long long m = __ballot(act);
         if (FILL && act) a.active_idx[base + n + __popcll(m & ((1ull << lane) - 1ull))] = r * a.T + s;
         n += __popcll(m);
@@ -548,13 +561,25 @@ __global__ __launch_bounds__(kRayWaves * 64) void background_active_kernel(VdnBa
     }
 }
 
+static int launch_active(const ActiveJob& j, void* stream) {
+    const dim3 grid((j.B + kRayWaves - 1) / kRayWaves), block(kRayWaves * 64);
+    hipLaunchKernelGGL(active_list_kernel<false>, grid, block, 0, (hipStream_t)stream, j);
+    hipLaunchKernelGGL(active_list_kernel<true>, grid, block, 0, (hipStream_t)stream, j);
+    return (int)hipGetLastError();
+}
+
 extern "C" int vdn_background_active(const VdnBackgroundActiveArgs* a, void* stream) {
     if (!a || a->B <= 0 || a->N < 0 || a->T < a->N || !a->rays_o || !a->rays_d || (a->N > 0 && !a->mid_z) ||
         !a->active_idx || !a->n_active || !a->ray_counts) return -1;
-    const dim3 grid((a->B + kRayWaves - 1) / kRayWaves), block(kRayWaves * 64);
-    hipLaunchKernelGGL(background_active_kernel<false>, grid, block, 0, (hipStream_t)stream, *a);
-    hipLaunchKernelGGL(background_active_kernel<true>, grid, block, 0, (hipStream_t)stream, *a);
-    return (int)hipGetLastError();
+    const ActiveJob j = {a->rays_o, a->rays_d, a->mid_z, a->B, a->N, a->T, 1.0f, true, a->active_idx, a->n_active, a->ray_counts};
+    return launch_active(j, stream);
+}
+
+extern "C" int vdn_foreground_active(const VdnForegroundActiveArgs* a, void* stream) {
+    if (!a || a->B <= 0 || a->N <= 0 || !a->rays_o || !a->rays_d || !a->mid_z || !(a->radius > 0.0f) ||
+        !a->active_idx || !a->n_active || !a->ray_counts) return -1;
+    const ActiveJob j = {a->rays_o, a->rays_d, a->mid_z, a->B, a->N, a->N, a->radius, false, a->active_idx, a->n_active, a->ray_counts};
+    return launch_active(j, stream);
 }
 
 extern "C" int vdn_sections(const VdnSectionArgs* a, void* stream) {

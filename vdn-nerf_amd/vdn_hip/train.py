@@ -67,6 +67,7 @@ class TrainEngine:
         self._ev_fork = torch.cuda.Event() if use_side else None
         self._ev_join = torch.cuda.Event() if use_side else None
         self._pending = False
+        self._fg_compact = self._bg_compact = False
         precs = {m.precision for m in (renderer.nerf, renderer.sdf_network, renderer.color_network, renderer.depth_network) if m is not None}
         if len(precs) != 1:
             raise ValueError("all networks of a renderer must share one precision, got %s" % sorted(precs))
@@ -83,11 +84,16 @@ class TrainEngine:
         w = self.w = {}
         # ---- forward saves
         w["dists"], w["mid_z"] = f(B, N), f(B, N)
-        w["sdf"], w["feat"], w["normals"] = f(P), fs(Pp, 256), f(P, 3)
+        # dense per-point outputs are zero-initialised: points a work list skips keep finite values, and the compositor only
+        # ever multiplies those by exact zeros (include/vdn_render.h: vdn_foreground_active / vdn_background_active)
+        fz = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
+        w["sdf"], w["feat"], w["normals"] = fz(P), fs(Pp, 256), fz(P, 3)
+        w["fg_active"] = (torch.zeros(P, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev),
+                          torch.zeros(B, dtype=torch.int32, device=dev))
         w["S"], w["H"], w["V"], w["PE"] = fs(8, Pp, 256), fs(8, Pp, 256), fs(8, Pp, 256), fs(Pp, 64)
-        w["col_out"], w["col_h"], w["col_small"] = f(P, 3), fs(4, Pp, 256), fs(Pp, 64)
+        w["col_out"], w["col_h"], w["col_small"] = fz(P, 3), fs(4, Pp, 256), fs(Pp, 64)
         if self.wdepth:
-            w["vdn_out"], w["vdn_h"], w["vdn_small"] = f(P, 96), fs(4, Pp, 256), fs(Pp, 64)
+            w["vdn_out"], w["vdn_h"], w["vdn_small"] = fz(P, 96), fs(4, Pp, 256), fs(Pp, 64)
         if O > 0:
             w["z_feed"], w["bg_dists"], w["bg_mid"] = f(B, T), f(B, T), f(B, T)
             # zero-initialised: points the active list skips keep finite values (the compositor multiplies them by zero)
@@ -224,6 +230,7 @@ class TrainEngine:
         self.slab = torch.empty(max(slab_elems, 1), dtype=torch.float32, device=dev)
         self.colsum = torch.empty(max(cs_elems, 1), dtype=torch.float32, device=dev)
         P4 = lambda spec: spec[0].data_ptr() + spec[0].element_size() * (spec[1] + layout.col_offset_elems(spec[2], prec))
+        self.dw_list_kind = []
         for i, e in enumerate(ent):
             mt, nt, splits, so, co, mo, wg0 = lay[i]
             d = dw[i]
@@ -233,8 +240,9 @@ class TrainEngine:
             if e.get("A2") is not None:
                 d["A2"], d["lda2"], d["B2"], d["ldb2"] = P4(e["A2"]), e["A2"][3], P4(e["B2"]), e["B2"][3]
             d["P"], d["m_tiles"], d["n_tiles"], d["splits"], d["wg_begin"] = e["Pn"], mt, nt, splits, wg0
-            if e["net"] == "nerf":
-                d["P_dev"] = w["bg_active"][1].data_ptr()       # rows of the compact background list (device scalar)
+            # rows of the compact work lists (device scalars written by the forward)
+            d["P_dev"] = (w["bg_active"] if e["net"] == "nerf" else w["fg_active"])[1].data_ptr()
+            self.dw_list_kind.append("bg" if e["net"] == "nerf" else "fg")
             d["slab"] = self.slab.data_ptr() + 4 * so
             want_cs = e["bias"] or e.get("extra_row0")
             d["colsum"] = self.colsum.data_ptr() + 4 * co if want_cs else 0
@@ -277,8 +285,12 @@ class TrainEngine:
         return tuple(p.data_ptr() for net in self.nets.values() for p in net.module.parameters())
 
     # ------------------------------------------------------------------------------------------
-    def forward(self, rays_o, rays_d, z, z_out, background_rgb, cos_anneal_ratio):
-        """Differentiable part of render() at detached z [B,N] (+ z_out [B,O]); returns the output tensors."""
+    def forward(self, rays_o, rays_d, z, z_out, background_rgb, cos_anneal_ratio, skip_far=False):
+        """Differentiable part of render() at detached z [B,N] (+ z_out [B,O]); returns the output tensors.
+        skip_far (the Trainer's hot loop): inside samples beyond the relaxed sphere (|p| >= 1.2: inside_sphere = 0 and
+        relax_inside_sphere = 0, renderer.py:284-286) enter the loss only through exact zeros, so the SDF / colour / VDN
+        networks skip them; `normals` / `sdf` are then only valid at the listed points (render() never sets it: it returns
+        `gradients` for every sample)."""
         r, w, B, N, T = self.r, self.w, self.B, self.N, self.T
         st = _stream()
         for net in self.nets.values():
@@ -289,6 +301,14 @@ class TrainEngine:
         a = lib.VdnSectionArgs()
         a.z, a.dists, a.mid_z, a.sample_dist, a.B, a.n, a.ld = z.data_ptr(), w["dists"].data_ptr(), w["mid_z"].data_ptr(), sample_dist, B, N, z.stride(0)
         lib.call("vdn_sections", a, st)
+        self._fg_compact = bool(skip_far) and os.environ.get("VDN_FG_COMPACT", "1") != "0"
+        if self._fg_compact:
+            fa = lib.VdnForegroundActiveArgs()
+            fa.rays_o, fa.rays_d, fa.mid_z, fa.B, fa.N, fa.radius = rays_o.data_ptr(), rays_d.data_ptr(), w["mid_z"].data_ptr(), B, N, 1.2
+            fa.active_idx, fa.n_active, fa.ray_counts = (t.data_ptr() for t in w["fg_active"])
+            lib.call("vdn_foreground_active", fa, st)
+        else:
+            w["fg_active"][1].fill_(self.P)               # the dW GEMM's device-side row count
         O = r.n_outside
         if O > 0:
             m = lib.VdnMergeArgs()
@@ -326,7 +346,7 @@ class TrainEngine:
             c.normals, c.feat, c.out = w["normals"].data_ptr(), w["feat"].data_ptr(), out.data_ptr()
             c.save_h, c.save_small = save_h.data_ptr(), small.data_ptr()
             c.P, c.d_out, c.squeeze_out = self.P, d_out, int(module.squeeze_out)
-            lib.call("vdn_rendernet_fwd" + self.sfx, c, st)
+            lib.call("vdn_rendernet_fwd" + self.sfx, self._fg(c), st)
         if self.wdepth:
             rnet("vdn", w["vdn_out"], w["vdn_h"], w["vdn_small"], 96, r.depth_network)
         rnet("color", w["col_out"], w["col_h"], w["col_small"], 3, r.color_network)
@@ -342,6 +362,12 @@ class TrainEngine:
         self._ctx = (rays_o, rays_d, background_rgb, cos_anneal_ratio, z)
         self.generation = getattr(self, "generation", 0) + 1
         return w
+
+    def _fg(self, args):
+        """Attach the foreground work list of the current forward to a kernel argument block."""
+        if self._fg_compact:
+            args.active_idx, args.n_active = self.w["fg_active"][0].data_ptr(), self.w["fg_active"][1].data_ptr()
+        return args
 
     # ---- optional side stream for the background network (VDN_SIDE_STREAM=1; default: everything on the caller's stream)
     def _fork(self):
@@ -374,26 +400,28 @@ class TrainEngine:
         s.sdf, s.feat, s.normals, s.S = w["sdf"].data_ptr(), w["feat"].data_ptr(), w["normals"].data_ptr(), w["S"].data_ptr()
         s.w8row = img.weff_view("lin8").data_ptr()
         s.H, s.V, s.PE = w["H"].data_ptr(), w["V"].data_ptr(), w["PE"].data_ptr()
-        lib.call("vdn_sdf_mlp_fwd" + self.sfx, 1, s, _stream())
+        lib.call("vdn_sdf_mlp_fwd" + self.sfx, 1, self._fg(s), _stream())
+
+    def _dw_rows(self):
+        """Rows each weight-gradient entry contracts over in the current step (the work lists of the last forward)."""
+        n = {"bg": int(self.w["bg_active"][1].item()) if "bg_active" in self.w else 0, "fg": int(self.w["fg_active"][1].item())}
+        tab = np.frombuffer(self.dw_table.cpu().numpy().tobytes(), dtype=lib.struct_dtype("VdnDwDesc"))
+        return tab, [min(int(d["P"]), n[k]) for d, k in zip(tab, self.dw_list_kind)]
 
     def dw_bytes(self):
         """Algorithmic HBM bytes of one weight-gradient GEMM launch: every operand plane read once + the slabs written."""
         esz = 4 if self.precision == "fp32" else 2
         total = 0
-        tab = np.frombuffer(self.dw_table.cpu().numpy().tobytes(), dtype=lib.struct_dtype("VdnDwDesc"))
-        n_bg = int(self.w["bg_active"][1].item()) if "bg_active" in self.w else 0
-        for d in tab:
+        tab, rows = self._dw_rows()
+        for d, r in zip(tab, rows):
             segs = 2 if d["A2"] else 1
-            rows = min(int(d["P"]), n_bg) if d["P_dev"] else int(d["P"])     # background operands: the compact list of the last forward
-            total += segs * rows * 32 * (int(d["m_tiles"]) + int(d["n_tiles"])) * esz
+            total += segs * r * 32 * (int(d["m_tiles"]) + int(d["n_tiles"])) * esz
             total += int(d["splits"]) * int(d["m_tiles"]) * 32 * int(d["n_tiles"]) * 32 * 4
         return total
 
     def dw_flops(self):
-        tab = np.frombuffer(self.dw_table.cpu().numpy().tobytes(), dtype=lib.struct_dtype("VdnDwDesc"))
-        n_bg = int(self.w["bg_active"][1].item()) if "bg_active" in self.w else 0
-        rows = lambda d: min(int(d["P"]), n_bg) if d["P_dev"] else int(d["P"])
-        return sum(2.0 * (2 if d["A2"] else 1) * rows(d) * int(d["m_tiles"]) * 32 * int(d["n_tiles"]) * 32 for d in tab)
+        tab, rows = self._dw_rows()
+        return sum(2.0 * (2 if d["A2"] else 1) * r * int(d["m_tiles"]) * 32 * int(d["n_tiles"]) * 32 for d, r in zip(tab, rows))
 
     def _launch_dw(self):
         lib.call("vdn_dw_gemm" + self.sfx, lib.ptr(self.dw_table), self.n_dw, self.dw_total_wgs, _stream())
@@ -465,7 +493,7 @@ class TrainEngine:
             b.d_feat, b.d_normals = w["d_featvec"].data_ptr(), w["d_normals"].data_ptr()
             b.acc_feat, b.acc_normals = int(accumulate), 1
             b.P, b.d_out, b.squeeze_out = self.P, d_out, int(module.squeeze_out)
-            lib.call("vdn_rendernet_bwd" + self.sfx, b, st)
+            lib.call("vdn_rendernet_bwd" + self.sfx, self._fg(b), st)
         # d_normals already holds the alpha + eikonal parts: the heads add their input gradients into it;
         # d_featvec is overwritten by the first head and accumulated by the second
         rnet_bwd("color", w["d_color"], w["col_out"], w["col_h"], w["col_dout"], w["col_dh"], 3, r.color_network, False)
@@ -483,12 +511,12 @@ class TrainEngine:
         s_planes = w["H"] if s_from_h else w["S"]
         rb.g_normals, rb.S, rb.V, rb.UB, rb.EX = w["d_normals"].data_ptr(), s_planes.data_ptr(), w["V"].data_ptr(), w["UB"].data_ptr(), w["EX"].data_ptr()
         rb.s_from_h = s_from_h
-        lib.call("vdn_sdf_bwd_rbar" + self.sfx, rb, st)
+        lib.call("vdn_sdf_bwd_rbar" + self.sfx, self._fg(rb), st)
         fb = lib.VdnSdfFbarArgs()
         fb.blob = img.blobs["fbar"].data_ptr()
         fb.g_sdf, fb.g_feat, fb.S, fb.EX, fb.AB = w["d_sdf"].data_ptr(), w["d_featvec"].data_ptr(), s_planes.data_ptr(), w["EX"].data_ptr(), w["AB"].data_ptr()
         fb.P, fb.scale, fb.s_from_h = self.P, float(r.sdf_network.scale), s_from_h
-        lib.call("vdn_sdf_bwd_fbar" + self.sfx, fb, st)
+        lib.call("vdn_sdf_bwd_fbar" + self.sfx, self._fg(fb), st)
 
         self._join()
         self._launch_dw()
