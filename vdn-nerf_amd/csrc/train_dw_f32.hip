@@ -132,8 +132,20 @@ __global__ void dw_finalize_kernel(const DwFinalizeDesc* descs, int phase) {
         for (int j = threadIdx.x; j < d.N; j += blockDim.x) {
             const int cc = d.cmap[j];
             if (cc < 0) continue;
-            float v = 0.0f;
-            for (int s = 0; s < d.splits; ++s) v += d.slab[((long)s * d.M + i) * d.N + j];
+            // fixed summation order (s ascending within four interleaved partial sums): deterministic, and four loads in
+            // flight per thread instead of one dependent chain
+            float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
+            const float* col = d.slab + (long)i * d.N + j;
+            const long step = (long)d.M * d.N;
+            int s = 0;
+            for (; s + 4 <= d.splits; s += 4) {
+                v0 += col[(s + 0) * step];
+                v1 += col[(s + 1) * step];
+                v2 += col[(s + 2) * step];
+                v3 += col[(s + 3) * step];
+            }
+            for (; s < d.splits; ++s) v0 += col[s * step];
+            const float v = (v0 + v1) + (v2 + v3);
             float* t = d.target + (long)r * d.t_stride + cc;
             *t = d.accumulate ? *t + d.scale * v : d.scale * v;
         }
