@@ -351,3 +351,35 @@ def test_trainer_work_lists_do_not_change_the_step(monkeypatch, precision):
     assert np.array_equal(sc1, sc0)
     for a, b in zip(g1, g0):
         assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-12
+
+
+def test_trainer_without_background_evaluates_every_sample():
+    """n_outside = 0: render_core has no inside_sphere blend (renderer.py:289), so the Trainer must not skip far samples;
+    its step equals the autograd path's loss and gradients."""
+    from vdn_train import synth, factory
+    from vdn_train.trainer import Trainer
+    dev = torch.device("cuda:0")
+    B, seed = 96, 59
+    st = synth.make_all_states(seed, wdepth=False)
+    cams = synth.make_cameras(seed)
+    o, d = synth.random_pixel_batch(seed, 0, 1, B, cams=cams)
+    near, far = synth.near_far_from_sphere(o, d)
+    t1, _ = synth.jitter(seed, 0, B)
+    o, d, near, far, t1 = (g(x, dev) for x in (o, d, near, far, t1))
+    rgb = g(synth.uniform(seed, "nb/rgb", (B, 3)), dev)
+    tr = Trainer(factory.build_renderer(device=dev, states=st, n_outside=0), B, dev)
+    tr.iter_step = 10
+    sc = tr.train_step(o, d, near, far, rgb, t_rand=t1).cpu().numpy()
+    assert int(tr.engine.w["fg_active"][1]) == B * 128
+    got = tr.engine.param_grads()
+    rend = factory.build_renderer(device=dev, states=st, n_outside=0)
+    out = rend.render(o, d, near, far, background_rgb=torch.ones(1, 3, device=dev), cos_anneal_ratio=10 / 50000, t_rand=t1)     # the Trainer's value at iter_step 10
+    loss = (out["color_fine"] - rgb).abs().sum() / (B + 1e-5) + 0.1 * out["gradient_error"]
+    loss.backward()
+    assert abs(sc[0] - loss.item()) <= 2e-6 * abs(loss.item())
+    grads = {id(p): gr for p, gr in zip(tr.params, got)}
+    for p_ref, p_tr in zip(rend._all_parameters(), tr.params):
+        if p_ref.grad is None:
+            continue
+        gr = grads[id(p_tr)]
+        assert (p_ref.grad - gr).abs().max().item() <= 1e-5 * p_ref.grad.abs().max().item() + 1e-12

@@ -301,7 +301,9 @@ class TrainEngine:
         a = lib.VdnSectionArgs()
         a.z, a.dists, a.mid_z, a.sample_dist, a.B, a.n, a.ld = z.data_ptr(), w["dists"].data_ptr(), w["mid_z"].data_ptr(), sample_dist, B, N, z.stride(0)
         lib.call("vdn_sections", a, st)
-        self._fg_compact = bool(skip_far) and os.environ.get("VDN_FG_COMPACT", "1") != "0"
+        # without a background pass (n_outside = 0) render_core does not blend with inside_sphere (renderer.py:289): every
+        # foreground sample counts, nothing may be skipped
+        self._fg_compact = bool(skip_far) and r.n_outside > 0 and os.environ.get("VDN_FG_COMPACT", "1") != "0"
         if self._fg_compact:
             fa = lib.VdnForegroundActiveArgs()
             fa.rays_o, fa.rays_d, fa.mid_z, fa.B, fa.N, fa.radius = rays_o.data_ptr(), rays_d.data_ptr(), w["mid_z"].data_ptr(), B, N, 1.2
