@@ -124,6 +124,10 @@ class NeuSRenderer:
             raise ValueError("n_importance must be a multiple of up_sample_steps with at most 64 samples per round")
         if n_samples + n_importance + n_outside > 256 or n_outside > 64:
             raise ValueError("the per-ray kernels handle up to 256 samples per ray and n_outside <= 64")
+        if depth_network is not None and n_outside > 0 and not getattr(nerf, "gen_depth_feats", False):
+            # renderer.py:295-299 blends the VDN features with the background's only when the NeRF produces them; the
+            # kernels implement the shipped pairing (womsk_white_wdepth: both on)
+            raise ValueError("a depth_network needs a background NeRF with gen_depth_feats=True (the shipped wdepth configuration)")
         self._const_cache = {}
 
     # constant vectors whose rounding must be torch.linspace's (renderer.py:335,340,352-354; 53)
