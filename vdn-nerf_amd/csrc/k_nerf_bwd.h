@@ -49,7 +49,6 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void nerf_bwd_ke
             }
         }
     }
-    constexpr int C4 = P::chunk_bytes(4), C8 = P::chunk_bytes(8), C9 = P::chunk_bytes(9), CO = P::chunk_bytes(KO);
     auto ldH = [&](int l) VDN_INL { return [=](int nt) VDN_INL { return P::load_tile(save_h + l * PS, p, 256, nt, h); }; };
     auto mask_store = [&](auto& D, ST* dst, int ld) VDN_INL {
         return [&D, dst, ld, p, ok, h](int nt, const f32x16& acc, const f32x16& hv) VDN_INL {
@@ -63,10 +62,10 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void nerf_bwd_ke
     ws.all_issue = __any(ok);
     ws.start();
     // Wout^T: -> d hv (128), masked by the views layer's ReLU
-    dense<P, KO, 4, C4, false>(ws, X, 0, [&](int nt) VDN_INL { return P::load_tile(save_hv, p, 128, nt, h); },
+    dense<P, KO, 4, false>(ws, X, 0, [&](int nt) VDN_INL { return P::load_tile(save_hv, p, 128, nt, h); },
                                mask_store(Y, delta_v, 128), 4);
     // Wviews^T: -> d [feature (8 tiles) | PE(view) (dropped)]; feature_linear has no activation
-    dense<P, 4, 9, C9, false>(ws, Y, 0, NoPre{}, [&](int nt, const f32x16& acc, int) VDN_INL {
+    dense<P, 4, 9, false>(ws, Y, 0, NoPre{}, [&](int nt, const f32x16& acc, int) VDN_INL {
         if (nt < 8) {
             X.set(nt, acc);
             P::store_tile(delta_head, p, 288, nt, h, acc, ok);
@@ -78,11 +77,11 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void nerf_bwd_ke
         X.set(8, t16);
         P::store_tile(delta_head, p, 288, 8, h, t16, ok);
     }
-    dense<P, 9, 8, C8, false>(ws, X, 0, ldH(7), mask_store(Y, delta_h + 7 * PS, 256), 4, 4);     // Whead^T
-    dense<P, 8, 8, C8, false>(ws, Y, 0, ldH(6), mask_store(X, delta_h + 6 * PS, 256), 4, 4);     // W7^T
-    dense<P, 8, 8, C8, false>(ws, X, 0, ldH(5), mask_store(Y, delta_h + 5 * PS, 256), 4, 4);     // W6^T
+    dense<P, 9, 8, false>(ws, X, 0, ldH(7), mask_store(Y, delta_h + 7 * PS, 256), 4, 4);     // Whead^T
+    dense<P, 8, 8, false>(ws, Y, 0, ldH(6), mask_store(X, delta_h + 6 * PS, 256), 4, 4);     // W7^T
+    dense<P, 8, 8, false>(ws, X, 0, ldH(5), mask_store(Y, delta_h + 5 * PS, 256), 4, 4);     // W6^T
     // W5^T: 11 output tiles = [PE (3, dropped) | h4 (8)]
-    dense<P, 8, 11, C8, false>(ws, Y, 0,
+    dense<P, 8, 11, false>(ws, Y, 0,
         [&](int nt) VDN_INL { return nt >= 3 ? P::load_tile(save_h + 4 * PS, p, 256, nt - 3, h) : f32x16{}; },
         [&](int nt, const f32x16& acc, const f32x16& hv) VDN_INL {
             if (nt >= 3) {
@@ -93,10 +92,10 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void nerf_bwd_ke
                 P::store_tile(delta_h + 4 * PS, p, 256, nt - 3, h, o, ok);
             }
         });
-    dense<P, 8, 8, C8, false>(ws, X, 0, ldH(3), mask_store(Y, delta_h + 3 * PS, 256), 4, 4);     // W4^T
-    dense<P, 8, 8, C8, false>(ws, Y, 0, ldH(2), mask_store(X, delta_h + 2 * PS, 256), 4, 4);     // W3^T
-    dense<P, 8, 8, C8, false>(ws, X, 0, ldH(1), mask_store(Y, delta_h + 1 * PS, 256), 4, 4);     // W2^T
-    dense<P, 8, 8, 0, false>(ws, Y, 0, ldH(0), mask_store(X, delta_h + 0 * PS, 256), 4, 4);      // W1^T
+    dense<P, 8, 8, false>(ws, X, 0, ldH(3), mask_store(Y, delta_h + 3 * PS, 256), 4, 4);     // W4^T
+    dense<P, 8, 8, false>(ws, Y, 0, ldH(2), mask_store(X, delta_h + 2 * PS, 256), 4, 4);     // W3^T
+    dense<P, 8, 8, false>(ws, X, 0, ldH(1), mask_store(Y, delta_h + 1 * PS, 256), 4, 4);     // W2^T
+    dense<P, 8, 8, false>(ws, Y, 0, ldH(0), mask_store(X, delta_h + 0 * PS, 256), 4, 4);      // W1^T
 }
 
 template <class P>

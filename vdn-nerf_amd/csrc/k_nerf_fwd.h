@@ -71,25 +71,24 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void nerf_fwd_ke
         };
     };
     auto sv = [&](int l) VDN_INL { return save_h ? save_h + l * PS : (ST*)nullptr; };
-    constexpr int C3 = P::chunk_bytes(3), C4 = P::chunk_bytes(4), C8 = P::chunk_bytes(8), C9 = P::chunk_bytes(9), C11 = P::chunk_bytes(11);
     const int est = save_h != nullptr ? 4 : 0;
     ws.all_issue = __any(ok);
     put_pe(true);
     ws.start();
-    dense<P, 3, 8, C8, true>(ws, X, 0, NoPre{}, relu_into(Y, 0, sv(0), 256), est);          // pts_linears.0
-    dense<P, 8, 8, C8, true>(ws, Y, 0, NoPre{}, relu_into(X, 0, sv(1), 256), est);          // 1
-    dense<P, 8, 8, C8, true>(ws, X, 0, NoPre{}, relu_into(Y, 0, sv(2), 256), est);          // 2
-    dense<P, 8, 8, C8, true>(ws, Y, 0, NoPre{}, relu_into(X, 0, sv(3), 256), est);          // 3
-    dense<P, 8, 8, C11, true>(ws, X, 0, NoPre{}, relu_into(Y, 0, sv(4), 256), est);         // 4
+    dense<P, 3, 8, true>(ws, X, 0, NoPre{}, relu_into(Y, 0, sv(0), 256), est);          // pts_linears.0
+    dense<P, 8, 8, true>(ws, Y, 0, NoPre{}, relu_into(X, 0, sv(1), 256), est);          // 1
+    dense<P, 8, 8, true>(ws, X, 0, NoPre{}, relu_into(Y, 0, sv(2), 256), est);          // 2
+    dense<P, 8, 8, true>(ws, Y, 0, NoPre{}, relu_into(X, 0, sv(3), 256), est);          // 3
+    dense<P, 8, 8, true>(ws, X, 0, NoPre{}, relu_into(Y, 0, sv(4), 256), est);         // 4
     // skip (fields.py:334-335): h = cat([input_pts, h]) -> X = [PE (3 tiles) | h (8 tiles)]
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt) X.copy_tile(3 + kt, Y, kt);
     put_pe(false);
-    dense<P, 11, 8, C8, true>(ws, X, 0, NoPre{}, relu_into(Y, 0, sv(5), 256), est);         // 5
-    dense<P, 8, 8, C8, true>(ws, Y, 0, NoPre{}, relu_into(X, 0, sv(6), 256), est);          // 6
-    dense<P, 8, 8, C8, true>(ws, X, 0, NoPre{}, relu_into(Y, 0, sv(7), 256), est);          // 7
+    dense<P, 11, 8, true>(ws, X, 0, NoPre{}, relu_into(Y, 0, sv(5), 256), est);         // 5
+    dense<P, 8, 8, true>(ws, Y, 0, NoPre{}, relu_into(X, 0, sv(6), 256), est);          // 6
+    dense<P, 8, 8, true>(ws, X, 0, NoPre{}, relu_into(Y, 0, sv(7), 256), est);          // 7
     // heads on h: image rows 0..255 feature_linear, row 256 alpha_linear
-    dense<P, 8, 9, C9, true>(ws, Y, 0, NoPre{}, [&](int nt, const f32x16& acc, int) VDN_INL {
+    dense<P, 8, 9, true>(ws, Y, 0, NoPre{}, [&](int nt, const f32x16& acc, int) VDN_INL {
         if (nt < 8) {
             X.set(nt, acc);
             if (a.save_feature != nullptr) P::store_tile(reinterpret_cast<ST*>(a.save_feature), q, 256, nt, h, acc, ok);
@@ -104,9 +103,9 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void nerf_fwd_ke
         X.set(8, t16);
         if (a.save_vpe != nullptr) P::store_tile(reinterpret_cast<ST*>(a.save_vpe), q, 32, 0, h, t16, ok);
     }
-    dense<P, 9, 4, C4, true>(ws, X, 0, NoPre{}, relu_into(Y, 0, reinterpret_cast<ST*>(a.save_hv), 128));
+    dense<P, 9, 4, true>(ws, X, 0, NoPre{}, relu_into(Y, 0, reinterpret_cast<ST*>(a.save_hv), 128));
     // rgb_linear (image tile 0, rows 0..2) and dpt_linear (image tiles 1..3)
-    dense<P, 4, DPT ? 4 : 1, 0, true>(ws, Y, 0, NoPre{}, [&](int nt, const f32x16& acc, int) VDN_INL {
+    dense<P, 4, DPT ? 4 : 1, true>(ws, Y, 0, NoPre{}, [&](int nt, const f32x16& acc, int) VDN_INL {
         if (nt == 0) {
             if (ok && h == 0) {
                 a.rgb[p * 3 + 0] = acc[0];

@@ -63,15 +63,14 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_b
             P::store_tile(delta_h + l * PS, p, 256, nt, h, o, ok);
         };
     };
-    constexpr int C8 = P::chunk_bytes(8), CO = P::chunk_bytes(NT_OUT);
     ws.all_issue = __any(ok);
     ws.start();
-    dense<P, NT_OUT, 8, C8, false>(ws, X, 0, ldH(3), mask_store(Y, 3), 4, 4);   // W4^T
-    dense<P, 8, 8, C8, false>(ws, Y, 0, ldH(2), mask_store(X, 2), 4, 4);        // W3^T
-    dense<P, 8, 8, C8, false>(ws, X, 0, ldH(1), mask_store(Y, 1), 4, 4);        // W2^T
-    dense<P, 8, 8, C8, false>(ws, Y, 0, ldH(0), mask_store(X, 0), 4, 4);        // W1^T
+    dense<P, NT_OUT, 8, false>(ws, X, 0, ldH(3), mask_store(Y, 3), 4, 4);   // W4^T
+    dense<P, 8, 8, false>(ws, Y, 0, ldH(2), mask_store(X, 2), 4, 4);        // W3^T
+    dense<P, 8, 8, false>(ws, X, 0, ldH(1), mask_store(Y, 1), 4, 4);        // W2^T
+    dense<P, 8, 8, false>(ws, Y, 0, ldH(0), mask_store(X, 0), 4, 4);        // W1^T
     f32x16 SM[2];
-    dense<P, 8, 10, 0, false>(ws, X, 0, NoPre{}, [&](int nt, const f32x16& acc, int) VDN_INL {   // W0^T
+    dense<P, 8, 10, false>(ws, X, 0, NoPre{}, [&](int nt, const f32x16& acc, int) VDN_INL {   // W0^T
         if (nt < 8) {
             f32x16 o = acc;
             if (a.acc_feat) {

@@ -61,15 +61,14 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_f
             if (save_h != nullptr) P::store_tile(save_h + l * PS, p, 256, nt, h, o, ok);
         };
     };
-    constexpr int C10 = P::chunk_bytes(10), C8 = P::chunk_bytes(8);
     const int est = save_h != nullptr ? 4 : 0;
     ws.all_issue = __any(ok);
     ws.start();
-    dense<P, 10, 8, C8, true>(ws, X, 0, NoPre{}, relu_into(Y, 0), est);
-    dense<P, 8, 8, C8, true>(ws, Y, 0, NoPre{}, relu_into(X, 1), est);
-    dense<P, 8, 8, C8, true>(ws, X, 0, NoPre{}, relu_into(Y, 2), est);
-    dense<P, 8, 8, C8, true>(ws, Y, 0, NoPre{}, relu_into(X, 3), est);
-    dense<P, 8, NT_OUT, 0, true>(ws, X, 0, NoPre{}, [&](int nt, const f32x16& acc, int) VDN_INL {
+    dense<P, 10, 8, true>(ws, X, 0, NoPre{}, relu_into(Y, 0), est);
+    dense<P, 8, 8, true>(ws, Y, 0, NoPre{}, relu_into(X, 1), est);
+    dense<P, 8, 8, true>(ws, X, 0, NoPre{}, relu_into(Y, 2), est);
+    dense<P, 8, 8, true>(ws, Y, 0, NoPre{}, relu_into(X, 3), est);
+    dense<P, 8, NT_OUT, true>(ws, X, 0, NoPre{}, [&](int nt, const f32x16& acc, int) VDN_INL {
         f32x16 o;
 #pragma unroll
         for (int t = 0; t < 16; ++t) o[t] = a.squeeze_out ? sigmoidf_(acc[t]) : relu0(acc[t]);

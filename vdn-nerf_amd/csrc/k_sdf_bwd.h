@@ -108,23 +108,22 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_rbar_ke
             P::store_tile(EX + l * PS, p, 256, nt, h, ex, ok);
         };
     };
-    constexpr int C2 = P::chunk_bytes(2), C8 = P::chunk_bytes(8), C9 = P::chunk_bytes(9);
     ws.all_issue = __any(ok);
     ws.start();
-    dense<P, 2, 8, C8, false>(ws, X, 0, ldSV(0), epi(Y, ub1, 256, 0), 8, 8);
-    dense<P, 8, 8, C8, false>(ws, Y, 0, ldSV(1), epi(X, ub2, 256, 1), 8, 8);
-    dense<P, 8, 8, C8, false>(ws, X, 0, ldSV(2), epi(Y, ub3, 256, 2), 8, 8);
-    dense<P, 8, 7, C9, false>(ws, Y, 0, ldSV(3), epi(X, ub4, 288, 3), 8, 8);      // ub_4[h part]: 7 tiles
+    dense<P, 2, 8, false>(ws, X, 0, ldSV(0), epi(Y, ub1, 256, 0), 8, 8);
+    dense<P, 8, 8, false>(ws, Y, 0, ldSV(1), epi(X, ub2, 256, 1), 8, 8);
+    dense<P, 8, 8, false>(ws, X, 0, ldSV(2), epi(Y, ub3, 256, 2), 8, 8);
+    dense<P, 8, 7, false>(ws, Y, 0, ldSV(3), epi(X, ub4, 288, 3), 8, 8);      // ub_4[h part]: 7 tiles
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {                                        // ub_4[PE part] = ub_total
         const f32x16 t16 = vals_tile<39>(ub39, h, kt);
         X.set(7 + kt, t16);
         P::store_tile(ub4, p, 288, 7 + kt, h, t16, ok);
     }
-    dense<P, 9, 8, C8, false>(ws, X, 0, ldSV(4), epi(Y, ub5, 256, 4), 8, 8);
-    dense<P, 8, 8, C8, false>(ws, Y, 0, ldSV(5), epi(X, ub6, 256, 5), 8, 8);
-    dense<P, 8, 8, C8, false>(ws, X, 0, ldSV(6), epi(Y, ub7, 256, 6), 8, 8);
-    dense<P, 8, 8, 0, false>(ws, Y, 0, ldSV(7), epi(X, ub8, 256, 7), 8, 8);
+    dense<P, 9, 8, false>(ws, X, 0, ldSV(4), epi(Y, ub5, 256, 4), 8, 8);
+    dense<P, 8, 8, false>(ws, Y, 0, ldSV(5), epi(X, ub6, 256, 5), 8, 8);
+    dense<P, 8, 8, false>(ws, X, 0, ldSV(6), epi(Y, ub7, 256, 6), 8, 8);
+    dense<P, 8, 8, false>(ws, Y, 0, ldSV(7), epi(X, ub8, 256, 7), 8, 8);
 }
 
 template <class P>
@@ -180,16 +179,15 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_fbar_ke
             P::store_tile(dst, p, 256, nt, h, o, ok);
         };
     };
-    constexpr int C7 = P::chunk_bytes(7), C8 = P::chunk_bytes(8), C9 = P::chunk_bytes(9);
     ws.all_issue = __any(ok);
     ws.start();
-    dense<P, 9, 8, C8, false>(ws, X, 0, ldSE(7), epi(Y, 7), 4, 8);     // W8^T
-    dense<P, 8, 8, C8, false>(ws, Y, 0, ldSE(6), epi(X, 6), 4, 8);     // W7^T
-    dense<P, 8, 8, C8, false>(ws, X, 0, ldSE(5), epi(Y, 5), 4, 8);     // W6^T
-    dense<P, 8, 8, C8, false>(ws, Y, 0, ldSE(4), epi(X, 4), 4, 8);     // W5^T
+    dense<P, 9, 8, false>(ws, X, 0, ldSE(7), epi(Y, 7), 4, 8);     // W8^T
+    dense<P, 8, 8, false>(ws, Y, 0, ldSE(6), epi(X, 6), 4, 8);     // W7^T
+    dense<P, 8, 8, false>(ws, X, 0, ldSE(5), epi(Y, 5), 4, 8);     // W6^T
+    dense<P, 8, 8, false>(ws, Y, 0, ldSE(4), epi(X, 4), 4, 8);     // W5^T
     {   // W4^T: 9 output tiles = [h4 part (7) | PE part (2, no gradient wanted)]
         ST* dst = ab(3);
-        dense<P, 8, 9, C7, false>(ws, X, 0,
+        dense<P, 8, 9, false>(ws, X, 0,
             [&](int nt) VDN_INL {
                 SE r;
                 if (nt < 7) {
@@ -211,9 +209,9 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_fbar_ke
                 }
             });
     }
-    dense<P, 7, 8, C8, false>(ws, Y, 0, ldSE(2), epi(X, 2), 4, 8);     // W3^T
-    dense<P, 8, 8, C8, false>(ws, X, 0, ldSE(1), epi(Y, 1), 4, 8);     // W2^T
-    dense<P, 8, 8, 0, false>(ws, Y, 0, ldSE(0), epi(X, 0), 4, 8);      // W1^T
+    dense<P, 7, 8, false>(ws, Y, 0, ldSE(2), epi(X, 2), 4, 8);     // W3^T
+    dense<P, 8, 8, false>(ws, X, 0, ldSE(1), epi(Y, 1), 4, 8);     // W2^T
+    dense<P, 8, 8, false>(ws, Y, 0, ldSE(0), epi(X, 0), 4, 8);      // W1^T
 }
 
 template <class P>

@@ -91,31 +91,30 @@ __global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(Sdf
                 }
             });
     };
-    constexpr int C2 = P::chunk_bytes(2), C7 = P::chunk_bytes(7), C8 = P::chunk_bytes(8), C9 = P::chunk_bytes(9);
     const int est_h = SV ? (Hs != nullptr && !derive ? 8 : 4) : 0;     // stores per hidden-layer tile (S and / or H)
     const int est_v = Vs != nullptr ? 4 : 0;                // stores per sweep tile (V when training)
     put_pe(0);
     ws.start();
-    dense<P, 2, 8, C8, true>(ws, X, 0, NoPre{}, hidden(Y, 0), est_h);
-    dense<P, 8, 8, C8, true>(ws, Y, 0, NoPre{}, hidden(X, 1), est_h);
-    dense<P, 8, 8, C8, true>(ws, X, 0, NoPre{}, hidden(Y, 2), est_h);
-    dense<P, 8, 7, C9, true>(ws, Y, 0, NoPre{}, hidden(X, 3), est_h);
+    dense<P, 2, 8, true>(ws, X, 0, NoPre{}, hidden(Y, 0), est_h);
+    dense<P, 8, 8, true>(ws, Y, 0, NoPre{}, hidden(X, 1), est_h);
+    dense<P, 8, 8, true>(ws, X, 0, NoPre{}, hidden(Y, 2), est_h);
+    dense<P, 8, 7, true>(ws, Y, 0, NoPre{}, hidden(X, 3), est_h);
     put_pe(7);   // skip: layer-4 input = [h4 (217 -> 7 tiles) | PE (39 -> 2 tiles)] / sqrt2 (1/sqrt2 is in the image)
-    dense<P, 9, 8, C8, true>(ws, X, 0, NoPre{}, hidden(Y, 4), est_h);
-    dense<P, 8, 8, C8, true>(ws, Y, 0, NoPre{}, hidden(X, 5), est_h);
-    dense<P, 8, 8, C8, true>(ws, X, 0, NoPre{}, hidden(Y, 6), est_h);
-    dense<P, 8, 8, C8, true>(ws, Y, 0, NoPre{}, hidden(X, 7), est_h);
+    dense<P, 9, 8, true>(ws, X, 0, NoPre{}, hidden(Y, 4), est_h);
+    dense<P, 8, 8, true>(ws, Y, 0, NoPre{}, hidden(X, 5), est_h);
+    dense<P, 8, 8, true>(ws, X, 0, NoPre{}, hidden(Y, 6), est_h);
+    dense<P, 8, 8, true>(ws, Y, 0, NoPre{}, hidden(X, 7), est_h);
 
     const float inv_scale = 1.0f / a.scale;
     if constexpr (MODE == 0) {
         // last layer reduced to its sdf row (image row 0 = W8 row 0)
-        dense<P, 8, 1, 0, true>(ws, X, 0, NoPre{}, [&](int, const f32x16& acc, int) VDN_INL {
+        dense<P, 8, 1, true>(ws, X, 0, NoPre{}, [&](int, const f32x16& acc, int) VDN_INL {
             if (ok && h == 0) a.sdf[sdf_idx] = acc[0] * inv_scale;
         });
     } else {
         // image rows: 0..255 = feature rows (W8 rows 1..256), 256 = sdf row (W8 row 0)
         ST* feat = reinterpret_cast<ST*>(a.feat);
-        dense<P, 8, 9, C8, true>(ws, X, 0, NoPre{}, [&](int nt, const f32x16& acc, int) VDN_INL {
+        dense<P, 8, 9, true>(ws, X, 0, NoPre{}, [&](int nt, const f32x16& acc, int) VDN_INL {
             if (nt < 8) {
                 P::store_tile(feat, p, 256, nt, h, acc, ok);
             } else {
@@ -165,12 +164,12 @@ __global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(Sdf
                 }
             }
         };
-        dense<P, 8, 8, C8, false>(ws, Y, 0, loadS(6), mulInto(X, 6), est_v, 4);   // through W7^T
-        dense<P, 8, 8, C8, false>(ws, X, 0, loadS(5), mulInto(Y, 5), est_v, 4);   // W6^T
-        dense<P, 8, 8, C8, false>(ws, Y, 0, loadS(4), mulInto(X, 4), est_v, 4);   // W5^T
+        dense<P, 8, 8, false>(ws, Y, 0, loadS(6), mulInto(X, 6), est_v, 4);   // through W7^T
+        dense<P, 8, 8, false>(ws, X, 0, loadS(5), mulInto(Y, 5), est_v, 4);   // W6^T
+        dense<P, 8, 8, false>(ws, Y, 0, loadS(4), mulInto(X, 4), est_v, 4);   // W5^T
         {   // W4^T: 9 output tiles = [h4 part (7 tiles) | PE part (2 tiles)]
             f32x16 UPE[2];
-            dense<P, 8, 9, C7, false>(ws, X, 0,
+            dense<P, 8, 9, false>(ws, X, 0,
                 [&](int nt) VDN_INL { return nt < 7 ? P::load_tile(Ssrc + 3 * PS, p, 256, nt, h) : f32x16{}; },
                 [&](int nt, const f32x16& acc, const f32x16& sv) VDN_INL {
                     if (nt < 7) {
@@ -185,11 +184,11 @@ __global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(Sdf
                 });
             pe_backward(UPE);
         }
-        dense<P, 7, 8, C8, false>(ws, Y, 0, loadS(2), mulInto(X, 2), est_v, 4);   // W3^T
-        dense<P, 8, 8, C8, false>(ws, X, 0, loadS(1), mulInto(Y, 1), est_v, 4);   // W2^T
-        dense<P, 8, 8, C8, false>(ws, Y, 0, loadS(0), mulInto(X, 0), est_v, 4);   // W1^T
+        dense<P, 7, 8, false>(ws, Y, 0, loadS(2), mulInto(X, 2), est_v, 4);   // W3^T
+        dense<P, 8, 8, false>(ws, X, 0, loadS(1), mulInto(Y, 1), est_v, 4);   // W2^T
+        dense<P, 8, 8, false>(ws, Y, 0, loadS(0), mulInto(X, 0), est_v, 4);   // W1^T
         f32x16 U0[2];
-        dense<P, 8, 2, 0, false>(ws, X, 0, NoPre{}, [&](int nt, const f32x16& acc, int) VDN_INL { U0[nt] = acc; });   // W0^T
+        dense<P, 8, 2, false>(ws, X, 0, NoPre{}, [&](int nt, const f32x16& acc, int) VDN_INL { U0[nt] = acc; });   // W0^T
         pe_backward(U0);
         if (ok && h == 0) {
 #pragma unroll

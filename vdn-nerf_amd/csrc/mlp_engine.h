@@ -375,8 +375,7 @@ struct BF16 {
 
 // One dense layer on the wave's 32 points: for every output tile nt, acc = bias + W[nt] . X[x0 ..],
 // then epi(nt, acc, aux) with aux = pre(nt) evaluated right after the chunk is acquired (so its
-// loads overlap the MFMA loop). NEXT_BYTES = size of the chunk that follows this layer's last chunk
-// in the stream (0 at the end of the stream).
+// loads overlap the MFMA loop).
 // epi_stores = vector-memory store instructions every in-range wave issues in epi() per tile, pre_loads = load
 // instructions in pre() per tile (their sum must be 0, 4, 8, 12 or 16; a lower bound is safe, 0 drains the queue
 // at every step). Both are younger than the glds of the chunk being acquired, so they may stay in flight across
@@ -403,7 +402,7 @@ VDN_DEV ElemEpi<ScratchT, Elem, Finish> elem_epi(Elem e, Finish f) { return {e, 
 template <class T> struct is_elem_epi : std::false_type {};
 template <class S, class E, class F> struct is_elem_epi<ElemEpi<S, E, F>> : std::true_type {};
 
-template <class P, int KT, int NT, int NEXT_BYTES, bool BIAS, class WS, class ActT, class Pre, class Epi>
+template <class P, int KT, int NT, bool BIAS, class WS, class ActT, class Pre, class Epi>
 VDN_DEV void dense(WS& ws, const ActT& X, int x0, Pre&& pre, Epi&& epi, int epi_stores = 0, int pre_loads = 0) {
     const int lane = ws.lane;
     using EpiT = std::remove_cv_t<std::remove_reference_t<Epi>>;
