@@ -250,6 +250,7 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist
+        dist.barrier()                 # rank 0 is still timing single kernels / printing: leave together
         dist.destroy_process_group()
 
 
