@@ -73,3 +73,24 @@ def test_two_rank_gradient_equals_single_process_on_concatenated_batch():
     assert flat.shape == ref.shape == (1409087,)
     assert abs(eik - float(sc[3].item())) < 1e-5 * abs(eik)                 # global eikonal term
     assert np.abs(flat - ref).max() < 2e-5 * np.abs(ref).max()
+
+
+def test_bench_two_rank_control_flow():
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one rank per process), with gloo
+    and both ranks on the one GPU of this box: the barriers, the gradient all-reduce, the max-over-ranks timing and the
+    single JSON line of rank 0."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VDN_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["parallelism"] == "dp2" and d["roofline"]["frac"] > 0 and d["cpu_baseline"] is None
