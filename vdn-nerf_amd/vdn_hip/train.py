@@ -60,8 +60,8 @@ class TrainEngine:
         self.P = B * self.N
         self.Q = B * self.T
         self.wdepth = renderer.depth_network is not None
-        # opt-in (VDN_SIDE_STREAM=1): measured gain 0.4 % - both kernel families already fill the CUs - and concurrent kernels
-        # blur the per-kernel rocprof durations the roofline numbers are checked against
+        # opt-in (VDN_SIDE_STREAM=1): measured gain 1.9 % of the step; off by default because concurrent kernels blur the
+        # per-kernel rocprof durations the roofline numbers are checked against
         use_side = os.environ.get("VDN_SIDE_STREAM", "0") == "1" and torch.device(dev).type == "cuda"
         self._side = torch.cuda.Stream(device=dev) if use_side else None
         self._ev_fork = torch.cuda.Event() if use_side else None
