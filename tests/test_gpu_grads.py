@@ -383,3 +383,36 @@ def test_trainer_without_background_evaluates_every_sample():
             continue
         gr = grads[id(p_tr)]
         assert (p_ref.grad - gr).abs().max().item() <= 1e-5 * p_ref.grad.abs().max().item() + 1e-12
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("B", [1, 33, 130])
+def test_trainer_ragged_batches(B, precision):
+    """Batch sizes that are not multiples of the 32-point wave tile (partial tiles, padded bf16 planes, short work lists):
+    the Trainer's step equals render() + loss.backward() through the autograd node on the same rays."""
+    from vdn_train import synth, factory
+    from vdn_train.trainer import Trainer
+    dev = torch.device("cuda:0")
+    seed = 61
+    st = synth.make_all_states(seed, wdepth=True)
+    cams = synth.make_cameras(seed)
+    o, d = synth.random_pixel_batch(seed, B, 5, B, cams=cams, crop=600)
+    near, far = synth.near_far_from_sphere(o, d)
+    t1, t2 = synth.jitter(seed, B, B)
+    o, d, near, far, t1, t2 = (g(x, dev) for x in (o, d, near, far, t1, t2))
+    rgb, gtf = g(synth.uniform(seed, "rg/rgb%d" % B, (B, 3)), dev), g(synth.uniform(seed, "rg/f%d" % B, (B, 96)), dev)
+    tr = Trainer(factory.build_renderer(wdepth=True, device=dev, states=st, precision=precision), B, dev,
+                 conf=dict(extract_depth=True, depth_start_iter=-1))
+    tr.iter_step, tr.depth_iter = 10, 2500
+    wd, cos = tr.depth_iter_weight(), tr.cos_anneal_ratio()
+    sc = tr.train_step(o, d, near, far, rgb, gt_feats=gtf, t_rand=t1, t_rand_out=t2).cpu().numpy()
+    got = tr.engine.param_grads()
+    rend = factory.build_renderer(wdepth=True, device=dev, states=st, precision=precision)
+    out = rend.render(o, d, near, far, background_rgb=torch.ones(1, 3, device=dev), cos_anneal_ratio=cos, t_rand=t1, t_rand_out=t2)
+    ms = B + 1e-5
+    loss = (out["color_fine"] - rgb).abs().sum() / ms + 0.1 * out["gradient_error"] + (out["render_feats"] - gtf).abs().sum() / ms * wd
+    loss.backward()
+    assert np.isfinite(sc).all() and abs(sc[0] - loss.item()) <= 3e-6 * abs(loss.item())
+    tol = 2e-5 if precision == "fp32" else 2e-3          # bf16: the work lists change which rows share a dW split
+    for p, gr in zip(rend._all_parameters(), got):
+        assert (p.grad - gr).abs().max().item() <= tol * p.grad.abs().max().item() + 1e-12
