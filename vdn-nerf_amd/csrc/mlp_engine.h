@@ -409,15 +409,18 @@ VDN_DEV void dense(WS& ws, const ActT& X, int x0, Pre&& pre, Epi&& epi, int epi_
     if constexpr (P::kOverlapEpilogue && is_elem_epi<EpiT>::value) {
         // Software pipeline over the output tiles: step s acquires chunk s and issues tile s's MFMAs with elem() of tile
         // s-1 in their shadow (epi never writes X, so the order is free), then finish(s-1); step NT drains the last tile.
-        // In-flight accounting at acquire(s): younger than chunk s's DMA are at least the loads of pre(s-1) and, from
-        // s = 2 on, the stores of finish(s-2) (the chunk ahead is added inside acquire).
         f32x16 acc_prev;
         decltype(pre(0)) aux_prev{};
         static_for<NT + 1>([&](auto s_c) VDN_INL {
             constexpr int s = decltype(s_c)::value;
             typename EpiT::Scratch sc;
             if constexpr (s < NT) {
-                const int yg = s == 0 ? 0 : (s == 1 ? pre_loads : epi_stores + pre_loads);
+                // younger than chunk s's DMA (issued DEPTH steps ago) are the loads of pre(j) and the stores of finish(j-1)
+                // of the steps j = s-DEPTH .. s-1 of THIS layer (earlier layers' counts are unknown: not counted)
+                constexpr int D = WS::DEPTH;
+                constexpr int n_pre = s < D ? s : D;
+                constexpr int n_epi = s <= D ? (s > 0 ? s - 1 : 0) : D;
+                const int yg = n_pre * pre_loads + n_epi * epi_stores;
                 const char* w = ws.acquire(yg);
                 auto aux_cur = pre(s);
                 const f32x16 acc_cur = P::template mma_slots<KT, BIAS>(w, X, x0, lane, [&](auto k_c, auto ns_c) VDN_INL {
@@ -447,7 +450,8 @@ VDN_DEV void dense(WS& ws, const ActT& X, int x0, Pre&& pre, Epi&& epi, int epi_
     static_for<NT>([&](auto nt_c) VDN_INL {
         constexpr int nt = decltype(nt_c)::value;
         // tile 0 follows another layer's epilogue (unknown store count): only the chunks ahead stay in flight
-        const int yg = nt == 0 ? 0 : epi_stores + pre_loads;
+        constexpr int n_steps = nt < WS::DEPTH ? nt : WS::DEPTH;     // steps of this layer since chunk nt's DMA was issued
+        const int yg = n_steps * (epi_stores + pre_loads);
         const char* w = ws.acquire(yg);
         auto aux_next = aux;
         if constexpr (nt + 1 < NT) aux_next = pre(nt + 1);
