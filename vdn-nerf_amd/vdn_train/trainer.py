@@ -10,7 +10,7 @@ import math
 import numpy as np
 import torch
 
-from vdn_hip import lib
+from vdn_hip import images, lib
 from vdn_hip.train import TrainEngine
 from vdn_train import dp
 
@@ -29,6 +29,7 @@ class Trainer:
         self.conf.update(conf or {})
         self.world, self.rank = world_size, rank
         self.iter_step, self.depth_iter = 0, 0
+        self._img_cache = {}
         # flatten: every Parameter becomes a view of one buffer (names / state_dict unchanged), so Adam is one
         # launch and the gradient all-reduce one message
         self.params = renderer._all_parameters()
@@ -98,8 +99,8 @@ class Trainer:
             dp.allreduce_flat(grad)                # one flat message: all gradients of all networks
         lib.load().vdn_adam_step(self.param_flat.data_ptr(), grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                                  self.param_flat.numel(), self.learning_rate(), 0.9, 0.999, 1e-8, self.iter_step + 1 - self._step0(), st)
-        for net in eng.nets.values():
-            net.img.invalidate()                   # weights changed behind torch's version counters
+        # weights changed behind torch's version counters: rebuild every network's images now, in two launches
+        images.refresh_together([net.img for net in eng.nets.values()], st, self._img_cache)
         self.iter_step += 1
         return self.scalars        # device tensor [loss, color_loss, psnr, eikonal, depth_loss, mask_loss]; no host sync here
 
