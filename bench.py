@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-all-samples", action="store_true", help="skip the second timed leg (work lists off); keeps a rocprof trace of "
+                    "this command to one population of launches per kernel")
     ap.add_argument("--config", choices=["womsk_white", "womsk_white_wdepth"], default="womsk_white",
                     help="womsk_white = BASELINE.json configs[1] (the headline); womsk_white_wdepth = configs[2] (VDN head + depth-feature loss)")
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16",
@@ -160,22 +162,24 @@ def main():
     loss_final = float(out[0].item())
     # The same K steps with every sample evaluated, as the reference does: the default path skips samples that enter the loss
     # only through exact zeros ("Work lists") - identical results, reported side by side for transparency.
-    os.environ["VDN_FG_COMPACT"] = os.environ["VDN_BG_COMPACT"] = "0"
-    for i in range(min(2, args.warmup + args.steps)):
-        step(i)
-    fence()
-    t0 = time.time()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    fence()
-    dt_all = time.time() - t0
-    if world > 1:
-        import torch.distributed as dist
-        tmax = torch.tensor([dt_all], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt_all = float(tmax.item())
-    del os.environ["VDN_FG_COMPACT"], os.environ["VDN_BG_COMPACT"]
-    step(0)                                       # restore the work lists of a default step for the kernel timings below
+    dt_all = None
+    if not args.no_all_samples:
+        os.environ["VDN_FG_COMPACT"] = os.environ["VDN_BG_COMPACT"] = "0"
+        for i in range(min(2, args.warmup + args.steps)):
+            step(i)
+        fence()
+        t0 = time.time()
+        for i in range(args.steps):
+            step(args.warmup + i)
+        fence()
+        dt_all = time.time() - t0
+        if world > 1:
+            import torch.distributed as dist
+            tmax = torch.tensor([dt_all], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt_all = float(tmax.item())
+        del os.environ["VDN_FG_COMPACT"], os.environ["VDN_BG_COMPACT"]
+        step(0)                                   # restore the work lists of a default step for the kernel timings below
     # forward-only render() throughput on the same rays (inference path), reported beside the headline
     with torch.no_grad():
         for i in range(2):
@@ -236,8 +240,9 @@ def main():
                        "foreground_points_evaluated_last_step": fg_rows, "foreground_points_total": eng.P},
             "model_flops_per_s": value * flop_per_ray,
             "forward_only_rays_per_s": fwd_rays_per_s, "final_loss": loss_final,
-            "all_samples_evaluated": {"value": world * B * args.steps / dt_all, "ms_per_step": dt_all / args.steps * 1e3,
-                                      "note": "same steps with VDN_FG_COMPACT=0 VDN_BG_COMPACT=0 (no zero-weight samples skipped)"},
+            "all_samples_evaluated": None if dt_all is None else {
+                "value": world * B * args.steps / dt_all, "ms_per_step": dt_all / args.steps * 1e3,
+                "note": "same steps with VDN_FG_COMPACT=0 VDN_BG_COMPACT=0 (no zero-weight samples skipped)"},
             "roofline": {"bound": "mfma", "kernel": "sdf_fwd_kernel<%s> (fused PE + SDF MLP + gradient sweep, "
                                                    "training-mode launch of the timed step over its foreground work list)" % ("F32,1,4,false" if dtype == "f32" else "BF16,1,4,true"),
                          "achieved": flops_train / tk / 1e12, "peak": PEAK[dtype] / 1e12, "unit": "TFLOP/s",
