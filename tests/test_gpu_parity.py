@@ -479,3 +479,30 @@ def test_background_active_list_and_bitwise_equivalence(env, dev, golden, monkey
     want = [r * T + s for r in range(B) for s in range(T) if s >= N or inside[r, s] == 0.0]
     assert int(n) == len(want) and idx[:int(n)].cpu().tolist() == want
     assert 32 * B <= len(want) < B * T          # something was skipped, the outside samples never are
+
+
+@pytest.mark.parametrize("sorted_old", [True, False])
+def test_merge_sorted_kernel_vs_stable_sort(dev, sorted_old):
+    """vdn_merge_sorted = cat + sort + permuted sdf (renderer.py:197-205), with ties and - through the counting path -
+    unsorted old rows: equals a stable sort of the concatenation, for z and for the sdf that travels with it."""
+    from vdn_hip import lib
+    gen = torch.Generator().manual_seed(11)
+    B, M, K, ld = 37, 80, 16, 128
+    old = torch.round(torch.rand(B, M, generator=gen) * 50) / 50            # many exact ties
+    if sorted_old:
+        old = torch.sort(old, -1)[0]
+    new = torch.sort(torch.round(torch.rand(B, K, generator=gen) * 50) / 50, -1)[0]
+    sdf_old, sdf_new = torch.rand(B, M, generator=gen), torch.rand(B, K, generator=gen)
+    z = torch.zeros(B, ld)
+    s = torch.zeros(B, ld)
+    z[:, :M], s[:, :M] = old, sdf_old
+    z, s, new_d, sdf_new_d = z.to(dev), s.to(dev), new.to(dev).contiguous(), sdf_new.to(dev).contiguous()
+    m = lib.VdnMergeArgs()
+    m.z, m.new_z, m.z_out = z.data_ptr(), new_d.data_ptr(), z.data_ptr()
+    m.sdf, m.new_sdf, m.sdf_out = s.data_ptr(), sdf_new_d.data_ptr(), s.data_ptr()
+    m.B, m.M, m.K, m.ld, m.ld_out = B, M, K, ld, ld
+    lib.call("vdn_merge_sorted", m, torch.cuda.current_stream().cuda_stream)
+    cat_z, cat_s = torch.cat([old, new], -1), torch.cat([sdf_old, sdf_new], -1)
+    want_z, idx = torch.sort(cat_z, dim=-1, stable=True)
+    assert torch.equal(z[:, :M + K].cpu(), want_z)
+    assert torch.equal(s[:, :M + K].cpu(), torch.gather(cat_s, 1, idx))
