@@ -45,39 +45,44 @@ def time_kernel(fn, iters=10):
 
 
 def cpu_baseline(B, seed, wdepth=False, max_seconds=30.0):
-    """The oracle's training step (render forward + loss + autograd backward) on the host cores, same workload,
-    bounded sample. Adam is excluded (negligible against the 8 s step)."""
+    """The oracle's training step (render forward + loss + autograd backward) on the host cores: a bounded sample of the same
+    workload - half a batch (256 rays x (64+64+32) samples) per iteration, as many iterations as fit in ~30 s after a small
+    warm-up - reported in rays/s. Adam is excluded (negligible against a multi-second step)."""
     import oracle.neus_oracle as orc
     from vdn_train import synth
     st = synth.make_all_states(seed, wdepth=wdepth)
     cams = synth.make_cameras(seed)
-    o, d = synth.random_pixel_batch(seed, 0, 0, B, cams=cams)
-    near, far = synth.near_far_from_sphere(o, d)
-    t1, t2 = synth.jitter(seed, 0, B)
     tt = torch.tensor
     nets = orc.nets_from_numpy(st, requires_grad=True)
-    args = (nets, tt(o), tt(d), tt(near), tt(far))
-    kw = dict(background_rgb=torch.ones(1, 3), cos_anneal_ratio=0.5, t_rand=tt(t1), t_rand_out=tt(t2))
-    rgb = tt(synth.target_colors(o, d))
     params = [p for _, p in orc.all_params(nets)]
-    cores = torch.get_num_threads()
-    lkw = dict(gt_feats=tt(synth.uniform(seed, "bench/feats", (B, 96)).astype(np.float32)), depth_ramp=0.5) if wdepth else {}
+    # 16 threads: the fastest setting for this oracle on the GPU box's 2 x EPYC host (tests/probes/cpu_threads.py: 8 -> 106,
+    # 16 -> 120, 32 -> 102, 64 -> 62, 128 -> 27 rays/s); more threads only add synchronisation on these tensor sizes
+    prev_threads = torch.get_num_threads()
+    cores = min(int(os.environ.get("VDN_CPU_THREADS", "16")), os.cpu_count() or 1)
+    torch.set_num_threads(cores)
 
-    def one():
-        lo = orc.loss_from_render(orc.render(*args, **kw), rgb, **lkw)
+    def one(n, step):
+        o, d = synth.random_pixel_batch(seed, step, 0, n, cams=cams)
+        near, far = synth.near_far_from_sphere(o, d)
+        t1, t2 = synth.jitter(seed, step, n)
+        lkw = dict(gt_feats=tt(synth.uniform(seed, "bench/feats", (n, 96)).astype(np.float32)), depth_ramp=0.5) if wdepth else {}
+        out = orc.render(nets, tt(o), tt(d), tt(near), tt(far), background_rgb=torch.ones(1, 3), cos_anneal_ratio=0.5,
+                         t_rand=tt(t1), t_rand_out=tt(t2))
+        lo = orc.loss_from_render(out, tt(synth.target_colors(o, d)), **lkw)
         torch.autograd.grad(lo["loss"], params, allow_unused=True)
-    t0 = time.time()
-    one()                                       # warm-up (first call pays allocator / thread-pool start)
-    warm = time.time() - t0
-    times = []
-    while len(times) < 3 and (sum(times) + warm) < max_seconds:
+
+    one(32, 0)                                  # warm-up: thread pool, allocator
+    n = max(1, B // 2)
+    times, t_begin = [], time.time()
+    while not times or (time.time() - t_begin + float(np.mean(times)) < max_seconds and len(times) < 5):
         t = time.time()
-        one()
+        one(n, 1 + len(times))
         times.append(time.time() - t)
-    med = float(np.median(times)) if times else warm
-    return {"value": B / med, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": "%d x (render forward + loss + backward) of %d rays (64+64+32 samples), oracle fp32 on %d threads, median"
-                      % (max(len(times), 1), B, cores)}
+    med = float(np.median(times))
+    torch.set_num_threads(prev_threads)
+    return {"value": n / med, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": "%d x (render forward + loss + backward) of %d rays (64+64+32 samples each), oracle fp32 on %d threads, "
+                      "median; %.0f s of CPU work" % (len(times), n, cores, sum(times))}
 
 
 def main():
