@@ -33,7 +33,7 @@ typedef struct {
 } VdnWeightNormDesc;
 int vdn_weightnorm_materialize(const VdnWeightNormDesc* descs_dev, int n_layers, int max_rows, void* stream);
 
-/* One 32-row MFMA weight chunk to build (see csrc/mlp_engine_f32.h for the chunk format).
+/* One 32-row MFMA weight chunk to build (see csrc/mlp_engine.h for the chunk format).
  * value(i, k) = scale * src[nmap[n0+i]*row_stride + kmap[k]*col_stride]   (0 where a map entry is -1)
  * so a transposed image is just swapped strides. */
 typedef struct {
