@@ -1,5 +1,5 @@
 """Weight-image plans: how each network's effective weights are re-tiled into the MFMA chunk
-streams the kernels consume (csrc/mlp_engine_f32.h), and the device tables that drive
+streams the kernels consume (csrc/mlp_engine.h), and the device tables that drive
 vdn_weightnorm_materialize / vdn_build_images.
 
 A *stream* is the exact sequence of 32-row chunks one kernel walks through; a layer of a stream is
