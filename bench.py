@@ -85,6 +85,21 @@ def cpu_baseline(B, seed, wdepth=False, max_seconds=30.0):
                       "median; %.0f s of CPU work" % (len(times), n, cores, sum(times))}
 
 
+def spawn_ranks(n):
+    """Run this script as n ranks under torch.distributed.run (one per GPU) as a CHILD process; returns its exit code."""
+    import socket
+    import subprocess
+    if torch.cuda.device_count() < n and os.environ.get("VDN_DIST_BACKEND", "nccl") == "nccl":
+        print("bench.py: --gpus %d but only %d GPU(s) visible" % (n, torch.cuda.device_count()), file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,9 +115,18 @@ def main():
                     help="bf16 = BASELINE.json's headline config (bf16 MFMA, fp32 accumulate); fp32 = the parity path")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start N fresh ranks BEFORE anything touches the GPU (a process that
+        # has initialised HIP must never exec) and relay rank 0's line. The driver's own torch.distributed.run launch sets
+        # WORLD_SIZE and skips this.
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with `python -m torch.distributed.run --nproc-per-node %d bench.py "
+              "--gpus %d ...` (or plain `python bench.py --gpus %d`)" % (args.gpus, world, args.gpus, args.gpus, args.gpus), file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -29,18 +29,40 @@ sys.path.insert(0, ROOT)
 warnings.filterwarnings("ignore")
 
 
+REFERENCE = "/root/reference"
+
+
 def import_reference():
+    """Load the reference's three hot-path modules straight from their files, under the package name they import each
+    other by (`dpt_models`, fields.py:5). The reference's dpt_models/ has no __init__.py (a namespace package), so a
+    plain `import dpt_models.fields` resolves to THIS repo's regular package of the same name whenever it is on
+    sys.path; loading by file path cannot be shadowed, and the asserts below prove where the code came from."""
+    import importlib.util
     sys.modules.setdefault("mcubes", types.ModuleType("mcubes"))
     ic = types.ModuleType("icecream")
     ic.ic = lambda *a, **k: None
     sys.modules.setdefault("icecream", ic)
-    sys.path.insert(0, "/root/reference")
-    import importlib
-    fields = importlib.import_module("dpt_models.fields")
-    renderer = importlib.import_module("dpt_models.renderer")
-    embedder = importlib.import_module("dpt_models.embedder")
-    sys.path.remove("/root/reference")
-    return fields, renderer, embedder
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "dpt_models" or k.startswith("dpt_models.")}
+    pkg = types.ModuleType("dpt_models")
+    pkg.__path__ = [os.path.join(REFERENCE, "dpt_models")]
+    sys.modules["dpt_models"] = pkg
+    mods = {}
+    try:
+        for name in ("embedder", "fields", "renderer"):
+            path = os.path.join(REFERENCE, "dpt_models", name + ".py")
+            spec = importlib.util.spec_from_file_location("dpt_models." + name, path)
+            mod = importlib.util.module_from_spec(spec)
+            sys.modules["dpt_models." + name] = mod
+            spec.loader.exec_module(mod)
+            assert os.path.realpath(mod.__file__).startswith(REFERENCE + os.sep), mod.__file__
+            mods[name] = mod
+        assert mods["fields"].get_embedder is mods["embedder"].get_embedder
+    finally:
+        # the reference modules stay reachable through `mods` only; this repo's dpt_models (if it was imported) comes back
+        for k in [k for k in sys.modules if k == "dpt_models" or k.startswith("dpt_models.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+    return mods["fields"], mods["renderer"], mods["embedder"]
 
 
 def build_reference(fields, renderer, states, wdepth, dtype, n_importance=64, n_outside=32):
@@ -297,38 +319,77 @@ def adam_fixture(fields, renderer, seed=5, B=12, steps=3):
     return fx
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--check-only", action="store_true")
-    args = ap.parse_args()
+CASES = [
+    # name, seed, B, wdepth, variance, cos_anneal, perturb, kwargs
+    ("white_v03_c0", 1, 24, False, 0.3, 0.0, 1.0, {}),
+    ("white_v03_c05_det", 2, 24, False, 0.3, 0.5, 0.0, {}),
+    ("white_v065_c1", 4, 24, False, 0.65, 1.0, 1.0, {}),
+    ("wdepth_v03_c05", 6, 16, True, 0.3, 0.5, 1.0, {}),
+    ("wdepth_v065_c1", 7, 16, True, 0.65, 1.0, 1.0, {}),
+    ("white_n64_v03", 8, 24, False, 0.3, 0.3, 1.0, {"n_importance": 0}),
+    ("black_v03", 9, 16, False, 0.3, 1.0, 1.0, {"white": False, "with_grads": False}),
+]
+F64_COMPANIONS = ("white_v03_c0", "white_v065_c1", "wdepth_v065_c1")
+
+
+def generate(only=None):
+    """Run the reference and return {fixture name: {key: array}} (all fixtures, or the names in `only`)."""
     fields, renderer, embedder = import_reference()
+    want = (lambda n: True) if only is None else (lambda n: n in only)
     torch.manual_seed(0)
     out = {}
-    out["stages"], _ = stage_fixture(fields, renderer, embedder)
-    cases = [
-        # name, seed, B, wdepth, variance, cos_anneal, perturb, kwargs
-        ("white_v03_c0", 1, 24, False, 0.3, 0.0, 1.0, {}),
-        ("white_v03_c05_det", 2, 24, False, 0.3, 0.5, 0.0, {}),
-        ("white_v065_c1", 4, 24, False, 0.65, 1.0, 1.0, {}),
-        ("wdepth_v03_c05", 6, 16, True, 0.3, 0.5, 1.0, {}),
-        ("wdepth_v065_c1", 7, 16, True, 0.65, 1.0, 1.0, {}),
-        ("white_n64_v03", 8, 24, False, 0.3, 0.3, 1.0, {"n_importance": 0}),
-        ("black_v03", 9, 16, False, 0.3, 1.0, 1.0, {"white": False, "with_grads": False}),
-    ]
-    for (name, seed, B, wd, var, ca, pt, kw) in cases:
-        out[name], _ = run_case(fields, renderer, name, seed, B, wd, var, ca, pt, **kw)
-        if name in ("white_v03_c0", "white_v065_c1", "wdepth_v065_c1"):
+    if want("stages"):
+        out["stages"], _ = stage_fixture(fields, renderer, embedder)
+    for (name, seed, B, wd, var, ca, pt, kw) in CASES:
+        if want(name):
+            out[name], _ = run_case(fields, renderer, name, seed, B, wd, var, ca, pt, **kw)
+        if name in F64_COMPANIONS and want(name + "_f64"):
             # fp64 companion: calibrates tolerances (SURVEY.md 4 noise floor)
             fx64, _ = run_case(fields, renderer, name + "_f64", seed, B, wd, var, ca, pt, dtype=torch.float64, **kw)
             keep = {k: v for k, v in fx64.items() if k.startswith("out_") or k.startswith("grad_") or
                     k in ("loss", "psnr", "z_vals_inside")}
             out[name + "_f64"] = keep
-    out["adam3"] = adam_fixture(fields, renderer)
-    if not args.check_only:
-        for name, fx in out.items():
-            path = os.path.join(HERE, name + ".npz")
-            np.savez_compressed(path, **{k.replace("/", "__"): np.asarray(v) for k, v in fx.items()})
-            print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+    if want("adam3"):
+        out["adam3"] = adam_fixture(fields, renderer)
+    return out
+
+
+def compare_with_committed(out):
+    """Bit-for-bit comparison of freshly generated fixtures with the committed .npz files -> list of mismatches."""
+    bad = []
+    for name, fx in out.items():
+        path = os.path.join(HERE, name + ".npz")
+        if not os.path.exists(path):
+            bad.append((name, "<file missing>"))
+            continue
+        have = dict(np.load(path, allow_pickle=False))
+        new = {k.replace("/", "__"): np.asarray(v) for k, v in fx.items()}
+        if set(have) != set(new):
+            bad.append((name, "key sets differ: %s" % sorted(set(have) ^ set(new))[:5]))
+            continue
+        for k in sorted(new):
+            if have[k].shape != new[k].shape or have[k].dtype != new[k].dtype or not np.array_equal(have[k], new[k], equal_nan=True):
+                bad.append((name, k))
+    return bad
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check-only", action="store_true",
+                    help="regenerate from the reference, compare with the committed fixtures bit for bit, write nothing")
+    ap.add_argument("--only", default=None, help="comma-separated fixture names (default: all)")
+    args = ap.parse_args()
+    out = generate(None if args.only is None else set(args.only.split(",")))
+    if args.check_only:
+        bad = compare_with_committed(out)
+        for name, key in bad:
+            print("MISMATCH %s: %s" % (name, key))
+        print("checked %d fixtures against the reference: %s" % (len(out), "all bit-identical" if not bad else "%d differences" % len(bad)))
+        sys.exit(1 if bad else 0)
+    for name, fx in out.items():
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **{k.replace("/", "__"): np.asarray(v) for k, v in fx.items()})
+        print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
 
 
 if __name__ == "__main__":
