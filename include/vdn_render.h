@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VDN_ABI_VERSION 5
+#define VDN_ABI_VERSION 6
 
 int vdn_abi_version(void);
 
@@ -50,7 +50,7 @@ typedef struct {
     int32_t kt_begin;        /* this descriptor fills k-tiles [kt_begin, kt_begin+kt_count) of the chunk; */
     int32_t kt_count;        /* kmap is indexed from the start of that range. kt_count 0 = whole chunk    */
     int32_t write_bias;      /* 1: also write the chunk's bias/pad block (exactly one descriptor per chunk) */
-    int32_t _pad;
+    float bias_scale;        /* the bias block holds bias_scale * bias[row] */
 } VdnChunkDesc;
 int vdn_build_images(const VdnChunkDesc* descs_dev, int n_chunks, void* stream);
 
@@ -71,11 +71,14 @@ typedef struct {
     float* sdf;                /* out, see sdf_ld */
     void* feat;               /* [P,256] out (mode 1) */
     float* normals;            /* [P,3] out (mode 1) */
-    void* S;                  /* [8,P,256] workspace: softplus'(pre-activation) per hidden layer (mode 1). The bf16 entry point
-                               * leaves it untouched when H is given: softplus' is then re-derived from H (1 - exp(-100 h)),
-                               * here and - via s_from_h - in the backward chains, which saves writing 8 planes */
+    void* S;                  /* [8,P,256] workspace: softplus'(pre-activation) per hidden layer (mode 1, f32 entry point).
+                               * The bf16 entry point never touches it: it keeps softplus' on the chip (8-bit, LDS + registers) */
     const float* w8row;        /* [256] row 0 of the last layer's effective weight (mode 1) */
-    /* training-mode saves (mode 1), all optional (NULL = not saved): */
+    /* training-mode saves (mode 1), optional (H == NULL = nothing saved; with H, V is required and PE optional).
+     * The f32 entry point saves in the network's own units. The bf16 entry point saves all three in units of
+     * 1/(100 log2 e) (H = 100 log2(e) softplus(a), V = 100 log2(e) v, PE = 100 log2(e) encoding): the units its
+     * hidden layers compute in (csrc/k_sdf_fwd2.h). Consumers: s_from_h = 2 in the backward chains, and a factor
+     * 1/(100 log2 e) in the finalize scale of the weight-gradient entries that contract over these planes. */
     void* H;                  /* [8,P,256] H[l] = softplus output of layer l (= input of layer l+1) */
     void* V;                  /* [8,P,256] V[l] = sweep value v_l = u_{l+1} * softplus'(a_l) */
     void* PE;                 /* [P,64] positional encoding of the point (39 valid) */
@@ -85,7 +88,9 @@ typedef struct {
     const int32_t* n_active;
 } VdnSdfArgs;
 int vdn_sdf_mlp_fwd_f32(int mode, const VdnSdfArgs* args_host, void* stream);
-/* bf16-MFMA variant: blob holds bf16 chunks (fmt 1); feat / S / H / V / PE are bf16 arrays; sdf / normals stay f32. */
+/* bf16-MFMA variant (csrc/k_sdf_fwd2.h): blob holds bf16 chunks (fmt 1) of the SCALED streams (vdn_hip/images.py:
+ * sdf_streams(scaled=True): hidden biases x 100 log2 e, last layer's weights / (100 log2 e), sweep weights / 255);
+ * feat / H / V / PE are bf16 arrays in the tile-blocked layout of csrc/mlp_engine.h; sdf / normals stay f32. */
 int vdn_sdf_mlp_fwd_bf16(int mode, const VdnSdfArgs* args_host, void* stream);
 
 /* ---- RenderingNetwork (colour head / 96-channel VDN head): fields.py:148-176, mode 'idr' ------
@@ -303,7 +308,8 @@ typedef struct {
     const void* V;            /* [8,P,256] from the forward */
     void* UB;                 /* out, see above */
     void* EX;                 /* out */
-    int32_t s_from_h;          /* 1: S points at the H planes; softplus' = 1 - exp(-100 h) is evaluated in the kernel */
+    int32_t s_from_h;          /* 1: S points at the H planes; softplus' = 1 - exp(-100 h) is evaluated in the kernel.
+                               * 2: H and V are in units of 1/(100 log2 e) (bf16 forward): softplus' = 1 - 2^-H */
     /* optional work list (vdn_foreground_active; same contract as VdnNerfArgs.active_idx): per-point inputs / outputs
      * are addressed by the dense point id, training saves and deltas by the compact row */
     const int32_t* active_idx;

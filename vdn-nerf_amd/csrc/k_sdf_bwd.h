@@ -31,7 +31,9 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_rbar_ke
     const long p = wr.row, pd = wr.point;          // p: row of the saves / adjoint planes; pd: dense point id
     const long Pn = P::rows(a.P), PS = Pn * 256;
     const ST* S = reinterpret_cast<const ST*>(a.S);
-    const bool from_h = a.s_from_h != 0;
+    const int from_h = a.s_from_h;
+    // V holds v (s_from_h 0/1) or 100 log2(e) v (s_from_h 2): softplus'' = 100 s (1 - s) either way
+    const float ex_k = from_h == 2 ? 0.6931471805599453f : 100.0f;
     const ST* V = reinterpret_cast<const ST*>(a.V);
     ST* EX = reinterpret_cast<ST*>(a.EX);
 
@@ -95,13 +97,13 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_rbar_ke
     };
     // epilogue of layer l: ub_{l+1} = vb * s_l -> D (registers) and dst (HBM); ex_l -> EX[l]
     auto epi = [&](auto& D, ST* dst, int ld, int l) VDN_INL {
-        return [&D, dst, ld, l, EX, PS, p, ok, h, from_h](int nt, const f32x16& acc, const SV& sv) VDN_INL {
+        return [&D, dst, ld, l, EX, PS, p, ok, h, from_h, ex_k](int nt, const f32x16& acc, const SV& sv) VDN_INL {
             f32x16 ub, ex;
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const float s = sprime(sv.s[t], from_h);
                 ub[t] = acc[t] * s;
-                ex[t] = 100.0f * acc[t] * sv.v[t] * (1.0f - s);
+                ex[t] = ex_k * acc[t] * sv.v[t] * (1.0f - s);
             }
             D.set(nt, ub);
             P::store_tile(dst, p, ld, nt, h, ub, ok);
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_fbar_ke
     const long p = wr.row, pd = wr.point;          // p: row of the saves / adjoint planes; pd: dense point id
     const long Pn = P::rows(a.P), PS = Pn * 256;
     const ST* S = reinterpret_cast<const ST*>(a.S);
-    const bool from_h = a.s_from_h != 0;
+    const int from_h = a.s_from_h;
     const ST* EX = reinterpret_cast<const ST*>(a.EX);
     const ST* g_feat = reinterpret_cast<const ST*>(a.g_feat);
     ST* ab8 = reinterpret_cast<ST*>(a.AB);

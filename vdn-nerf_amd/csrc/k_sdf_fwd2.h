@@ -1,0 +1,580 @@
+// SDF network forward + analytic input-gradient sweep on gfx950, second-generation bf16 kernel.
+// Replaces reference dpt_models/fields.py:72-108 (SDFNetwork.forward / .sdf / .gradient) like k_sdf_fwd.h, with a
+// different execution structure. What the measurements said about the first kernel (profiles/README.md, round 2):
+// one wave's instruction ISSUE, not the matrix pipe, bounds it (per 32 points: 61 K cycles of MFMA against ~130 K cycles
+// of VALU, LDS-read and DMA issue), and its softplus' round trip through HBM was 17x its boundary I/O. Hence:
+//
+//  * softplus'(a_l) of all 8 hidden layers never leaves the chip: 8-bit fixed point (255 sigma; exact at the saturated
+//    values 0 and 1 that Softplus(beta=100) produces almost everywhere), the first tiles in LDS, the rest in registers.
+//    That needs the whole register file: 1 wave per SIMD, 4 waves = 128 points per CU.
+//  * activations are carried in units of 1/(100 log2 e):  t = 100 log2(e) a,  g = 100 log2(e) softplus(a) =
+//    max(t, 0) + log2(1 + 2^-|t|),  sigma(100 a) = 1 - 2^-g.  Hidden-layer weights are unchanged by this
+//    (W g = 100 log2(e) W h), biases are scaled by 100 log2(e), the encoded input is scaled at the source, the last
+//    layer's weights carry 1/(100 log2 e) and the sweep's transposed weights 1/255: no multiply is left in the epilogues.
+//  * the stream of chunk steps is flat: step c issues chunk c's MFMAs with the epilogue of chunk c-1 in their shadow,
+//    also across layer boundaries (a boundary only demands that the pending tile is packed before the MFMA group that
+//    reads it); the sweep's first operand v7 is formed under the last layer's MFMAs.
+//  * the chunk barrier is off the MFMA path: step c certifies chunk c+1 (counted vmcnt + s_barrier behind its first
+//    MFMAs), the opening weight fragments of chunk c+1 are read during the last MFMAs of chunk c, and the DMA pieces of
+//    chunk c+DEPTH are issued one per MFMA group. All wait counts are compile-time constants (every lane issues every
+//    store: out-of-range lanes work on a clamped row and store duplicates of it).
+//
+// Weight stream ("sdf2" / "full2", vdn_hip/images.py): chunk format of mlp_engine.h (BF16 policy), uniform 20-KiB stride,
+// same chunk order as the first kernel's streams.
+#pragma once
+#include "mlp_engine.h"
+#include "vdn_kernels.h"
+
+namespace vdn {
+namespace sdf2 {
+
+#ifndef VDN_SDF2_PRE
+#define VDN_SDF2_PRE 4
+#endif
+#ifndef VDN_SDF2_GROUP
+#define VDN_SDF2_GROUP 2
+#endif
+#ifndef VDN_SDF2_ABL
+#define VDN_SDF2_ABL 0   // timing-only ablations (development harness), bit mask: 1 no epilogue math, 2 no MFMA, 4 no weight DMA, 8 no chunk barrier
+#endif
+constexpr int kStride = 20480;          // BF16::stride(9)
+constexpr int kWaves = 4;
+constexpr int kG = kStride / 1024 / kWaves;   // global_load_lds instructions per wave per chunk
+constexpr int kPre = VDN_SDF2_PRE;      // weight fragments read ahead of their MFMA
+constexpr int kGroup = VDN_SDF2_GROUP;  // MFMAs per scheduling group (the epilogue slices of one group interleave freely)
+constexpr float kC1 = 144.26950408889634f;    // 100 log2(e)
+constexpr float kVSave = kC1 / 255.0f;        // 255 sigma u -> saved V plane (100 log2(e) v)
+constexpr int kSTiles = 63;             // softplus' tiles per point block: 8 + 8 + 8 + 7 + 8 + 8 + 8 + 8
+
+// ---- compile-time program of the chunk stream -------------------------------------------------------------------
+enum { HID = 0, LAST = 1, SWEEP = 2, SWEEP_SKIP = 3, SWEEP_PE = 4 };
+struct LayerDesc { int kind, kt, nt, l; };
+
+template <int MODE>
+struct Prog {
+    static constexpr int NL = MODE == 0 ? 9 : 17;
+    static constexpr LayerDesc layer(int i) {
+        constexpr LayerDesc full[17] = {
+            {HID, 2, 8, 0}, {HID, 8, 8, 1}, {HID, 8, 8, 2}, {HID, 8, 7, 3}, {HID, 9, 8, 4}, {HID, 8, 8, 5}, {HID, 8, 8, 6}, {HID, 8, 8, 7},
+            {LAST, 8, 9, 8},
+            {SWEEP, 8, 8, 6}, {SWEEP, 8, 8, 5}, {SWEEP, 8, 8, 4}, {SWEEP_SKIP, 8, 9, 3}, {SWEEP, 7, 8, 2}, {SWEEP, 8, 8, 1}, {SWEEP, 8, 8, 0},
+            {SWEEP_PE, 8, 2, -1}};
+        LayerDesc d = full[i];
+        if (MODE == 0 && i == 8) d.nt = 1;
+        return d;
+    }
+    static constexpr int first_chunk(int i) {
+        int c = 0;
+        for (int j = 0; j < i; ++j) c += layer(j).nt;
+        return c;
+    }
+    static constexpr int total = first_chunk(NL);
+    static constexpr int layer_of(int c) {
+        int i = 0;
+        while (i + 1 < NL && first_chunk(i + 1) <= c) ++i;
+        return i;
+    }
+    static constexpr int tile_of(int c) { return c - first_chunk(layer_of(c)); }
+    static constexpr int kt_of(int c) { return (c >= 0 && c < total) ? layer(layer_of(c)).kt : 0; }
+    static constexpr bool bias_of(int c) { return c >= 0 && c < total && layer(layer_of(c)).kind <= LAST; }
+    // first softplus' tile of hidden layer l
+    static constexpr int s_tile0(int l) { return l <= 3 ? 8 * l : 8 * l - 1; }
+};
+
+// vector-memory stores issued by the epilogue of chunk c's tile (every lane of every wave issues all of them);
+// they are issued during step c+1
+template <int MODE, bool SAVE>
+constexpr int tile_stores(int c) {
+    using PG = Prog<MODE>;
+    if (c < 0 || c >= PG::total) return 0;
+    const LayerDesc d = PG::layer(PG::layer_of(c));
+    const int t = PG::tile_of(c);
+    switch (d.kind) {
+        case HID: return SAVE ? 4 : 0;                                           // H plane tile
+        case LAST: return (MODE == 1 && t < 8) ? (SAVE ? 8 : 4) : 0;             // feature tile (+ V[7] tile)
+        case SWEEP: return SAVE ? 4 : 0;                                         // V[l]
+        case SWEEP_SKIP: return (SAVE && t < 7) ? 4 : 0;
+        default: return 0;
+    }
+}
+// s_waitcnt vmcnt(N) that retires this wave's DMA of chunk c+1 in step c (before its barrier). Younger than that DMA
+// (issued during step c+1-DEPTH) are the DMAs of chunks c+2 .. c+DEPTH-1 and the stores of steps c+2-DEPTH .. c-1
+// (the stores of step c+1-DEPTH itself interleave with its DMA pieces: not counted, which only waits longer).
+template <int MODE, bool SAVE, int DEPTH>
+constexpr int wait_count(int c) {
+    using PG = Prog<MODE>;
+    int n = 0;
+    for (int j = c + 2; j <= c + DEPTH - 1; ++j)
+        if (j < PG::total) n += kG;
+    for (int j = c + 2 - DEPTH; j <= c - 1; ++j) n += tile_stores<MODE, SAVE>(j - 1);     // step j runs the epilogue of chunk j-1
+    return n < 63 ? n : 63;
+}
+
+template <int N>
+VDN_DEV void wait_vmcnt() {
+    static_assert(N >= 0 && N <= 63, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// LDS-DMA of 16 B per lane, written as inline asm: the builtin makes hipcc's wait-count pass treat every later LDS
+// wait as out of order (it marks a pending FLAT access), and it then emits s_waitcnt lgkmcnt(0) in front of every MFMA
+// that consumes a fragment - a full LDS round trip per MFMA group instead of a counted wait. Scalar base (wave-uniform)
+// + 32-bit per-lane offset; the LDS destination (wave-uniform byte address) goes through M0, which nothing else in this
+// kernel uses. Completion is tracked by the kernel's own counted vmcnt (the compiler does not see these loads).
+VDN_DEV void glds16_saddr(const char* base_uniform, unsigned lane_off, char* lds_wave_base) {
+    const unsigned lds = (unsigned)(size_t)lds_wave_base;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" ::"v"(lane_off), "s"(lds), "s"(base_uniform) : "memory");
+}
+
+// ---- pipeline state ---------------------------------------------------------------------------------------------
+template <int NSLOT>
+struct Pipe {
+    const char* g;      // weight stream (wave-uniform)
+    char* lds;          // ring base
+    int wave, lane;
+    unsigned lane16;    // lane * 16
+    bf16x8 fr[kPre];    // first fragments of the next chunk step (already read)
+    f32x4 bias[4];      // its bias rows
+    template <int C>
+    VDN_DEV char* slot() const { return lds + (C % NSLOT) * kStride; }
+    // DMA piece I (of kG) of chunk C: 1 KiB, wave-uniform base + per-lane 32-bit offset (scalar-base addressing)
+    template <int C, int I>
+    VDN_DEV void issue_piece() {
+#if !(VDN_SDF2_ABL & 4)
+        const int piece = wave + I * kWaves;
+        glds16_saddr(g + ((long)C * kStride + piece * 1024), lane16, slot<C>() + piece * 1024);
+#endif
+    }
+    template <int C>
+    VDN_DEV void issue() {
+        static_for<kG>([&](auto i_c) VDN_INL { issue_piece<C, decltype(i_c)::value>(); });
+    }
+    // reads that open chunk step C (its first fragments, and its bias rows)
+    template <int C, int KT, bool BIAS>
+    VDN_DEV void prefetch() {
+        const char* w = slot<C>();
+        const bf16x8* wa = reinterpret_cast<const bf16x8*>(w) + lane;
+#pragma unroll
+        for (int s = 0; s < (kPre < 2 * KT ? kPre : 2 * KT); ++s) fr[s] = wa[s * 64];
+        if constexpr (BIAS) {
+            const f32x4* b = reinterpret_cast<const f32x4*>(w + KT * 2048);
+            const int h = lane >> 5;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bias[q] = b[2 * q + h];
+        }
+    }
+};
+
+// One chunk step: acc = (bias) + W[chunk C] . X over KT input tiles. group(gi, NG) = the VALU work assigned to MFMA
+// group gi of NG (kGroup MFMAs per group). Group 0 certifies chunk C+1; the DMA pieces of chunk C+DEPTH follow one per
+// group; the tail reads the opening fragments of chunk C+1.
+template <int MODE, bool SAVE, int NSLOT, int DEPTH, int C, class ActT, class Group>
+VDN_DEV f32x16 chunk_step(Pipe<NSLOT>& pp, const ActT& X, Group&& group) {
+    using PG = Prog<MODE>;
+    constexpr int KT = PG::kt_of(C);
+    constexpr bool BIAS = PG::bias_of(C);
+    constexpr int NS = KT * 2, NG = (NS + kGroup - 1) / kGroup;
+    constexpr int KTN = PG::kt_of(C + 1);
+    constexpr bool HAS_NEXT = C + 1 < PG::total;
+    constexpr bool HAS_DMA = C + DEPTH < PG::total;
+    const bf16x8* wa = reinterpret_cast<const bf16x8*>(pp.template slot<C>()) + pp.lane;
+    const bf16x8* wn = reinterpret_cast<const bf16x8*>(pp.template slot<C + 1>()) + pp.lane;
+    bf16x8 fr[NS];
+    f32x16 acc;
+    constexpr int PF = kPre < NS ? kPre : NS;                       // fragments of this chunk read by the previous step
+    constexpr int PFN = kPre < 2 * KTN ? kPre : 2 * KTN;            // fragments of the next chunk this step reads
+    static_for<PF>([&](auto s_c) VDN_INL { fr[decltype(s_c)::value] = pp.fr[decltype(s_c)::value]; });
+    if constexpr (BIAS) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc[4 * q + 0] = pp.bias[q][0]; acc[4 * q + 1] = pp.bias[q][1]; acc[4 * q + 2] = pp.bias[q][2]; acc[4 * q + 3] = pp.bias[q][3];
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[t] = 0.0f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<NG>([&](auto g_c) VDN_INL {
+        constexpr int gi = decltype(g_c)::value;
+        constexpr int s0 = gi * kGroup, s1 = (gi + 1) * kGroup < NS ? (gi + 1) * kGroup : NS;
+        static_for<s1 - s0>([&](auto j_c) VDN_INL {
+            constexpr int s = s0 + decltype(j_c)::value;
+#if VDN_SDF2_ABL & 2
+            { const bf16x8 keep = fr[s]; asm volatile("" ::"v"(keep)); }
+#else
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[s], X.r[s], acc, 0, 0, 0);
+#endif
+        });
+        if constexpr (gi == 0 && HAS_NEXT) {
+            __builtin_amdgcn_sched_barrier(0);      // the step's first MFMAs are in the pipe while the wave waits
+            wait_vmcnt<wait_count<MODE, SAVE, DEPTH>(C)>();
+#if !(VDN_SDF2_ABL & 8)
+            __builtin_amdgcn_s_barrier();
+#endif
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // DMA of chunk C+DEPTH (into the slot chunk C-1 was read from: every wave is past the barrier), spread over the groups
+        if constexpr (HAS_DMA) {
+#ifdef VDN_SDF2_STAGGER
+            // even waves issue in even groups, odd waves in odd groups: at most two of the four waves' pieces meet in the
+            // CU's vector-memory path (the waves run in lockstep, so an unstaggered piece always meets three others)
+            if constexpr (NG >= 2 * kG - 2) {
+                constexpr int i = gi / 2;
+                if constexpr (i < kG - 1) {
+                    if ((pp.wave & 1) == (gi & 1)) pp.template issue_piece<C + DEPTH, i>();
+                }
+                if constexpr (gi == NG - 1) pp.template issue_piece<C + DEPTH, kG - 1>();
+            } else
+#endif
+            static_for<kG>([&](auto i_c) VDN_INL {
+                constexpr int i = decltype(i_c)::value;
+                if constexpr ((NG >= kG ? i * NG / kG : (i < NG ? i : NG - 1)) == gi) pp.template issue_piece<C + DEPTH, i>();
+            });
+        }
+        // fragment reads kPre MFMAs ahead: the rest of this chunk, then the opening fragments of chunk C+1
+        static_for<s1 - s0>([&](auto j_c) VDN_INL {
+            constexpr int s = s0 + decltype(j_c)::value;
+            if constexpr (s + PF < NS) fr[s + PF] = wa[(s + PF) * 64];
+            else if constexpr (HAS_NEXT && s + PF - NS < PFN) pp.fr[s + PF - NS] = wn[(s + PF - NS) * 64];
+            // a chunk shorter than the next one's opening: its last MFMA slot reads the remainder
+            if constexpr (HAS_NEXT && s == NS - 1)
+                static_for<(PFN > PF ? PFN - PF : 0)>([&](auto e_c) VDN_INL { pp.fr[PF + decltype(e_c)::value] = wn[(PF + decltype(e_c)::value) * 64]; });
+        });
+        if constexpr (gi == NG - 1 && HAS_NEXT && KTN > 0 && PG::bias_of(C + 1)) {
+            const f32x4* b = reinterpret_cast<const f32x4*>(pp.template slot<C + 1>() + KTN * 2048);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pp.bias[q] = b[2 * q + (pp.lane >> 5)];
+        }
+        group(g_c, std::integral_constant<int, NG>{});
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    return acc;
+}
+
+// softplus in scaled units:  t -> g = max(t,0) + log2(1 + 2^-|t|)
+VDN_DEV float softplus_t(float t) {
+#if VDN_SDF2_ABL & 1
+    return t;
+#endif
+    const float e = __builtin_amdgcn_exp2f(-fabsf(t));
+    return relu0(t) + __builtin_amdgcn_logf(1.0f + e);
+}
+// 2^-g = 1 - sigma(100 a)
+VDN_DEV float one_minus_sigma(float g) {
+#if VDN_SDF2_ABL & 1
+    return g;
+#endif
+    return __builtin_amdgcn_exp2f(-g);
+}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// four values E = 1 - sigma in [0,1] -> one dword of 255 sigma (8 bits each): unorm16 conversion (round(65535 E), two
+// values per instruction), the high bytes gathered by one v_perm, complemented (255 - q). Exact at E = 0 and E = 1.
+VDN_DEV unsigned sigma255_pack(float e0, float e1, float e2, float e3) {
+    const unsigned d0 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pknorm_u16(e0, e1));
+    const unsigned d1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pknorm_u16(e2, e3));
+    return ~__builtin_amdgcn_perm(d1, d0, 0x07050301u);
+}
+VDN_DEV float ubyte_f32(unsigned w, int b) { return (float)((w >> (8 * b)) & 0xffu); }
+
+// S store: tiles [0, NLDS) in LDS (16 B per lane per tile, wave-private), the rest in registers
+template <int NLDS>
+struct SStore {
+    static constexpr int NREG = kSTiles > NLDS ? (kSTiles - NLDS) : 0;
+    u32x4 reg[NREG > 0 ? NREG : 1];
+    char* lds;      // this lane's 16 bytes of tile 0
+    template <int T>
+    VDN_DEV void put(const u32x4& v) {
+        if constexpr (T < NLDS) *reinterpret_cast<u32x4*>(lds + T * 1024) = v;
+        else reg[T - NLDS] = v;
+    }
+    template <int T>
+    VDN_DEV u32x4 get() const {
+        if constexpr (T < NLDS) return *reinterpret_cast<const u32x4*>(lds + T * 1024);
+        else return reg[T - NLDS];
+    }
+};
+
+// element pairs [pair_begin(gi), pair_begin(gi+1)) of a 16-register tile are worked on in MFMA group gi of the GA groups
+// available to the tile's epilogue
+constexpr int pair_begin(int gi, int GA) { return gi >= GA ? 8 : gi * 8 / GA; }
+
+// MODE 0: sdf only (sampler passes, 2 waves / SIMD). MODE 1: sdf + feature + normals, softplus' on chip (1 wave / SIMD);
+// SAVE adds the training saves (H in scaled units g = 100 log2(e) h, V, PE).
+// (VID only gives the development harness's co-linked tuning variants distinct symbols)
+template <int MODE, bool SAVE, int NSLOT, int DEPTH, int VID = 0>
+__global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kernel(SdfArgs a) {
+    using PG = Prog<MODE>;
+    using P = BF16;
+    using ST = unsigned short;
+    static_assert(NSLOT >= DEPTH + 1, "ring: the chunk being read, the one being opened and DEPTH-1 in flight");
+    constexpr int kRing = NSLOT * kStride;
+    constexpr int kW8 = MODE == 1 ? 1024 : 0;          // W8 row 0 (f32) behind the ring
+    constexpr int kLdsTotal = MODE == 1 ? 160 * 1024 : kRing;
+    constexpr int NLDS = MODE == 1 ? ((kLdsTotal - kRing - kW8) / (kWaves * 1024) < kSTiles ? (kLdsTotal - kRing - kW8) / (kWaves * 1024) : kSTiles) : 0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Pipe<NSLOT> pp;
+    pp.g = a.blob;
+    pp.lds = smem;
+    pp.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    pp.lane = threadIdx.x & 63;
+    pp.lane16 = pp.lane * 16;
+    const int lane = pp.lane, c = lane & 31, h = lane >> 5;
+    const WorkRow wr = work_row(a.active_idx, a.n_active, a.P, kWaves, pp.wave, c);
+    if (wr.none) return;
+#ifdef VDN_SDF2_STAMP      // development harness: shader-clock and 100-MHz stamps of the workgroup, into the (otherwise unused) PE buffer
+    const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long stamp_p1 = 0, stamp_p2 = 0;     // end of the hidden layers / of the last layer
+#endif
+    const bool ok = wr.ok;
+    const long p = wr.row, pd = wr.point;
+
+    float xin[3];
+    long sdf_idx = pd;
+    if (a.pts != nullptr) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) xin[d] = a.pts[pd * 3 + d] * a.scale;
+    } else {
+        const long r = pd / a.n_per_ray;
+        const long sidx = pd - r * a.n_per_ray;
+        const float z = a.z[r * a.z_ld + sidx];
+        sdf_idx = r * a.sdf_ld + sidx;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) xin[d] = (a.rays_o[r * 3 + d] + a.rays_d[r * 3 + d] * z) * a.scale;
+    }
+    ST* Hs = reinterpret_cast<ST*>(a.H);
+    ST* Vs = reinterpret_cast<ST*>(a.V);
+    ST* feat = reinterpret_cast<ST*>(a.feat);
+    const long PS = P::plane(a.P, 256);
+    const long prow = (p >> 5) * (32L * 256) + h * 128 + (p & 31) * 4;       // PT32 offset of this lane's pieces (mlp_engine.h)
+    const float inv_scale = 1.0f / a.scale;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ordinary loads above: nothing but DMA and stores from here on
+
+    typename P::template Act<9> X, Y;
+    SStore<NLDS> SS;
+    SS.lds = smem + kRing + kW8 + pp.wave * (NLDS * 1024) + lane * 16;
+    const float* w8lds = reinterpret_cast<const float*>(smem + kRing);
+
+    // positional encoding in scaled units: X tiles 0,1 (layer 0) and a copy for the skip input of layer 4 (tiles 7,8):
+    // tile 8 of X is not touched by anything else, tile 7's copy waits in registers
+    bf16x8 pe7[2];
+    {
+        float pe[39];
+        posenc<3, 6, false>(xin, pe);
+#pragma unroll
+        for (int i = 0; i < 39; ++i) pe[i] *= kC1;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) X.set(kt, vals_tile<39>(pe, h, kt));
+        if constexpr (SAVE) {       // saved in the same scaled units as H and V (include/vdn_render.h: VdnSdfArgs)
+            if (a.PE != nullptr) {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) P::store_tile(reinterpret_cast<ST*>(a.PE), p, 64, kt, h, vals_tile<39>(pe, h, kt), true);
+            }
+        }
+        pe7[0] = X.r[0]; pe7[1] = X.r[1];
+        X.r[16] = X.r[2]; X.r[17] = X.r[3];
+    }
+    // ring start (behind the PE stores, so that nothing but counted operations is younger than a DMA): W8 row 0 into its
+    // fixed place (wave 0), chunks 0 .. DEPTH-1 in flight, chunk 0 certified, its opening fragments read
+    if constexpr (MODE == 1) {
+        if (pp.wave == 0) glds16_saddr(reinterpret_cast<const char*>(a.w8row), pp.lane16, smem + kRing);
+    }
+    static_for<DEPTH>([&](auto i_c) VDN_INL { pp.template issue<decltype(i_c)::value>(); });
+    wait_vmcnt<(DEPTH - 1) * kG>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    pp.template prefetch<0, 2, true>();
+
+    f32x16 acc_prev;            // accumulator of the previous chunk's tile (its epilogue runs under this chunk's MFMAs)
+    u32x4 sq_prev;              // 255 sigma of the previous chunk's tile: read by the sweep's epilogue, built by a hidden layer's
+    u32x4 sq_v7;                // 255 sigma_7 tile while v7 is formed
+    unsigned hold0 = 0, hold1 = 0;  // a pair's values waiting for their partners (one 4-value pack / one 8-byte store)
+    f32x16 UPE[2];              // d sdf / d(PE) tiles (W4^T rows 7,8 and W0^T)
+    float n[3] = {0.0f, 0.0f, 0.0f};
+    auto pe_backward = [&]() VDN_INL {      // n += J_PE^T u  (transpose Jacobian of the encoding)
+        float u[39];
+        tiles_vals<39, 2>(UPE, h, u);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) n[d] += u[d];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const float f = (float)(1 << k);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                float sn, co;
+                sincos_pe<false>(xin[d] * f, sn, co);
+                n[d] += f * (co * u[3 + 6 * k + d] - sn * u[3 + 6 * k + 3 + d]);
+            }
+        }
+    };
+
+    // epilogue of chunk CP's tile, element pairs [PB, PE): runs in step CP+1
+    auto epilogue = [&](auto cp_c, auto pb_c, auto pe_c) VDN_INL {
+        constexpr int CP = decltype(cp_c)::value, PB = decltype(pb_c)::value, PE_ = decltype(pe_c)::value;
+        if constexpr (CP >= 0 && PE_ > PB) {
+            constexpr int LI = PG::layer_of(CP), T = PG::tile_of(CP);
+            constexpr LayerDesc L = PG::layer(LI);
+            auto& D = (LI & 1) ? X : Y;                 // layer LI reads (LI & 1 ? Y : X) and writes the other
+            if constexpr (L.kind == HID) {
+                static_for<PE_ - PB>([&](auto i_c) VDN_INL {
+                    constexpr int pr = PB + decltype(i_c)::value;       // elements 2pr, 2pr+1
+                    const float g0 = softplus_t(acc_prev[2 * pr]);
+                    const float g1 = softplus_t(acc_prev[2 * pr + 1]);
+                    unsigned pk = pack_bf16x2(g0, g1);
+                    asm volatile("" : "+v"(pk));
+                    u32x4 cur = __builtin_bit_cast(u32x4, D.r[T * 2 + (pr >> 2)]);
+                    cur[pr & 3] = pk;
+                    D.r[T * 2 + (pr >> 2)] = __builtin_bit_cast(bf16x8, cur);
+                    if constexpr (MODE == 1) {
+                        if constexpr ((pr & 1) == 0) {
+                            hold0 = __builtin_bit_cast(unsigned, one_minus_sigma(g0));
+                            hold1 = __builtin_bit_cast(unsigned, one_minus_sigma(g1));
+                            asm volatile("" : "+v"(hold0), "+v"(hold1));
+                        } else {
+                            unsigned w = sigma255_pack(__builtin_bit_cast(float, hold0), __builtin_bit_cast(float, hold1),
+                                                       one_minus_sigma(g0), one_minus_sigma(g1));
+                            asm volatile("" : "+v"(w));      // materialise here: otherwise the chain sinks to the tile's end
+                            sq_prev[pr >> 1] = w;
+                            if constexpr (SAVE) {       // H plane piece q = pr >> 1: elements 4q .. 4q+3
+                                uint2 o;
+                                o.x = cur[(pr & 3) - 1];
+                                o.y = cur[pr & 3];
+                                *reinterpret_cast<uint2*>(Hs + L.l * PS + prow + T * 1024 + 256 * (pr >> 1)) = o;
+                            }
+                            if constexpr (pr == 7) SS.template put<PG::s_tile0(L.l) + T>(sq_prev);
+                        }
+                    }
+                });
+            } else if constexpr (L.kind == LAST) {
+                if constexpr (MODE == 1 && T < 8) {
+                    // feature tile T to HBM; v7 tile T = (W8 row 0 / scale) (.) 255 sigma_7 -> Y (free while layer 8 reads X)
+                    static_for<PE_ - PB>([&](auto i_c) VDN_INL {
+                        constexpr int pr = PB + decltype(i_c)::value;
+                        if constexpr ((pr & 1) == 1) {
+                            constexpr int q = pr >> 1;
+                            uint2 o;
+                            o.x = pack_bf16x2(acc_prev[4 * q], acc_prev[4 * q + 1]);
+                            o.y = pack_bf16x2(acc_prev[4 * q + 2], acc_prev[4 * q + 3]);
+                            *reinterpret_cast<uint2*>(feat + prow + T * 1024 + 256 * q) = o;
+                            const f32x4 w = *reinterpret_cast<const f32x4*>(w8lds + 32 * T + 8 * q + 4 * h);
+                            if constexpr (q == 0) sq_v7 = SS.template get<PG::s_tile0(7) + T>();
+                            const unsigned sw = sq_v7[q];
+                            const float v0 = w[0] * inv_scale * ubyte_f32(sw, 0), v1 = w[1] * inv_scale * ubyte_f32(sw, 1);
+                            const float v2 = w[2] * inv_scale * ubyte_f32(sw, 2), v3 = w[3] * inv_scale * ubyte_f32(sw, 3);
+                            u32x4 cur = __builtin_bit_cast(u32x4, Y.r[T * 2 + (q >> 1)]);
+                            unsigned k0 = pack_bf16x2(v0, v1), k1 = pack_bf16x2(v2, v3);
+                            asm volatile("" : "+v"(k0), "+v"(k1));      // materialise here (the sweep is the first reader)
+                            cur[2 * (q & 1)] = k0;
+                            cur[2 * (q & 1) + 1] = k1;
+                            Y.r[T * 2 + (q >> 1)] = __builtin_bit_cast(bf16x8, cur);
+                            if constexpr (SAVE) {
+                                uint2 ov;
+                                ov.x = pack_bf16x2(v0 * kVSave, v1 * kVSave);
+                                ov.y = pack_bf16x2(v2 * kVSave, v3 * kVSave);
+                                *reinterpret_cast<uint2*>(Vs + 7 * PS + prow + T * 1024 + 256 * q) = ov;
+                            }
+                        }
+                    });
+                }
+            } else if constexpr (L.kind == SWEEP || (L.kind == SWEEP_SKIP && T < 7)) {
+                // v_l tile = u (.) 255 sigma_l   (the 1/255 is in the next transposed image)
+                static_for<PE_ - PB>([&](auto i_c) VDN_INL {
+                    constexpr int pr = PB + decltype(i_c)::value;
+                    const float v0 = acc_prev[2 * pr] * ubyte_f32(sq_prev[pr >> 1], 2 * (pr & 1));
+                    const float v1 = acc_prev[2 * pr + 1] * ubyte_f32(sq_prev[pr >> 1], 2 * (pr & 1) + 1);
+                    unsigned pk = pack_bf16x2(v0, v1);
+                    asm volatile("" : "+v"(pk));
+                    u32x4 cur = __builtin_bit_cast(u32x4, D.r[T * 2 + (pr >> 2)]);
+                    cur[pr & 3] = pk;
+                    D.r[T * 2 + (pr >> 2)] = __builtin_bit_cast(bf16x8, cur);
+                    if constexpr (SAVE) {
+                        // the V plane holds 100 log2(e) v, v = u (.) sigma: the units of H and PE
+                        unsigned pv = pack_bf16x2(v0 * kVSave, v1 * kVSave);
+                        if constexpr ((pr & 1) == 0) {
+                            hold0 = pv;
+                            asm volatile("" : "+v"(hold0));
+                        } else {
+                            uint2 o;
+                            o.x = hold0;
+                            o.y = pv;
+                            *reinterpret_cast<uint2*>(Vs + L.l * PS + prow + T * 1024 + 256 * (pr >> 1)) = o;
+                        }
+                    }
+                });
+            }
+        }
+    };
+
+    // ---- the flat stream of chunk steps ---------------------------------------------------------------------------
+    static_for<PG::total + 1>([&](auto c_c) VDN_INL {
+        constexpr int C = decltype(c_c)::value;
+        constexpr int CP = C - 1;
+        constexpr int CPs = CP >= 0 ? CP : 0;
+        if constexpr (C < PG::total) {
+            constexpr int LI = PG::layer_of(C), T = PG::tile_of(C);
+            constexpr LayerDesc L = PG::layer(LI);
+            constexpr int NS = 2 * L.kt, NG = (NS + kGroup - 1) / kGroup;
+#ifdef VDN_SDF2_STAMP
+            if constexpr (C == PG::first_chunk(8)) stamp_p1 = __builtin_amdgcn_s_memtime();
+            if constexpr (MODE == 1 && C == PG::first_chunk(MODE == 1 ? 9 : 8)) stamp_p2 = __builtin_amdgcn_s_memtime();
+#endif
+            // groups available to the pending epilogue: inside a layer all of them; across a layer boundary those before
+            // the MFMA group that reads the pending tile (k-steps 2 T', 2 T' + 1 of this layer's input)
+            constexpr bool boundary = CP >= 0 && PG::layer_of(CPs) != LI;
+            constexpr int KP = PG::layer(PG::layer_of(CPs)).kind;
+            constexpr bool prev_writes_input = boundary && (KP == HID || KP == SWEEP);
+            constexpr int GA = prev_writes_input ? ((2 * PG::tile_of(CPs)) / kGroup < NG ? (2 * PG::tile_of(CPs)) / kGroup : NG) : NG;
+            static_assert(GA >= 1, "a pending tile needs at least one MFMA group before its reader");
+            if constexpr (L.kind == HID && L.l == 4 && T == 0) { X.r[14] = pe7[0]; X.r[15] = pe7[1]; }
+            // sweep: fetch this tile's 255 sigma one step before its epilogue runs
+            constexpr bool sweep_tile = L.kind == SWEEP || (L.kind == SWEEP_SKIP && T < 7);
+            u32x4 sq_next;
+            if constexpr (sweep_tile) sq_next = SS.template get<PG::s_tile0(L.l) + T>();
+            const auto& Xin = (LI & 1) ? Y : X;
+            const f32x16 acc_cur = chunk_step<MODE, SAVE, NSLOT, DEPTH, C>(pp, Xin, [&](auto g_c, auto) VDN_INL {
+                constexpr int gi = decltype(g_c)::value;
+                epilogue(std::integral_constant<int, CP>{}, std::integral_constant<int, pair_begin(gi, GA)>{},
+                         std::integral_constant<int, pair_begin(gi + 1, GA)>{});
+            });
+            if constexpr (L.kind == SWEEP_SKIP && T >= 7) UPE[T - 7] = acc_cur;
+            if constexpr (L.kind == SWEEP_PE) UPE[T] = acc_cur;
+            if constexpr (L.kind == LAST && T == L.nt - 1) {
+                if (ok && h == 0) a.sdf[sdf_idx] = acc_cur[0] * inv_scale;
+            }
+            acc_prev = acc_cur;
+            if constexpr (sweep_tile) sq_prev = sq_next;
+            if constexpr ((L.kind == SWEEP_SKIP && T == 8) || (L.kind == SWEEP_PE && T == 1)) pe_backward();
+        } else {
+            // drain: the last chunk's tile (MODE 0: nothing is pending, the sdf row was stored above)
+            epilogue(std::integral_constant<int, CP>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    if constexpr (MODE == 1) {
+        if (ok && h == 0) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) a.normals[pd * 3 + d] = n[d] * a.scale;
+        }
+    }
+#ifdef VDN_SDF2_STAMP
+    if (threadIdx.x == 0 && a.PE != nullptr) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(a.PE) + 8 * blockIdx.x;
+        o[0] = stamp_c0; o[1] = __builtin_amdgcn_s_memtime(); o[2] = stamp_r0; o[3] = __builtin_amdgcn_s_memrealtime();
+        o[4] = stamp_p1; o[5] = stamp_p2;
+    }
+#endif
+}
+
+template <int MODE, bool SAVE, int NSLOT, int DEPTH, int VID = 0>
+int launch(const VdnSdfArgs* args, hipStream_t stream) {
+    constexpr size_t lds = MODE == 1 ? 160 * 1024 : NSLOT * kStride;
+    static bool once = (allow_big_lds(sdf_fwd2_kernel<MODE, SAVE, NSLOT, DEPTH, VID>, lds), true);
+    (void)once;
+    const int grid = (args->P + kWaves * 32 - 1) / (kWaves * 32);
+    hipLaunchKernelGGL((sdf_fwd2_kernel<MODE, SAVE, NSLOT, DEPTH, VID>), dim3(grid), dim3(kWaves * 64), lds, stream, *args);
+    return (int)hipGetLastError();
+}
+
+}  // namespace sdf2
+}  // namespace vdn

@@ -102,9 +102,12 @@ struct WStream {
     }
 };
 
-// softplus' from a loaded plane value: the value itself, or 1 - exp(-100 h) when the plane holds h = softplus(a)
-VDN_DEV float sprime(float raw, bool from_h) {
-    return from_h ? 1.0f - __builtin_amdgcn_exp2f(-144.26950408889634f * raw) : raw;
+// softplus' from a loaded plane value. from_h 0: the plane holds softplus' itself; 1: the plane holds h = softplus(a):
+// sigma(100 a) = 1 - exp(-100 h); 2: the plane holds g = 100 log2(e) h (the units the second-generation SDF kernel
+// saves in, k_sdf_fwd2.h): sigma = 1 - 2^-g.
+VDN_DEV float sprime(float raw, int from_h) {
+    if (from_h == 0) return raw;
+    return 1.0f - __builtin_amdgcn_exp2f(from_h == 2 ? -raw : -144.26950408889634f * raw);
 }
 
 // Row bookkeeping of the MLP kernels: lane c of wave w of workgroup b works on row b*waves*32 + w*32 + c of the work

@@ -63,7 +63,7 @@ __global__ void build_images_kernel(const ChunkDesc* descs) {
             float bv = 0.0f;
             if (i < 32 && d.bias != nullptr) {
                 const int r = d.nmap[d.n0 + i];
-                if (r >= 0) bv = d.bias[r];
+                if (r >= 0) bv = d.bias_scale * d.bias[r];
             }
             b[i] = bv;
         }
@@ -89,7 +89,7 @@ __global__ void build_images_kernel(const ChunkDesc* descs) {
             float bv = 0.0f;
             if (i < 32 && d.bias != nullptr) {
                 const int r = d.nmap[d.n0 + i];
-                if (r >= 0) bv = d.bias[r];
+                if (r >= 0) bv = d.bias_scale * d.bias[r];
             }
             b[i] = bv;
         }

@@ -124,7 +124,8 @@ class SDFNetwork(_HipNet):
         return {"lin%d" % l: getattr(self, "lin%d" % l).triple() for l in range(self.num_layers - 1)}
 
     def _streams(self):
-        return images.sdf_streams(**self.conf)
+        # the bf16 kernel computes in scaled units (csrc/k_sdf_fwd2.h); the streams are rebuilt when the precision changes
+        return images.sdf_streams(scaled=(self.precision == "bf16"), **self.conf)
 
     # -- kernels ------------------------------------------------------------------------------
     def _run(self, mode, pts=None, rays=None, workspace=None, sdf_out=None):
@@ -155,12 +156,15 @@ class SDFNetwork(_HipNet):
         Pr = layout.rows(P, self.precision)          # bf16 planes are tile-blocked and padded to 32 points
         feat = torch.empty(Pr, 256, dtype=self._store_dtype(), device=dev)
         normals = torch.empty(P, 3, dtype=torch.float32, device=dev)
-        S = torch.empty(8, Pr, 256, dtype=self._store_dtype(), device=dev)
         a.blob = img.blobs["full"].data_ptr()
-        a.feat, a.normals, a.S = feat.data_ptr(), normals.data_ptr(), S.data_ptr()
+        a.feat, a.normals = feat.data_ptr(), normals.data_ptr()
+        S = None
+        if self.precision == "fp32":                 # the bf16 kernel keeps softplus' on the chip
+            S = torch.empty(8, Pr, 256, dtype=self._store_dtype(), device=dev)
+            a.S = S.data_ptr()
         a.w8row = img.weff_view("lin8").data_ptr()
         lib.call("vdn_sdf_mlp_fwd" + self._sfx(), 1, a, _stream())
-        if workspace is not None:
+        if workspace is not None and S is not None:
             workspace["S"] = S
         return sdf, feat, normals
 

@@ -47,11 +47,12 @@ class Layer:
     (matrix_name, use_bias, rowmap32) covering the whole contraction width, or a list of pieces
     (matrix_name, use_bias, rowmap32, kt_begin, kt_count) when its k-tiles come from several matrices."""
 
-    def __init__(self, kmap, chunks, scale=1.0, transposed=False):
+    def __init__(self, kmap, chunks, scale=1.0, transposed=False, bias_scale=1.0):
         self.kmap = np.asarray(kmap, np.int32)
         assert len(self.kmap) % 32 == 0
         self.chunks = chunks
         self.scale = float(scale)
+        self.bias_scale = float(bias_scale)
         self.transposed = transposed
 
     @property
@@ -59,11 +60,11 @@ class Layer:
         return len(self.kmap) // 32
 
 
-def dense_layer(name, kmap, nmap, bias=True, scale=1.0):
+def dense_layer(name, kmap, nmap, bias=True, scale=1.0, bias_scale=1.0):
     """Forward layer reading matrix `name` [rows, cols]: padded out row n <- source row nmap[n]."""
     nmap = np.asarray(nmap, np.int32)
     assert len(nmap) % 32 == 0
-    return Layer(kmap, [(name, bias, nmap[i:i + 32]) for i in range(0, len(nmap), 32)], scale)
+    return Layer(kmap, [(name, bias, nmap[i:i + 32]) for i in range(0, len(nmap), 32)], scale, bias_scale=bias_scale)
 
 
 def transposed_layer_multi(parts, fwd_kmap, scale=1.0):
@@ -174,6 +175,7 @@ class NetImages:
             ch[i]["n0"] = 0
             ch[i]["k_pad"] = len(L.kmap)
             ch[i]["scale"] = L.scale
+            ch[i]["bias_scale"] = L.bias_scale
             ch[i]["fmt"] = self.fmt
             ch[i]["kt_begin"], ch[i]["kt_count"], ch[i]["write_bias"] = kt0, ktc, int(first)
         self.wn_table = torch.from_numpy(wn.view(np.uint8)).to(self.device)
@@ -229,8 +231,14 @@ def refresh_together(images, stream, cache):
 # plans for the shipped shape family
 # ---------------------------------------------------------------------------------------------
 
-def sdf_streams(d_in, d_out, d_hidden, n_layers, skip_in, multires):
-    """Streams of csrc/sdf_f32.hip: 'sdf' (mode 0) and 'full' (mode 1: forward + reverse sweep)."""
+SDF_UNIT = 100.0 * math.log2(math.e)      # the bf16 SDF kernel computes in units of 1 / (100 log2 e)  (csrc/k_sdf_fwd2.h)
+
+
+def sdf_streams(d_in, d_out, d_hidden, n_layers, skip_in, multires, scaled=False):
+    """Streams of the SDF kernels: 'sdf' (mode 0), 'full' (mode 1: forward + reverse sweep), 'fbar' (adjoint chain).
+    scaled=True (bf16 path, csrc/k_sdf_fwd2.h): activations are carried as g = 100 log2(e) h, so hidden-layer weights
+    stay as they are while their biases are scaled by 100 log2 e, the last layer's weights by 1 / (100 log2 e), and the
+    sweep's transposed weights by 1/255 (it multiplies by 255 sigma). 'fbar' is never scaled."""
     if not (d_in == 3 and d_hidden == 256 and n_layers == 8 and tuple(skip_in) == (4,) and multires == 6 and d_out == 257):
         raise ValueError("SDFNetwork: the HIP kernels implement the shipped shape family only "
                          "(d_in=3, d_out=257, d_hidden=256, n_layers=8, skip_in=(4,), multires=6); got "
@@ -252,13 +260,16 @@ def sdf_streams(d_in, d_out, d_hidden, n_layers, skip_in, multires):
         else:
             km, nm, sc = ident_map(256), ident_map(256), 1.0
         fwd.append((name, km, nm, sc))
-    hidden = [dense_layer(n, km, nm, True, sc) for (n, km, nm, sc) in fwd]
-    last_sdf = dense_layer("lin8", ident_map(256), ident_map(1, 32), True)
+    bsc = SDF_UNIT if scaled else 1.0
+    wsc8 = 1.0 / SDF_UNIT if scaled else 1.0
+    swsc = 1.0 / 255.0 if scaled else 1.0
+    hidden = [dense_layer(n, km, nm, True, sc, bias_scale=bsc) for (n, km, nm, sc) in fwd]
+    last_sdf = dense_layer("lin8", ident_map(256), ident_map(1, 32), True, wsc8)
     nm8 = np.full(288, -1, np.int32)
     nm8[:256] = 1 + np.arange(256)      # feature rows
     nm8[256] = 0                        # sdf row
-    last_full = dense_layer("lin8", ident_map(256), nm8, True)
-    sweep = [transposed_layer(n, km, nm, sc) for (n, km, nm, sc) in reversed(fwd[0:8])]
+    last_full = dense_layer("lin8", ident_map(256), nm8, True, wsc8)
+    sweep = [transposed_layer(n, km, nm, sc * swsc) for (n, km, nm, sc) in reversed(fwd[0:8])]
     # adjoint of the forward pass: W8^T, W7^T .. W1^T
     fbar = [transposed_layer("lin8", ident_map(256), nm8)] + [transposed_layer(n, km, nm, sc) for (n, km, nm, sc) in reversed(fwd[1:8])]
     return {"sdf": hidden + [last_sdf], "full": hidden + [last_full] + sweep, "fbar": fbar}

@@ -90,7 +90,9 @@ class TrainEngine:
         w["sdf"], w["feat"], w["normals"] = fz(P), fs(Pp, 256), fz(P, 3)
         w["fg_active"] = (torch.zeros(P, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev),
                           torch.zeros(B, dtype=torch.int32, device=dev))
-        w["S"], w["H"], w["V"], w["PE"] = fs(8, Pp, 256), fs(8, Pp, 256), fs(8, Pp, 256), fs(Pp, 64)
+        w["H"], w["V"], w["PE"] = fs(8, Pp, 256), fs(8, Pp, 256), fs(Pp, 64)
+        if self.precision == "fp32":          # the bf16 SDF kernel keeps softplus' on the chip (csrc/k_sdf_fwd2.h)
+            w["S"] = fs(8, Pp, 256)
         w["col_out"], w["col_h"], w["col_small"] = fz(P, 3), fs(4, Pp, 256), fs(Pp, 64)
         if self.wdepth:
             w["vdn_out"], w["vdn_h"], w["vdn_small"] = fz(P, 96), fs(4, Pp, 256), fs(Pp, 64)
@@ -152,6 +154,10 @@ class TrainEngine:
         sl = lambda t, l, ld=256: (t, l * t.shape[1] * t.shape[2], 0, ld)          # layer plane of a [L, rows, ld] tensor
         whole = lambda t, c0=0: (t, 0, c0, t.shape[1])
         maps = images.sdf_layer_maps()
+        # bf16: the SDF forward saves H, V and PE in units of 1/(100 log2 e) (include/vdn_render.h: VdnSdfArgs), so both
+        # segments of every entry below come out 100 log2(e) too large: the finalize scale takes it out
+        unit = 1.0 / images.SDF_UNIT if prec == "bf16" else 1.0
+        maps = [(name, km, nm, sc * unit) for (name, km, nm, sc) in maps]
         for l, (name, km, nm, sc) in enumerate(maps):
             if l == 8:
                 ent.append(dict(net="sdf", name=name, rmap=nm, cmap=km, scale=sc, A=AB(8), B=sl(w["H"], 7), bias=True, Pn=P))
@@ -399,7 +405,9 @@ class TrainEngine:
         s.blob = img.blobs["full"].data_ptr()
         s.rays_o, s.rays_d, s.z, s.n_per_ray, s.z_ld, s.sdf_ld = rays_o.data_ptr(), rays_d.data_ptr(), w["mid_z"].data_ptr(), N, N, N
         s.P, s.scale = self.P, float(r.sdf_network.scale)
-        s.sdf, s.feat, s.normals, s.S = w["sdf"].data_ptr(), w["feat"].data_ptr(), w["normals"].data_ptr(), w["S"].data_ptr()
+        s.sdf, s.feat, s.normals = w["sdf"].data_ptr(), w["feat"].data_ptr(), w["normals"].data_ptr()
+        if "S" in w:
+            s.S = w["S"].data_ptr()
         s.w8row = img.weff_view("lin8").data_ptr()
         s.H, s.V, s.PE = w["H"].data_ptr(), w["V"].data_ptr(), w["PE"].data_ptr()
         lib.call("vdn_sdf_mlp_fwd" + self.sfx, 1, self._fg(s), _stream())
@@ -508,8 +516,9 @@ class TrainEngine:
         rb.blob = img.blobs["full"].data_ptr()
         rb.rays_o, rb.rays_d, rb.z, rb.n_per_ray, rb.z_ld = rays_o.data_ptr(), rays_d.data_ptr(), w["mid_z"].data_ptr(), self.N, self.N
         rb.P, rb.scale = self.P, float(r.sdf_network.scale)
-        # bf16: the forward did not store softplus'; the chains re-derive it from the saved activations (mlp_engine.h: kDeriveS)
-        s_from_h = int(self.precision == "bf16")
+        # bf16: the forward did not store softplus'; the chains re-derive it from the saved activations, which (like V) are
+        # in units of 1/(100 log2 e): s_from_h = 2 (include/vdn_render.h)
+        s_from_h = 2 if self.precision == "bf16" else 0
         s_planes = w["H"] if s_from_h else w["S"]
         rb.g_normals, rb.S, rb.V, rb.UB, rb.EX = w["d_normals"].data_ptr(), s_planes.data_ptr(), w["V"].data_ptr(), w["UB"].data_ptr(), w["EX"].data_ptr()
         rb.s_from_h = s_from_h
