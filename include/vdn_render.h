@@ -178,6 +178,11 @@ typedef struct {
     float* new_z;              /* [B,n_imp] */
     float inv_s;               /* 64 * 2^round (renderer.py:378) */
     int32_t B, M, ld, n_imp;
+    /* optional: run sample_pdf(bins = z, weights, n_imp, det=True) (renderer.py:44-74) on GIVEN weights instead of the
+     * ones up_sample derives from sdf (which, with rays_o / rays_d, may then be NULL) - the form the reference's own
+     * sample_pdf vectors are stated in */
+    const float* weights;      /* [B,w_ld], first M-1 valid, or NULL */
+    int32_t w_ld, _pad;
 } VdnUpsampleArgs;
 int vdn_upsample_round(const VdnUpsampleArgs* args_host, void* stream);
 
@@ -434,6 +439,11 @@ int vdn_loss_fwd_bwd(const VdnLossArgs* args_host, void* stream);
 /* torch.optim.Adam (no weight decay, no amsgrad) over flat buffers: dpt_runner.py:144,254. */
 int vdn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   float lr, float beta1, float beta2, float eps, int32_t step, void* stream);
+/* The same over the element ranges [begin0, end0) and [begin1, end1) only (the second may be empty), with their own step
+ * count: torch.optim.Adam keeps a step per parameter and skips parameters whose grad is None - the VDN head and the
+ * background network's dpt_linear until the depth-feature loss switches on (dpt_runner.py:239-243). */
+int vdn_adam_step_ranges(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t begin0, int64_t end0,
+                         int64_t begin1, int64_t end1, float lr, float beta1, float beta2, float eps, int32_t step, void* stream);
 
 /* ---- on-device ray generator: poses.py:168-212 (fixed poses / intrinsics) + dataset.py:111-118 --------------
  * p = K^-1 [x,y,1]; v = p/|p|; rays_d = R v; rays_o = t; colour / mask / feature gathered from images resident in HBM;

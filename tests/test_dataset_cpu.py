@@ -98,3 +98,29 @@ def test_image_metrics_formula():
     assert abs(l1 - np.abs((img - gt) * mask).sum() / ms) < 1e-6
     assert abs(psnr - 20 * np.log10(1 / np.sqrt((((img - gt) ** 2) * mask).sum() / (ms * 3)))) < 1e-5
     assert validate._resize(gt, 3, 2, 2).shape == (3, 2, 3)
+
+
+@pytest.mark.parametrize("mode", ["1", "P", "L", "RGBA"])
+def test_mask_files_decode_like_imread_color(tmp_path, mode):
+    """cv.imread(mask) (poses.py:125) always yields 8-bit 3-channel: 1-bit, palette, grey and RGBA mask files must all
+    come out as {0, 255} x 3 (a 1-bit mask read raw would be {0, 1} and composite the object almost entirely to white)."""
+    from PIL import Image
+    rng = np.random.default_rng(2)
+    m = (rng.random((9, 7)) > 0.5)
+    base = Image.fromarray((m * 255).astype(np.uint8), "L")
+    im = {"1": base.convert("1"), "P": base.convert("P"), "L": base, "RGBA": base.convert("RGBA")}[mode]
+    path = os.path.join(tmp_path, "mask_%s.png" % mode)
+    im.save(path)
+    a = dataset._read_png(path, unchanged=False)
+    assert a.shape == (9, 7, 3)
+    np.testing.assert_array_equal(a, np.repeat((m * 255.0)[:, :, None], 3, axis=2))
+
+
+def test_palette_image_is_expanded_like_imread_unchanged(tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    rgb = rng.integers(0, 4, (6, 5, 3), dtype=np.uint8) * 80
+    path = os.path.join(tmp_path, "pal.png")
+    Image.fromarray(rgb, "RGB").convert("P", palette=Image.ADAPTIVE, colors=64).save(path)
+    a = dataset._read_png(path)                      # cv.imread(path, -1) expands palettes to BGR
+    np.testing.assert_array_equal(a, rgb[:, :, ::-1].astype(np.float64))

@@ -5,6 +5,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -30,11 +31,18 @@ def _render(nets, b):
     return orc.render(nets, o, d, near, far, background_rgb=torch.ones(1, 3), cos_anneal_ratio=0.5, t_rand=t1, t_rand_out=t2)
 
 
-def _worker(rank, port, q):
+def _feats(rank):
+    return torch.tensor(synth.uniform(SEED, "dp/feats%d" % rank, (B_PER_RANK, 96)).astype(np.float32))
+
+
+RAMP = 0.37        # depth_iter_weight() of the step (dpt_runner.py:167-171, 242)
+
+
+def _worker(rank, port, q, wdepth):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
     torch.set_num_threads(2)
-    nets = orc.nets_from_numpy(synth.make_all_states(SEED), requires_grad=True)
+    nets = orc.nets_from_numpy(synth.make_all_states(SEED, wdepth=wdepth), requires_grad=True)
     b = _batch(rank)
     out = _render(nets, b)
     nd = torch.stack([out["eik_num"].detach(), out["eik_den"].detach()])
@@ -44,7 +52,10 @@ def _worker(rank, port, q):
     loss = (out["color_fine"] - b[6]).abs().sum() / (B_PER_RANK + 1e-5) / WORLD + 0.1 * eik / WORLD * WORLD
     # note: the eikonal term is already the GLOBAL value; each rank differentiates only its own numerator
     named = orc.all_params(nets)
-    gs = torch.autograd.grad((out["color_fine"] - b[6]).abs().sum() / (B_PER_RANK + 1e-5) / WORLD + 0.1 * eik, [p for _, p in named], allow_unused=True)
+    local = (out["color_fine"] - b[6]).abs().sum() / (B_PER_RANK + 1e-5) / WORLD + 0.1 * eik
+    if wdepth:      # the VDN depth-feature term is a per-rank mean like the colour term: scaled by 1/W (dpt_runner.py:239-242)
+        local = local + RAMP * (out["render_feats"] - _feats(rank)).abs().sum() / (B_PER_RANK + 1e-5) / WORLD
+    gs = torch.autograd.grad(local, [p for _, p in named], allow_unused=True)
     flat = torch.cat([(torch.zeros_like(p) if gr is None else gr).reshape(-1) for (_, p), gr in zip(named, gs)])
     # remove the double-counted constant part: d/dtheta of (nd[0]-local_num) is zero, so nothing to fix
     dp.allreduce_flat(flat)
@@ -53,14 +64,15 @@ def _worker(rank, port, q):
     dist.destroy_process_group()
 
 
-def test_dp_equals_single_process_on_concatenated_batch():
+@pytest.mark.parametrize("wdepth", [False, True])
+def test_dp_equals_single_process_on_concatenated_batch(wdepth):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, port, q)) for r in range(WORLD)]
+    procs = [ctx.Process(target=_worker, args=(r, port, q, wdepth)) for r in range(WORLD)]
     for p in procs:
         p.start()
     flat, eik = q.get(timeout=600)
@@ -68,16 +80,21 @@ def test_dp_equals_single_process_on_concatenated_batch():
         p.join(timeout=600)
         assert p.exitcode == 0
     # single process, concatenated batch
-    nets = orc.nets_from_numpy(synth.make_all_states(SEED), requires_grad=True)
+    nets = orc.nets_from_numpy(synth.make_all_states(SEED, wdepth=wdepth), requires_grad=True)
     bs = [_batch(r) for r in range(WORLD)]
     cat = [torch.cat([bs[r][i] for r in range(WORLD)], 0) for i in range(7)]
     out = _render(nets, cat)
     # mean of the per-rank colour means == colour mean of the union for equal shards (mask_sum = B + 1e-5 each)
     col = sum((out["color_fine"][r * B_PER_RANK:(r + 1) * B_PER_RANK] - bs[r][6]).abs().sum() / (B_PER_RANK + 1e-5) for r in range(WORLD)) / WORLD
     loss = col + 0.1 * out["gradient_error"]
+    if wdepth:
+        loss = loss + RAMP * sum((out["render_feats"][r * B_PER_RANK:(r + 1) * B_PER_RANK] - _feats(r)).abs().sum() / (B_PER_RANK + 1e-5)
+                                 for r in range(WORLD)) / WORLD
     named = orc.all_params(nets)
     gs = torch.autograd.grad(loss, [p for _, p in named], allow_unused=True)
     ref = torch.cat([(torch.zeros_like(p) if gr is None else gr).reshape(-1) for (_, p), gr in zip(named, gs)]).numpy()
     assert abs(eik - out["gradient_error"].item()) < 1e-6 * abs(eik)
-    assert flat.shape == ref.shape == (1409087,)             # the all-reduce payload of SURVEY.md 8e
+    assert flat.shape == ref.shape == ((1718879,) if wdepth else (1409087,))     # the all-reduce payloads of SURVEY.md 8e
+    if wdepth:      # the VDN head's gradient is in the payload and is not zero
+        assert np.abs(ref[1409087 + 12384:]).max() > 0
     assert np.abs(flat - ref).max() < 1e-5 * np.abs(ref).max()

@@ -23,7 +23,15 @@ def _rays(rank):
     return [o, d, near, far, synth.target_colors(o, d), t1, t2]
 
 
-def _worker(rank, port, q):
+def _gt_feats(rank):
+    from vdn_train import synth
+    return synth.uniform(SEED, "dpg/feats%d" % rank, (B, 96)).astype(np.float32)
+
+
+WDEPTH_CONF = dict(extract_depth=True, depth_start_iter=-1)       # the depth-feature loss is live (dpt_runner.py:239)
+
+
+def _worker(rank, port, q, wdepth=False):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "vdn-nerf_amd"))
@@ -33,11 +41,11 @@ def _worker(rank, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=2)
     dev = torch.device("cuda:0")
-    rend = factory.build_renderer(device=dev, states=synth.make_all_states(SEED))
-    tr = Trainer(rend, B, dev, world_size=2, rank=rank)
+    rend = factory.build_renderer(wdepth=wdepth, device=dev, states=synth.make_all_states(SEED, wdepth=wdepth))
+    tr = Trainer(rend, B, dev, conf=WDEPTH_CONF if wdepth else None, world_size=2, rank=rank)
     g = lambda x: torch.tensor(x).to(dev)
     o, d, near, far, rgb, t1, t2 = _rays(rank)
-    sc = tr.train_step(g(o), g(d), g(near), g(far), g(rgb), t_rand=g(t1), t_rand_out=g(t2))
+    sc = tr.train_step(g(o), g(d), g(near), g(far), g(rgb), gt_feats=g(_gt_feats(rank)) if wdepth else None, t_rand=g(t1), t_rand_out=g(t2))
     torch.cuda.synchronize()
     if rank == 0:
         q.put((tr.engine.grad_flat.cpu().numpy(), float(sc[3].item())))
@@ -45,7 +53,8 @@ def _worker(rank, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_gradient_equals_single_process_on_concatenated_batch():
+@pytest.mark.parametrize("wdepth", [False, True])
+def test_two_rank_gradient_equals_single_process_on_concatenated_batch(wdepth):
     import torch.multiprocessing as mp
     from vdn_train import synth, factory
     from vdn_train.trainer import Trainer
@@ -55,7 +64,7 @@ def test_two_rank_gradient_equals_single_process_on_concatenated_batch():
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, port, q, wdepth)) for r in range(2)]
     for p in procs:
         p.start()
     flat, eik = q.get(timeout=600)
@@ -63,14 +72,18 @@ def test_two_rank_gradient_equals_single_process_on_concatenated_batch():
         p.join(timeout=600)
         assert p.exitcode == 0
     dev = torch.device("cuda:0")
-    rend = factory.build_renderer(device=dev, states=synth.make_all_states(SEED))
-    tr = Trainer(rend, 2 * B, dev)
+    rend = factory.build_renderer(wdepth=wdepth, device=dev, states=synth.make_all_states(SEED, wdepth=wdepth))
+    tr = Trainer(rend, 2 * B, dev, conf=WDEPTH_CONF if wdepth else None)
     g = lambda x: torch.tensor(x).to(dev)
     parts = [_rays(0), _rays(1)]
     cat = [np.concatenate([parts[0][i], parts[1][i]], 0) for i in range(7)]
-    sc = tr.train_step(g(cat[0]), g(cat[1]), g(cat[2]), g(cat[3]), g(cat[4]), t_rand=g(cat[5]), t_rand_out=g(cat[6]))
+    feats = g(np.concatenate([_gt_feats(0), _gt_feats(1)], 0)) if wdepth else None
+    sc = tr.train_step(g(cat[0]), g(cat[1]), g(cat[2]), g(cat[3]), g(cat[4]), gt_feats=feats, t_rand=g(cat[5]), t_rand_out=g(cat[6]))
     ref = tr.engine.grad_flat.cpu().numpy()
-    assert flat.shape == ref.shape == (1409087,)
+    # the all-reduce payloads of SURVEY.md 8e: 5 636 348 B, 6 875 516 B with the VDN head
+    assert flat.shape == ref.shape == ((1718879,) if wdepth else (1409087,))
+    if wdepth:
+        assert np.abs(ref[-297408:]).max() > 0          # the VDN head's gradient is live
     assert abs(eik - float(sc[3].item())) < 1e-5 * abs(eik)                 # global eikonal term
     assert np.abs(flat - ref).max() < 2e-5 * np.abs(ref).max()
 

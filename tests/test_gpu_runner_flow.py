@@ -1,0 +1,125 @@
+"""The reference runner's own flow over the drop-in boundary (dpt_runner.py:117-144, 197-257, 744): networks built from
+the conf's kwargs under torch.set_default_tensor_type('torch.cuda.FloatTensor'), .to(device), torch.optim.Adam over
+.parameters(), then render -> the runner's torch loss -> zero_grad -> backward -> optimizer.step (in-place parameter
+updates, which the weight images must notice). Checked against the REFERENCE's 3-step Adam trajectory (adam3.npz)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+# confs/womsk_white.conf:41-90, as pyhocon hands them to the constructors (dpt_runner.py:117-142)
+CONF = {
+    "nerf": dict(D=8, d_in=4, d_in_view=3, W=256, multires=10, multires_view=4, output_ch=4, skips=[4], rgb_dims=3, use_viewdirs=True),
+    "sdf_network": dict(d_out=257, d_in=3, d_hidden=256, n_layers=8, skip_in=[4], multires=6, bias=0.5, scale=1.0,
+                        geometric_init=True, weight_norm=True),
+    "variance_network": dict(init_val=0.3),
+    "rendering_network": dict(d_feature=256, mode="idr", d_in=9, d_out=3, d_hidden=256, n_layers=4, weight_norm=True,
+                              multires_view=4, squeeze_out=True),
+    "neus_renderer": dict(n_samples=64, n_importance=64, n_outside=32, up_sample_steps=4, perturb=1.0),
+}
+
+
+def test_runner_flow_three_adam_steps_match_reference(golden):
+    from vdn_train import synth
+    fx = golden("adam3")
+    B, seed = int(fx["B"]), int(fx["seed"])
+    torch.set_default_tensor_type("torch.cuda.FloatTensor")          # dpt_runner.py:744
+    try:
+        from dpt_models.fields import RenderingNetwork, SDFNetwork, SingleVarianceNetwork, NeRF      # dpt_runner.py:18-19
+        from dpt_models.renderer import NeuSRenderer
+        device = torch.device("cuda")
+        nerf_outside = NeRF(**CONF["nerf"]).to(device)
+        sdf_network = SDFNetwork(**CONF["sdf_network"]).to(device)
+        deviation_network = SingleVarianceNetwork(**CONF["variance_network"]).to(device)
+        color_network = RenderingNetwork(**CONF["rendering_network"]).to(device)
+        params_to_train = []
+        for m in (nerf_outside, sdf_network, deviation_network, color_network):
+            params_to_train += list(m.parameters())
+        renderer = NeuSRenderer(nerf_outside, sdf_network, deviation_network, color_network, None, **CONF["neus_renderer"])
+        optimizer = torch.optim.Adam(params_to_train, lr=5e-4)
+        # the fixture's weights (a checkpoint, in the reference's key schema: dpt_runner.py:350-359)
+        st = synth.make_all_states(seed, wdepth=False, variance=0.3)
+        tt = lambda d: {k: torch.tensor(v) for k, v in d.items()}
+        nerf_outside.load_state_dict(tt(st["nerf"]), strict=False)
+        sdf_network.load_state_dict(tt(st["sdf_network_fine"]))
+        deviation_network.load_state_dict(tt(st["variance_network_fine"]))
+        color_network.load_state_dict(tt(st["color_network_fine"]))
+
+        data = torch.tensor(np.concatenate([fx["rays_o"], fx["rays_d"], np.ones((B, 1), np.float32), fx["true_rgb"]], axis=1))
+        near, far = torch.tensor(fx["near"]), torch.tensor(fx["far"])
+        losses = []
+        for it in range(int(fx["steps"])):
+            for gq in optimizer.param_groups:
+                gq["lr"] = 5e-4 * (it + 100) / 5000.0                       # dpt_runner.py:311-312 at iter_step = it + 100
+            rays_o, rays_d, mask, true_rgb = data[:, :3], data[:, 3:6], data[:, 6:7], data[:, 7:10]    # dpt_runner.py:201 (views)
+            background_rgb = torch.ones([1, 3])
+            mask = torch.ones_like(mask)
+            mask_sum = mask.sum() + 1e-5
+            t1, t2 = synth.jitter(seed, it, B)
+            render_out = renderer.render(rays_o, rays_d, near, far, background_rgb=background_rgb,
+                                         cos_anneal_ratio=min(1.0, (it + 100) / 50000.0), depth_before_color=False,
+                                         t_rand=torch.tensor(t1), t_rand_out=torch.tensor(t2))      # the two torch.rand draws, injected
+            color_fine, gradient_error, weight_sum = render_out["color_fine"], render_out["gradient_error"], render_out["weight_sum"]
+            color_error = (color_fine - true_rgb) * mask
+            color_fine_loss = F.l1_loss(color_error, torch.zeros_like(color_error), reduction="sum") / mask_sum
+            mask_loss = F.binary_cross_entropy(weight_sum.clip(1e-3, 1.0 - 1e-3), mask)
+            loss = color_fine_loss + gradient_error * 0.1 + mask_loss * 0.0
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
+            losses.append(loss.item())
+            del render_out
+        for it, (got, want) in enumerate(zip(losses, fx["losses"])):
+            assert abs(got - want) < 5e-5 * abs(want), (it, got, want)
+        named = [("nerf." + n, p) for n, p in nerf_outside.named_parameters()] + [("sdf." + n, p) for n, p in sdf_network.named_parameters()] + \
+                [("variance", deviation_network.variance)] + [("color." + n, p) for n, p in color_network.named_parameters()]
+        for n, p in named:
+            got = p.detach().cpu().reshape(-1)[torch.as_tensor(fx["p_idx/" + n]).cpu()].numpy()
+            assert np.abs(got - fx["p_val/" + n]).max() < 2e-5, n
+    finally:
+        torch.set_default_tensor_type(torch.FloatTensor)
+
+
+def test_adam_step_groups_match_torch_adam_across_depth_start():
+    """torch.optim.Adam keeps a step per parameter and skips parameters without a gradient: the VDN head and the background
+    network's dpt_linear have none until the depth-feature loss switches on (dpt_runner.py:239-243). The Trainer's fused Adam
+    must give them their own step count (bias correction) from that moment: compared with torch.optim.Adam fed the
+    Trainer's own gradients, 3 steps before and 3 after the switch."""
+    from vdn_train import synth, factory
+    from vdn_train.trainer import Trainer
+    dev = torch.device("cuda:0")
+    B, seed = 64, 11
+    st = synth.make_all_states(seed, wdepth=True)
+    rend = factory.build_renderer(wdepth=True, device=dev, states=st)
+    tr = Trainer(rend, B, dev, conf=dict(extract_depth=True, depth_start_iter=2, warm_up_end=10))
+    shadow = [torch.nn.Parameter(p.detach().clone()) for p in tr.params]
+    opt = torch.optim.Adam(shadow, lr=1.0)
+    cams = synth.make_cameras(seed)
+    g = lambda x: torch.tensor(x).to(dev)
+    feats = g(synth.uniform(seed, "adam/feats", (B, 96)).astype(np.float32))
+    for it in range(6):
+        o, d = synth.random_pixel_batch(seed, it, 0, B, cams=cams)
+        near, far = synth.near_far_from_sphere(o, d)
+        t1, t2 = synth.jitter(seed, it, B)
+        lr = tr.learning_rate()
+        depth_on = tr.iter_step > 2
+        tr.train_step(g(o), g(d), g(near), g(far), g(synth.target_colors(o, d)), gt_feats=feats, t_rand=g(t1), t_rand_out=g(t2))
+        grads = tr.engine.param_grads(clone=True)
+        for gq in opt.param_groups:
+            gq["lr"] = lr
+        for i, (sp, gr) in enumerate(zip(shadow, grads)):
+            sp.grad = None if (i in tr._depth_idx and not depth_on and tr._depth_adam_steps == 0) else gr.view_as(sp).clone()
+        opt.step()
+        for i, (sp, p) in enumerate(zip(shadow, tr.params)):
+            err = (sp.detach() - p.detach()).abs().max().item()
+            assert err < 2e-6, (it, i, err)
+    assert tr._depth_adam_steps == 3 and len(tr._depth_idx) > 0
+    ck = tr.state_dict()
+    steps = {int(v["step"]) for v in ck["optimizer"]["state"].values()}
+    assert steps == {6, 3}
+    tr2 = Trainer(factory.build_renderer(wdepth=True, device=dev, states=st), B, dev, conf=dict(extract_depth=True, depth_start_iter=2, warm_up_end=10))
+    tr2.load_checkpoint(ck)
+    assert tr2._depth_adam_steps == 3 and tr2.iter_step - tr2._step0() == 6
+    assert torch.equal(tr2.exp_avg, tr.exp_avg) and torch.equal(tr2.param_flat, tr.param_flat)

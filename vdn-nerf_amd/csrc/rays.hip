@@ -98,16 +98,19 @@ __global__ __launch_bounds__(kRayWaves * 64) void upsample_kernel(UpsampleArgs a
     float* z = s_z[wave];
     float* sd = s_sdf[wave];
     float* cdf = s_cdf[wave];
+    const bool given_w = a.weights != nullptr;
     for (int i = lane; i < M; i += 64) {
         z[i] = a.z[(long)r * a.ld + i];
-        sd[i] = a.sdf[(long)r * a.ld + i];
+        sd[i] = given_w ? 0.0f : a.sdf[(long)r * a.ld + i];
     }
     __builtin_amdgcn_wave_barrier();
-    float o[3], d[3];
+    float o[3] = {0.0f, 0.0f, 0.0f}, d[3] = {0.0f, 0.0f, 0.0f};
+    if (!given_w) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        o[k] = a.rays_o[r * 3 + k];
-        d[k] = a.rays_d[r * 3 + k];
+        for (int k = 0; k < 3; ++k) {
+            o[k] = a.rays_o[r * 3 + k];
+            d[k] = a.rays_d[r * 3 + k];
+        }
     }
     auto radius = [&](float zz) {
         const float x = o[0] + d[0] * zz, y = o[1] + d[1] * zz, w = o[2] + d[2] * zz;
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(kRayWaves * 64) void upsample_kernel(UpsampleArgs a
 #pragma unroll
     for (int e = 0; e < kEPL; ++e) {
         const int i = kEPL * lane + e;
-        w[e] = (i < M - 1) ? (alpha[e] * T[e] + 1e-5f) : 0.0f;
+        w[e] = (i < M - 1) ? ((given_w ? a.weights[(long)r * a.w_ld + i] : alpha[e] * T[e]) + 1e-5f) : 0.0f;
         wsum += (double)w[e];
     }
     const float tot = (float)wave_sum(wsum);
@@ -491,7 +494,8 @@ extern "C" int vdn_coarse_z(const VdnCoarseArgs* a, void* stream) {
 }
 
 extern "C" int vdn_upsample_round(const VdnUpsampleArgs* a, void* stream) {
-    if (!a || a->B <= 0 || !a->z || !a->sdf || !a->new_z || !a->u || !a->rays_o || !a->rays_d) return -1;
+    if (!a || a->B <= 0 || !a->z || !a->new_z || !a->u) return -1;
+    if (a->weights == nullptr ? (!a->sdf || !a->rays_o || !a->rays_d) : a->w_ld < a->M - 1) return -1;
     if (a->M < 2 || a->M > kMaxT || a->n_imp < 1 || a->n_imp > 64 || a->ld < a->M) return -2;
     hipLaunchKernelGGL(upsample_kernel, dim3((a->B + kRayWaves - 1) / kRayWaves), dim3(kRayWaves * 64), 0, (hipStream_t)stream, *a);
     return (int)hipGetLastError();

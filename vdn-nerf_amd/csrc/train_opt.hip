@@ -71,10 +71,13 @@ __global__ __launch_bounds__(512) void loss_kernel(LossArgs a) {
     }
 }
 
+// elements [b0, e0) and [b1, e1) of the flat buffers (two ranges: parameters that share a step count need not be contiguous)
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            long n, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+                            long b0, long e0, long b1r, long e1, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
     const float step_size = lr / bc1;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long n0 = e0 - b0, n = n0 + (e1 - b1r);
+    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (long)gridDim.x * blockDim.x) {
+        const long i = j < n0 ? b0 + j : b1r + (j - n0);
         const float gi = g[i];
         const float mi = m[i] + (gi - m[i]) * (1.0f - b1);           // lerp form, as torch's _single_tensor_adam
         const float vi = v[i] * b2 + gi * gi * (1.0f - b2);
@@ -95,13 +98,20 @@ extern "C" int vdn_loss_fwd_bwd(const VdnLossArgs* a, void* stream) {
     return (int)hipGetLastError();
 }
 
-extern "C" int vdn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                             float lr, float beta1, float beta2, float eps, int32_t step, void* stream) {
-    if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step < 1) return -1;
+extern "C" int vdn_adam_step_ranges(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t begin0, int64_t end0,
+                                    int64_t begin1, int64_t end1, float lr, float beta1, float beta2, float eps, int32_t step, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || begin0 < 0 || end0 < begin0 || begin1 < 0 || end1 < begin1 || step < 1) return -1;
+    const int64_t n = (end0 - begin0) + (end1 - begin1);
+    if (n <= 0) return -1;
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     hipLaunchKernelGGL(vdn::adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq,
-                       (long)n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2));
+                       (long)begin0, (long)end0, (long)begin1, (long)end1, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2));
     return (int)hipGetLastError();
+}
+
+extern "C" int vdn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                             float lr, float beta1, float beta2, float eps, int32_t step, void* stream) {
+    return vdn_adam_step_ranges(param, grad, exp_avg, exp_avg_sq, 0, n, 0, 0, lr, beta1, beta2, eps, step, stream);
 }

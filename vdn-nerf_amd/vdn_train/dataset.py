@@ -38,15 +38,24 @@ def load_K_Rt_from_P(P):
     return intrinsics, pose
 
 
-def _read_png(path):
+def _read_png(path, unchanged=True):
+    """The array cv.imread yields (BGR / BGRA order, which the reference trains in).
+    unchanged=True  = cv.imread(path, -1) (poses.py:114, images): the file's own channels, palettes expanded, 16-bit scaled here;
+    unchanged=False = cv.imread(path)     (poses.py:125, masks):  always 8-bit 3-channel, whatever the file holds."""
     from PIL import Image
-    a = np.asarray(Image.open(path))
+    im = Image.open(path)
+    if not unchanged:
+        im = im.convert("RGB")                      # 1-bit, palette, grey, RGBA masks -> 3 x 8 bit like IMREAD_COLOR
+    elif im.mode in ("P", "1"):
+        im = im.convert("RGBA" if "transparency" in im.info else "RGB")
+    elif im.mode == "LA":
+        im = im.convert("RGBA")
+    a = np.asarray(im)
     if a.ndim == 2:
         a = np.repeat(a[:, :, None], 3, axis=2)
-    if a.dtype == np.uint16:
+    if a.dtype == np.uint16 or (a.dtype.kind in "iu" and a.dtype.itemsize > 1):
         a = (a / 257.0)
     a = a.astype(np.float64)
-    # cv.imread channel order (BGR / BGRA), which the reference trains in
     return np.concatenate([a[:, :, 2::-1], a[:, :, 3:]], axis=2) if a.shape[2] == 4 else a[:, :, ::-1]
 
 
@@ -93,7 +102,7 @@ class SceneData:
             pic, a = images[..., :3], images[..., 3:]
             images, masks = pic * a + (1 - a), a
         else:                                                        # poses.py:123-127
-            masks = np.stack([_read_png(f) for f in self.masks_lis]) / 255.0
+            masks = np.stack([_read_png(f, unchanged=False) for f in self.masks_lis]) / 255.0
             images = images * masks + (1 - masks)
         self.images, self.masks = images.astype(np.float32), masks.astype(np.float32)
         self.H, self.W = self.images.shape[1:3]

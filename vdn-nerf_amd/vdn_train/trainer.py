@@ -44,6 +44,33 @@ class Trainer:
                 off += n
         self.exp_avg = torch.zeros_like(self.param_flat)
         self.exp_avg_sq = torch.zeros_like(self.param_flat)
+        # torch.optim.Adam keeps a step count per parameter and skips parameters whose .grad is None. In the reference that
+        # is the VDN head and the background network's dpt_linear until the depth-feature loss first enters the loss
+        # (dpt_runner.py:239-243): their moments and bias correction start THEN. Two groups of flat-buffer ranges:
+        self._depth_idx = set()
+        ranges, off = [], 0
+        dn = renderer.depth_network
+        depth_ids = set(id(p) for p in dn.parameters()) if dn is not None else set()
+        dpt = getattr(renderer.nerf, "dpt_linear", None) if renderer.nerf is not None else None
+        if dpt is not None:
+            depth_ids |= set(id(p) for p in dpt.parameters())
+        for i, p in enumerate(self.params):
+            is_d = id(p) in depth_ids
+            if is_d:
+                self._depth_idx.add(i)
+            if ranges and ranges[-1][0] == is_d:
+                ranges[-1][2] = off + p.numel()
+            else:
+                ranges.append([is_d, off, off + p.numel()])
+            off += p.numel()
+        self._main_ranges = [(b, e) for d, b, e in ranges if not d]
+        self._depth_ranges = [(b, e) for d, b, e in ranges if d]
+        if len(self._main_ranges) > 2 or len(self._depth_ranges) > 2:
+            raise ValueError("unexpected parameter order: the fused Adam handles two ranges per step group")
+        self._depth_adam_steps = 0          # optimizer steps the depth group has taken
+        if world_size > 1:
+            import torch.distributed as dist
+            dist.broadcast(self.param_flat, 0)     # replicas must start from rank 0's parameters (e.g. per-process random init)
         self.engine = TrainEngine(renderer, batch_size, self.dev)
         B, T = batch_size, self.engine.T
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.dev)
@@ -72,6 +99,20 @@ class Trainer:
                    z_vals_inject=None):
         r, eng, st = self.r, self.engine, _stream()
         B = self.B
+        # the kernels take raw pointers: packed float32 rows on this device, exactly B of them. The reference's flow slices
+        # one [B, 10+C] row (dpt_runner.py:201): such column views are strided and are packed here.
+        def packed(t, shape, what):
+            if t is None:
+                return None
+            if not (torch.is_tensor(t) and t.device == self.dev and t.dtype == torch.float32):
+                raise ValueError("train_step: %s must be a float32 tensor on %s" % (what, self.dev))
+            if t.numel() != int(np.prod(shape)) or t.shape[0] != shape[0]:
+                raise ValueError("train_step: %s has shape %s, expected %s (batch size is fixed at construction)" % (what, tuple(t.shape), shape))
+            return t.reshape(shape).contiguous()
+        rays_o, rays_d = packed(rays_o, (B, 3), "rays_o"), packed(rays_d, (B, 3), "rays_d")
+        near, far = packed(near, (B, 1), "near"), packed(far, (B, 1), "far")
+        true_rgb = packed(true_rgb, (B, 3), "true_rgb")
+        gt_feats, mask = packed(gt_feats, (B, 96), "gt_feats"), packed(mask, (B, 1), "mask")
         with torch.no_grad():
             z, z_out = r._sample(rays_o, rays_d, near.reshape(B), far.reshape(B), r.perturb, t_rand, t_rand_out, z_vals_inject)
         w = eng.forward(rays_o, rays_d, z.contiguous(), z_out, self.bg, self.cos_anneal_ratio(), skip_far=True)
@@ -97,8 +138,14 @@ class Trainer:
                             self.g_weights if self.conf["mask_weight"] != 0.0 else None, self.g_eik)
         if self.world > 1:
             dp.allreduce_flat(grad)                # one flat message: all gradients of all networks
-        lib.load().vdn_adam_step(self.param_flat.data_ptr(), grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
-                                 self.param_flat.numel(), self.learning_rate(), 0.9, 0.999, 1e-8, self.iter_step + 1 - self._step0(), st)
+        def adam(ranges, step):
+            (b0, e0), (b1, e1) = ranges[0], (ranges[1] if len(ranges) > 1 else (0, 0))
+            lib.call("vdn_adam_step_ranges", lib.ptr(self.param_flat), lib.ptr(grad), lib.ptr(self.exp_avg), lib.ptr(self.exp_avg_sq),
+                     b0, e0, b1, e1, self.learning_rate(), 0.9, 0.999, 1e-8, step, st)
+        adam(self._main_ranges, self.iter_step + 1 - self._step0())
+        if self._depth_ranges and (depth_on or self._depth_adam_steps > 0):
+            self._depth_adam_steps += 1
+            adam(self._depth_ranges, self._depth_adam_steps)
         # weights changed behind torch's version counters: rebuild every network's images now, in two launches
         images.refresh_together([net.img for net in eng.nets.values()], st, self._img_cache)
         self.iter_step += 1
@@ -113,11 +160,13 @@ class Trainer:
         state, off = {}, 0
         for i, p in enumerate(self.params):
             n = p.numel()
-            state[i] = {"step": torch.tensor(float(self.iter_step - self._step0())),
-                        "exp_avg": self.exp_avg[off:off + n].view(p.shape).clone(),
-                        "exp_avg_sq": self.exp_avg_sq[off:off + n].view(p.shape).clone()}
+            steps = self._depth_adam_steps if i in self._depth_idx else self.iter_step - self._step0()
+            if steps > 0:          # torch.optim.Adam has no state for a parameter that never had a gradient
+                state[i] = {"step": torch.tensor(float(steps)),
+                            "exp_avg": self.exp_avg[off:off + n].view(p.shape).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[off:off + n].view(p.shape).clone()}
             off += n
-        opt = {"state": state if self.iter_step > self._step0() else {},
+        opt = {"state": state,
                "param_groups": [{"lr": self.learning_rate(), "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0, "amsgrad": False,
                                  "params": list(range(len(self.params)))}]}
         cl = lambda m: {k: v.detach().clone() for k, v in m.state_dict().items()}
@@ -150,12 +199,16 @@ class Trainer:
                 load(r.depth_network, ck["depth_network_fine"])
             st = ck["optimizer"]["state"]
             off = 0
-            steps = 0
+            steps = {False: 0, True: 0}           # per step group: (main, depth)
+            self.exp_avg.zero_()
+            self.exp_avg_sq.zero_()
             for i, p in enumerate(self.params):
                 n = p.numel()
                 if i in st:
                     self.exp_avg[off:off + n].copy_(st[i]["exp_avg"].reshape(-1).to(self.dev))
                     self.exp_avg_sq[off:off + n].copy_(st[i]["exp_avg_sq"].reshape(-1).to(self.dev))
-                    steps = int(st[i]["step"])
+                    g = i in self._depth_idx
+                    steps[g] = max(steps[g], int(st[i]["step"]))
                 off += n
-            self._adam_step_offset = self.iter_step - steps
+            self._adam_step_offset = self.iter_step - steps[False]
+            self._depth_adam_steps = steps[True]
