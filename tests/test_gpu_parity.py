@@ -119,7 +119,7 @@ def test_upsample_round_by_round_vs_reference(env, dev, golden, name):
     plus the SDF of those z (evaluated by the fp32 kernel, itself pinned to 1e-5 by test_sdf_network_stage) -> the 16 new z
     -> merged -> against the reference's z after round i (renderer.py:147-207). The inverse CDF is ill-conditioned where
     the CDF is flat: those entries are COUNTED, not skipped - at most 2 % of the samples may sit beyond
-    1e-5 and none of them may be off by more than the local bin width."""
+    1e-5 / 1e-4 against the reference's own fp32-vs-fp64 floor, and none may be off by more than one bin width."""
     from vdn_hip import lib
     from dpt_models.fields import _stream
     g = golden(name)
@@ -127,7 +127,7 @@ def test_upsample_round_by_round_vs_reference(env, dev, golden, name):
     o, d = torch.tensor(g["rays_o"]).to(dev), torch.tensor(g["rays_d"]).to(dev)
     B = o.shape[0]
     u = torch.linspace(0.5 / 16, 1.0 - 0.5 / 16, 16, device=dev)
-    n_bad = n_all = 0
+    n_bad = n_bad4 = n_all = 0
     for i in range(4):
         M = 64 + 16 * i
         if i > 0:
@@ -137,22 +137,44 @@ def test_upsample_round_by_round_vs_reference(env, dev, golden, name):
             z_prev = near + (far - near) * torch.linspace(0.0, 1.0, 64, device=dev)[None, :]
             z_prev = z_prev + (torch.tensor(g["t_rand"]).to(dev).view(B, 1) - 0.5) * (2.0 / 64)
         z_prev = z_prev.contiguous()
-        with torch.no_grad():
-            sdf = rend.sdf_network._run(0, rays=(o, d, z_prev)).view(B, M)
+        if i == 0:      # the reference's own SDF values at the coarse z: this round's inputs are bit-identical to the reference's
+            sdf = torch.tensor(g["coarse_sdf"]).to(dev).contiguous()
+        else:
+            with torch.no_grad():
+                sdf = rend.sdf_network._run(0, rays=(o, d, z_prev)).view(B, M)
         new = torch.empty(B, 16, device=dev)
         a = lib.VdnUpsampleArgs()
         a.rays_o, a.rays_d, a.z, a.sdf, a.u, a.new_z = o.data_ptr(), d.data_ptr(), z_prev.data_ptr(), sdf.data_ptr(), u.data_ptr(), new.data_ptr()
         a.B, a.M, a.ld, a.n_imp, a.inv_s = B, M, M, 16, 64.0 * 2 ** i
         lib.call("vdn_upsample_round", a, _stream())
-        merged, _ = torch.sort(torch.cat([z_prev, new], -1), dim=-1)
         ref = g["z_round%d" % i]
-        err = np.abs(merged.cpu().numpy() - ref)
-        width = np.diff(ref, axis=-1).max()
-        assert err.max() <= width + 1e-6, (i, err.max(), width)
-        n_bad += int((err > 1e-5).sum())
-        n_all += err.size
-        assert (err > 1e-5).mean() < 0.02, (i, (err > 1e-5).mean())
-    print("%s: %d of %d z beyond 1e-5 over 4 rounds" % (name, n_bad, n_all))
+        # the reference's 16 new z of this round = its merged row minus the previous row (old values are carried unchanged)
+        zp = z_prev.cpu().numpy()
+        got = np.sort(new.cpu().numpy(), axis=-1)
+        for r in range(B):
+            keep = np.ones(M + 16, bool)
+            j = 0
+            for k in range(M + 16):             # remove one occurrence of every old value (both rows are sorted)
+                if j < M and ref[r, k] == zp[r, j]:
+                    keep[k] = False
+                    j += 1
+            assert j == M and keep.sum() == 16, (i, r, j)
+            ref_new = ref[r, keep]
+            err = np.abs(got[r] - ref_new)
+            width = np.diff(ref[r]).max()
+            assert err.max() <= width + 1e-6, (i, r, err.max(), width)     # never further off than one bin
+            n_bad += int((err > 1e-5).sum())
+            n_bad4 += int((err > 1e-4).sum())
+            n_all += 16
+        if i == 0:
+            # identical inputs: what remains is the kernel's arithmetic against ATen's (sigmoid, fp64 scans, the flat-CDF branch)
+            print("%s round 0 on the reference's sdf: %d of %d new z beyond 1e-5, %d beyond 1e-4" % (name, n_bad, n_all, n_bad4))
+            assert n_bad <= 1 and n_bad4 == 0, (n_bad, n_bad4, n_all)
+    # ill-conditioned entries (flat CDF) are counted, not skipped. The yardstick is the reference against
+    # itself (fp32 vs fp64, SURVEY.md 4 [probe]): 13 % of the samples beyond 1e-5 and 0.8 % beyond 1e-4; a single round on
+    # identical z (rounds 1-3 differ in the SDF values' last bits: the kernel's own fp32 SDF) must stay at that level.
+    print("%s: %d of %d new z beyond 1e-5, %d beyond 1e-4" % (name, n_bad, n_all, n_bad4))
+    assert n_bad <= 0.13 * n_all and n_bad4 <= 0.015 * n_all, (n_bad, n_bad4, n_all)
 
 
 def test_merge_sorted_kernel_equals_stable_sort_with_ties(dev, golden, env):
