@@ -3,10 +3,17 @@
 per GPU per step (BASELINE.json metric), synthetic 800x800 scene, random-init weights of the
 shipped architecture.
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, or spawned here)
 
-One JSON line on rank 0 with the driver's contract plus `roofline` (dominant kernel, timed live with
-HIP events) and `cpu_baseline` (the oracle = CPU restatement of the reference, timed on this host).
+One JSON line on rank 0 with the driver's contract plus
+  roofline      the fused SDF kernel as the timed step launches it (HIP events on the launch stream), beside its
+                inference launch; traffic = PMC bytes from the committed profile of the same launch;
+  parity_path   the SAME step on the fp32 kernels (the path that holds the 1e-4 tolerance), driver-timed in this run;
+  wdepth        the womsk_white_wdepth step (VDN head + depth-feature loss);
+  all_samples_evaluated  the step with the zero-weight work lists off;
+  trials        every timed region is K steps bracketed by barrier + synchronize; `value` is the median region of at
+                least 5 regions / 1 s of timed GPU work, the spread is reported;
+  cpu_baseline  the oracle (CPU restatement of the reference) timed on this host.
 """
 import argparse
 import json
@@ -24,9 +31,16 @@ import torch
 
 # algorithmic FLOPs (2 per MAC, GEMM work only) - SURVEY.md 8d
 F_SDF, F_SDF1, F_GRAD, F_COL, F_VDN, F_NERF, F_NERF_DPT = 1049088, 918016, 918016, 542720, 590336, 1208320, 1232896
-FLOP_PER_RAY_FWD = 112 * F_SDF1 + 128 * (F_SDF + F_GRAD) + 128 * F_COL + 160 * F_NERF          # 617 406 464
-FLOP_PER_RAY_TRAIN = 112 * F_SDF1 + 3 * (128 * (F_SDF + F_GRAD) + 128 * F_COL + 160 * F_NERF)  # 1 646 583 808
 PEAK = {"f32": 157.3e12, "bf16": 2.5e15}     # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PROFILE_ROUND = "r02"
+
+
+def flop_per_ray(wdepth, fg_frac=1.0, bg_frac=1.0):
+    """SURVEY.md 8d's training-step convention (no-grad sampler x1, differentiable part x3) with the fraction of the
+    foreground (SDF + heads) / background (NeRF++) points the step actually evaluates."""
+    fg = 128 * (F_SDF + F_GRAD + F_COL + (F_VDN if wdepth else 0))
+    bg = 160 * (F_NERF_DPT if wdepth else F_NERF)
+    return 112 * F_SDF1 + 3 * (fg * fg_frac + bg * bg_frac)
 
 
 def time_kernel(fn, iters=10):
@@ -100,6 +114,122 @@ def spawn_ranks(n):
     return subprocess.call(cmd)
 
 
+class Leg:
+    """One configuration of the training step (precision x config) with its own renderer, trainer and resident batches."""
+
+    def __init__(self, args, dev, world, rank, precision, wdepth, n_batches):
+        from vdn_train import synth, factory
+        from vdn_train.trainer import Trainer
+        self.world, self.rank, self.dev, self.B, self.wdepth, self.precision = world, rank, dev, args.batch, wdepth, precision
+        seed = 0
+        st = synth.make_all_states(seed, wdepth=wdepth)
+        self.rend = factory.build_renderer(wdepth=wdepth, device=dev, states=st, precision=precision)
+        # wdepth: the depth-feature loss is live from the first timed step (dpt_runner.py:236 with depth_start_iter behind us)
+        self.trainer = Trainer(self.rend, self.B, dev, conf=dict(extract_depth=True, depth_start_iter=-1) if wdepth else None,
+                               world_size=world, rank=rank)
+        cams = synth.make_cameras(seed)
+        perm = np.argsort(synth.uniform(seed, "perm", (len(cams),)))
+        g = lambda x: torch.tensor(x).to(dev)
+        self.gt_feats = g(synth.uniform(seed, "bench/feats/%d" % rank, (self.B, 96)).astype(np.float32)) if wdepth else None
+
+        def batch(step):
+            o, d = synth.random_pixel_batch(seed, step, int(perm[step % len(perm)]), self.B, rank=rank, cams=cams)
+            near, far = synth.near_far_from_sphere(o, d)
+            return g(o), g(d), g(near), g(far), g(synth.target_colors(o, d))
+        self.batches = [batch(s) for s in range(n_batches)]     # resident in HBM before any timed region
+
+    def step(self, i):
+        # one iteration of dpt_runner.py:197-259: sample -> render -> loss -> backward -> (all-reduce) -> Adam
+        return self.trainer.train_step(*self.batches[i % len(self.batches)], gt_feats=self.gt_feats)
+
+    def fence(self):
+        torch.cuda.synchronize()
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def region(self, first, k):
+        """Exactly k steps bracketed by barrier + synchronize; MAX over ranks (seconds)."""
+        self.fence()
+        t0 = time.time()
+        for i in range(k):
+            out = self.step(first + i)
+        self.fence()
+        dt = time.time() - t0
+        if self.world > 1:
+            import torch.distributed as dist
+            tmax = torch.tensor([dt], device=self.dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        self.last = out
+        return dt
+
+    def measure(self, warmup, steps, min_trials=5, min_seconds=1.0, max_trials=60):
+        for i in range(warmup):
+            self.step(i)
+        regions = []
+        # (the loop condition only uses max-reduced times, so every rank runs the same number of regions)
+        while len(regions) < min_trials or (sum(regions) < min_seconds and len(regions) < max_trials):
+            regions.append(self.region(warmup + len(regions) * steps, steps))
+        med = float(np.median(regions))
+        eng = self.trainer.engine
+        fg = int(eng.w["fg_active"][1].item())
+        bg = int(eng.w["bg_active"][1].item()) if "bg_active" in eng.w else 0
+        rays = self.world * self.B * steps
+        fpr = flop_per_ray(self.wdepth, fg / float(eng.P), bg / float(eng.Q) if eng.Q else 1.0)
+        return {"value": rays / med, "ms_per_step": med / steps * 1e3,
+                "trials": {"regions": len(regions), "steps_per_region": steps, "timed_seconds": float(sum(regions)),
+                           "ms_per_step_min": min(regions) / steps * 1e3, "ms_per_step_max": max(regions) / steps * 1e3},
+                "foreground_points_evaluated_last_step": fg, "foreground_points_total": eng.P,
+                "background_points_evaluated_last_step": bg, "background_points_total": eng.Q,
+                "executed_flop_per_ray": fpr, "executed_model_flops_per_s": rays / med * fpr,
+                "final_loss": float(self.last[0].item())}
+
+    def sdf_kernel_roofline(self):
+        """The fused SDF-MLP kernel (north-star kernel): PE -> 9 layers -> sdf/feature + analytic gradient sweep, timed with HIP
+        events exactly as the timed training step launches it (foreground work list of the last step, training-mode saves),
+        and as render() launches it under no_grad (all 65 536 points, nothing saved)."""
+        eng, rend = self.trainer.engine, self.rend
+        dtype = "f32" if self.precision == "fp32" else "bf16"
+        o, d = self.batches[0][0], self.batches[0][1]
+        self.step(0)                                   # a default step's work lists
+        tk = time_kernel(lambda: eng._sdf_forward(o, d))
+        fg_rows = int(eng.w["fg_active"][1].item())
+        with torch.no_grad():
+            tk_inf = time_kernel(lambda: rend.sdf_network._run(1, rays=(o, d, eng.w["mid_z"])))
+
+        def traffic_of(tag):
+            tf = os.path.join(ROOT, "profiles", "%s_traffic_sdf_fwd_%s%s.json" % (PROFILE_ROUND, self.precision, tag))
+            if not os.path.exists(tf):
+                return None, None
+            j = json.load(open(tf))
+            return j.get("hbm_bytes_per_launch"), os.path.relpath(tf, ROOT)
+        tr_train, src_train = traffic_of("_train")
+        tr_inf, src_inf = traffic_of("")
+        if tr_train is not None:
+            tr_train *= fg_rows / float(eng.P)        # PMC figure is for a 65 536-point launch; bytes scale with the rows
+        fl_train, fl_inf = (F_SDF + F_GRAD) * fg_rows, (F_SDF + F_GRAD) * eng.P
+        name = ("sdf_fwd_kernel<F32,1,4,false>" if dtype == "f32" else "sdf2::sdf_fwd2_kernel<1,true,4,3> (csrc/k_sdf_fwd2.h)")
+        return {"bound": "mfma", "kernel": name + ": fused PE + SDF MLP + gradient sweep, training-mode launch of the timed step over its "
+                                                   "foreground work list",
+                "achieved": fl_train / tk / 1e12, "peak": PEAK[dtype] / 1e12, "unit": "TFLOP/s", "frac": fl_train / tk / PEAK[dtype],
+                "traffic": tr_train, "traffic_source": src_train, "kernel_ms": tk * 1e3, "points": fg_rows,
+                "inference_launch": {"kernel_ms": tk_inf * 1e3, "points": eng.P, "achieved": fl_inf / tk_inf / 1e12,
+                                     "frac": fl_inf / tk_inf / PEAK[dtype], "traffic": tr_inf, "traffic_source": src_inf}}
+
+    def dw_roofline(self):
+        eng = self.trainer.engine
+        dtype = "f32" if self.precision == "fp32" else "bf16"
+        tdw = time_kernel(lambda: eng._launch_dw())
+        dw_bytes, dw_flops = eng.dw_bytes(), eng.dw_flops()
+        tdwf = os.path.join(ROOT, "profiles", "%s_traffic_dw_gemm_%s.json" % (PROFILE_ROUND, dtype))
+        traffic = json.load(open(tdwf)).get("hbm_bytes_per_launch") if (os.path.exists(tdwf) and not self.wdepth) else None
+        return {"bound": "hbm", "kernel": "dw_gemm_%s_kernel (batched split-K weight-gradient GEMM, longest kernel of the step)" % dtype,
+                "achieved": dw_bytes / tdw / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": dw_bytes / tdw / 8e12,
+                "traffic": traffic, "kernel_ms": tdw * 1e3, "tflops": dw_flops / tdw / 1e12}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,10 +237,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-all-samples", action="store_true", help="skip the second timed leg (work lists off); keeps a rocprof trace of "
-                    "this command to one population of launches per kernel")
+    ap.add_argument("--headline-only", action="store_true", help="only the headline leg: keeps a rocprof trace of this command to one "
+                    "population of launches per kernel (no all-samples / fp32 / wdepth legs, no forward-only renders)")
+    ap.add_argument("--no-all-samples", action="store_true", help="skip the leg with the zero-weight work lists off")
     ap.add_argument("--config", choices=["womsk_white", "womsk_white_wdepth"], default="womsk_white",
-                    help="womsk_white = BASELINE.json configs[1] (the headline); womsk_white_wdepth = configs[2] (VDN head + depth-feature loss)")
+                    help="womsk_white = BASELINE.json configs[1] (the headline); womsk_white_wdepth = configs[4] (VDN head + depth-feature loss)")
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16",
                     help="bf16 = BASELINE.json's headline config (bf16 MFMA, fp32 accumulate); fp32 = the parity path")
     args = ap.parse_args()
@@ -139,151 +270,81 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    from vdn_train import synth, factory
-    from vdn_train.trainer import Trainer
-    seed, B = 0, args.batch
     wdepth = args.config == "womsk_white_wdepth"
-    st = synth.make_all_states(seed, wdepth=wdepth)
-    rend = factory.build_renderer(wdepth=wdepth, device=dev, states=st, precision=args.precision)
-    # wdepth: the depth-feature loss is live from the first timed step (dpt_runner.py:236 with depth_start_iter behind us)
-    trainer = Trainer(rend, B, dev, conf=dict(extract_depth=True, depth_start_iter=-1) if wdepth else None, world_size=world, rank=rank)
-    gt_feats = None
-    cams = synth.make_cameras(seed)
-    perm = np.argsort(synth.uniform(seed, "perm", (len(cams),)))
-    bg = torch.ones(1, 3, device=dev)
-    g = lambda x: torch.tensor(x).to(dev)
-    if wdepth:
-        gt_feats = g(synth.uniform(seed, "bench/feats/%d" % rank, (B, 96)).astype(np.float32))
+    K, W = args.steps, args.warmup
+    nb = W + K                                          # distinct resident batches; regions cycle through them
+    head = Leg(args, dev, world, rank, args.precision, wdepth, nb)
+    res = head.measure(W, K)
+    extras = {}
+    if not args.headline_only:
+        # The same K steps with every sample evaluated, as the reference does: the default path skips samples that enter the loss
+        # only through exact zeros ("Work lists") - identical results, reported side by side for transparency.
+        if not args.no_all_samples:
+            os.environ["VDN_FG_COMPACT"] = os.environ["VDN_BG_COMPACT"] = "0"
+            r = head.measure(2, K)
+            del os.environ["VDN_FG_COMPACT"], os.environ["VDN_BG_COMPACT"]
+            extras["all_samples_evaluated"] = {k: r[k] for k in ("value", "ms_per_step", "trials", "executed_model_flops_per_s")}
+            extras["all_samples_evaluated"]["note"] = "same steps with VDN_FG_COMPACT=0 VDN_BG_COMPACT=0 (no zero-weight samples skipped)"
+        # forward-only render() throughput on the same rays (inference path)
+        bg = torch.ones(1, 3, device=dev)
+        with torch.no_grad():
+            for i in range(2):
+                head.rend.render(*head.batches[i][:4], background_rgb=bg, cos_anneal_ratio=0.5)
+            head.fence()
+            t1 = time.time()
+            nf = max(10, K)
+            for i in range(nf):
+                head.rend.render(*head.batches[i % nb][:4], background_rgb=bg, cos_anneal_ratio=0.5)
+            head.fence()
+            extras["forward_only_rays_per_s"] = world * args.batch * nf / (time.time() - t1)
+    roof = head.sdf_kernel_roofline() if rank == 0 else None
+    roof_dw = head.dw_roofline() if rank == 0 else None
 
-    def batch(step):
-        o, d = synth.random_pixel_batch(seed, step, int(perm[step % len(perm)]), B, rank=rank, cams=cams)
-        near, far = synth.near_far_from_sphere(o, d)
-        return g(o), g(d), g(near), g(far), g(synth.target_colors(o, d))
-
-    batches = [batch(s) for s in range(args.warmup + args.steps)]     # resident in HBM before the timed region
-
-    def step(i):
-        # one iteration of dpt_runner.py:197-259: sample -> render -> loss -> backward -> (all-reduce) -> Adam
-        return trainer.train_step(*batches[i], gt_feats=gt_feats)
-
-    for i in range(args.warmup):
-        step(i)
-
-    def fence():
-        torch.cuda.synchronize()
+    def other_leg(precision, wd):
+        leg = Leg(args, dev, world, rank, precision, wd, nb)
+        r = leg.measure(W, K)
+        if rank == 0:
+            r["roofline"] = leg.sdf_kernel_roofline()
         if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    fence()
-    t0 = time.time()
-    for i in range(args.steps):
-        out = step(args.warmup + i)
-    fence()
-    dt = time.time() - t0
-    if world > 1:
-        import torch.distributed as dist
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
-    loss_final = float(out[0].item())
-    # The same K steps with every sample evaluated, as the reference does: the default path skips samples that enter the loss
-    # only through exact zeros ("Work lists") - identical results, reported side by side for transparency.
-    dt_all = None
-    if not args.no_all_samples:
-        os.environ["VDN_FG_COMPACT"] = os.environ["VDN_BG_COMPACT"] = "0"
-        for i in range(min(2, args.warmup + args.steps)):
-            step(i)
-        fence()
-        t0 = time.time()
-        for i in range(args.steps):
-            step(args.warmup + i)
-        fence()
-        dt_all = time.time() - t0
-        if world > 1:
-            import torch.distributed as dist
-            tmax = torch.tensor([dt_all], device=dev, dtype=torch.float64)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt_all = float(tmax.item())
-        del os.environ["VDN_FG_COMPACT"], os.environ["VDN_BG_COMPACT"]
-        step(0)                                   # restore the work lists of a default step for the kernel timings below
-    # forward-only render() throughput on the same rays (inference path), reported beside the headline
-    with torch.no_grad():
-        for i in range(2):
-            rend.render(*batches[i][:4], background_rgb=bg, cos_anneal_ratio=0.5)
-        fence()
-        t1 = time.time()
-        nf = max(5, args.steps // 2)
-        for i in range(nf):
-            rend.render(*batches[i % len(batches)][:4], background_rgb=bg, cos_anneal_ratio=0.5)
-        fence()
-        fwd_rays_per_s = world * B * nf / (time.time() - t1)
+            leg.fence()
+        del leg
+        torch.cuda.empty_cache()
+        return r
+    if not args.headline_only:
+        if args.precision == "bf16":
+            # the path that holds the north-star 1e-4 tolerance (tests/test_gpu_parity.py), driver-timed in the same run
+            extras["parity_path"] = dict(other_leg("fp32", wdepth), dtype="f32",
+                                         note="same step on the exact-fp32 MFMA kernels (v_mfma_f32_32x32x2_f32): the path the 1e-4 parity tests hold on")
+        if not wdepth:
+            extras["wdepth"] = dict(other_leg(args.precision, True), config="womsk_white_wdepth (VDN head 4x256->96 + depth-feature loss, BASELINE.json configs[4])")
 
     if rank == 0:
-        rays = world * B * args.steps
-        value = rays / dt
-        flop_per_ray = FLOP_PER_RAY_TRAIN + (3 * (128 * F_VDN + 160 * (F_NERF_DPT - F_NERF)) if wdepth else 0)
-        # The fused SDF-MLP kernel (north-star kernel): PE -> 9 layers -> sdf/feature + analytic gradient sweep on the
-        # 65 536 render_core points, timed with HIP events exactly as it is launched inside the timed training step
-        # (training-mode activation saves included), so it agrees with the rocprofv3 average of the same command.
-        eng = trainer.engine
-        o, d = batches[0][0], batches[0][1]
-        tk = time_kernel(lambda: eng._sdf_forward(o, d))
-        # the training step's launch covers the foreground work list of the last step (inside samples within the relaxed
-        # sphere; the others enter the loss through exact zeros), the inference launch all 65 536 points
-        fg_rows = int(eng.w["fg_active"][1].item())
-        flops_train = (F_SDF + F_GRAD) * fg_rows
-        flops = (F_SDF + F_GRAD) * eng.P
         dtype = "f32" if args.precision == "fp32" else "bf16"
-        # the same kernel without the training saves (what render() launches under torch.no_grad())
-        with torch.no_grad():
-            tk_inf = time_kernel(lambda: rend.sdf_network._run(1, rays=(o, d, eng.w["mid_z"])))
-        # the longest kernel of the step: the batched weight-gradient GEMM, HBM-bound (every saved plane read once)
-        tdw = time_kernel(lambda: eng._launch_dw())
-        dw_bytes, dw_flops = eng.dw_bytes(), eng.dw_flops()
-        # HBM bytes per launch of the fused kernel from the L2 memory-side PMC counters (FETCH_SIZE / WRITE_SIZE in separate
-        # rocprofv3 --pmc passes, gfx950 x2 correction on FETCH_SIZE): collected by tools/collect_traffic.sh, not live
-        def traffic_of(tag):
-            tf = os.path.join(ROOT, "profiles", "r01_traffic_sdf_fwd_%s%s.json" % (args.precision, tag))
-            return json.load(open(tf)).get("hbm_bytes_per_launch") if os.path.exists(tf) else None
-        traffic, traffic_inf = traffic_of("_train"), traffic_of("")
-        if traffic is not None:
-            traffic *= fg_rows / float(eng.P)        # PMC figure is for a 65 536-point launch; bytes scale with the rows
-        tdwf = os.path.join(ROOT, "profiles", "r01_traffic_dw_gemm_%s.json" % dtype)
-        traffic_dw = json.load(open(tdwf)).get("hbm_bytes_per_launch") if (os.path.exists(tdwf) and not wdepth) else None
         line = {
-            "metric": "rays/sec (512-ray batch, 128 samples/ray)", "value": value, "unit": "rays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "metric": "rays/sec (512-ray batch, 128 samples/ray)", "value": res["value"], "unit": "rays/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": res["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "training step of %s (hierarchical sampling + render forward + backward + gradient "
                                    "all-reduce + Adam): SDF 8x256 + colour 4x256 %s+ NeRF 8x256, 512 rays x (64 coarse + 64 importance "
                                    "+ 32 outside) per GPU per step" % (args.config, "+ VDN head 4x256->96 " if wdepth else ""),
-                       "rays_per_gpu": B, "samples_per_ray": 128, "outside_samples": 32, "parallelism": "dp%d" % world,
-                       "flop_per_ray": flop_per_ray, "allreduce_bytes": trainer.param_flat.numel() * 4,
-                       # flop_per_ray is SURVEY.md 8d's algorithmic count (all 160 background samples per ray); background
-                       # samples that render_core multiplies by zero (inside the unit sphere) are not evaluated
-                       "background_points_evaluated_last_step": int(eng.w["bg_active"][1].item()),
-                       "background_points_total": eng.Q,
-                       "foreground_points_evaluated_last_step": fg_rows, "foreground_points_total": eng.P},
-            "model_flops_per_s": value * flop_per_ray,
-            "forward_only_rays_per_s": fwd_rays_per_s, "final_loss": loss_final,
-            "all_samples_evaluated": None if dt_all is None else {
-                "value": world * B * args.steps / dt_all, "ms_per_step": dt_all / args.steps * 1e3,
-                "note": "same steps with VDN_FG_COMPACT=0 VDN_BG_COMPACT=0 (no zero-weight samples skipped)"},
-            "roofline": {"bound": "mfma", "kernel": "sdf_fwd_kernel<%s> (fused PE + SDF MLP + gradient sweep, "
-                                                   "training-mode launch of the timed step over its foreground work list)" % ("F32,1,4,false" if dtype == "f32" else "BF16,1,4,true"),
-                         "achieved": flops_train / tk / 1e12, "peak": PEAK[dtype] / 1e12, "unit": "TFLOP/s",
-                         "frac": flops_train / tk / PEAK[dtype], "traffic": traffic, "kernel_ms": tk * 1e3, "points": fg_rows,
-                         "inference_launch": {"kernel_ms": tk_inf * 1e3, "achieved": flops / tk_inf / 1e12, "frac": flops / tk_inf / PEAK[dtype],
-                                              "traffic": traffic_inf}},
-            "roofline_dw_gemm": {"bound": "hbm", "kernel": "dw_gemm_%s_kernel (batched split-K weight-gradient GEMM, longest kernel of the step)" % dtype,
-                                 "achieved": dw_bytes / tdw / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": dw_bytes / tdw / 8e12,
-                                 "traffic": traffic_dw, "kernel_ms": tdw * 1e3, "tflops": dw_flops / tdw / 1e12},
+                       "rays_per_gpu": args.batch, "samples_per_ray": 128, "outside_samples": 32, "parallelism": "dp%d" % world,
+                       "flop_per_ray": flop_per_ray(wdepth), "allreduce_bytes": head.trainer.param_flat.numel() * 4,
+                       # flop_per_ray is SURVEY.md 8d's algorithmic count (every sample evaluated); samples that render_core
+                       # multiplies by exact zeros are not evaluated: the executed count is below
+                       "executed_flop_per_ray": res["executed_flop_per_ray"],
+                       "background_points_evaluated_last_step": res["background_points_evaluated_last_step"],
+                       "background_points_total": res["background_points_total"],
+                       "foreground_points_evaluated_last_step": res["foreground_points_evaluated_last_step"],
+                       "foreground_points_total": res["foreground_points_total"]},
+            "trials": res["trials"],
+            # FLOPs of the points the step actually evaluated (not the all-samples count)
+            "model_flops_per_s": res["executed_model_flops_per_s"],
+            "final_loss": res["final_loss"],
+            "roofline": roof, "roofline_dw_gemm": roof_dw,
         }
+        line.update(extras)
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(B, seed, wdepth)
+            line["cpu_baseline"] = cpu_baseline(args.batch, 0, wdepth)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

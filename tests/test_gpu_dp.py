@@ -88,22 +88,53 @@ def test_two_rank_gradient_equals_single_process_on_concatenated_batch(wdepth):
     assert np.abs(flat - ref).max() < 2e-5 * np.abs(ref).max()
 
 
-def test_bench_two_rank_control_flow():
-    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one rank per process), with gloo
-    and both ranks on the one GPU of this box: the barriers, the gradient all-reduce, the max-over-ranks timing and the
-    single JSON line of rank 0."""
+def _bench(cmd, env=None):
     import json
-    import os
     import subprocess
-    import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, VDN_DIST_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["config"]["parallelism"] == "dp2" and d["roofline"]["frac"] > 0 and d["cpu_baseline"] is None
+    return json.loads(lines[0])
+
+
+def test_bench_two_rank_control_flow():
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one rank per process), with gloo
+    and both ranks on the one GPU of this box: the barriers, the gradient all-reduce, the max-over-ranks timing and the
+    single JSON line of rank 0. And the plain `python bench.py --gpus 2` form, which must spawn the ranks itself."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VDN_DIST_BACKEND="gloo")
+    tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--headline-only"]
+    for cmd in ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                 "--master-port", "29541"] + tail, [sys.executable] + tail):
+        env.pop("WORLD_SIZE", None)
+        d = _bench(cmd, env)
+        assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
+        assert d["config"]["parallelism"] == "dp2" and d["roofline"]["frac"] > 0 and d["cpu_baseline"] is None
+        assert d["trials"]["regions"] >= 5 and d["trials"]["steps_per_region"] == 3
+    # --gpus that does not match the launcher's world size must not print a line for the wrong GPU count
+    import subprocess
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, WORLD_SIZE="1"), cwd=root)
+    assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_line_carries_every_leg():
+    """One default-shaped run (shortened): the driver's contract keys, the executed-FLOP accounting, the trial spread and the
+    fp32 parity-path / wdepth / all-samples legs in the same line."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = _bench([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "trials", "parity_path", "wdepth", "all_samples_evaluated"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["dtype"] == "bf16" and d["vs_baseline"] is None and "workload" in d["config"]
+    assert d["trials"]["regions"] >= 5 and d["trials"]["timed_seconds"] >= 1.0
+    assert d["parity_path"]["dtype"] == "f32" and d["parity_path"]["value"] > 0 and d["parity_path"]["roofline"]["frac"] > 0
+    assert d["wdepth"]["value"] > 0 and d["wdepth"]["value"] < d["value"]
+    # model FLOP/s counts executed points only: never above the all-samples convention
+    assert d["model_flops_per_s"] <= d["value"] * d["config"]["flop_per_ray"] * (1 + 1e-9)
+    assert d["config"]["executed_flop_per_ray"] <= d["config"]["flop_per_ray"]
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
