@@ -192,8 +192,7 @@ class Leg:
         and as render() launches it under no_grad (all 65 536 points, nothing saved)."""
         eng, rend = self.trainer.engine, self.rend
         dtype = "f32" if self.precision == "fp32" else "bf16"
-        o, d = self.batches[0][0], self.batches[0][1]
-        self.step(0)                                   # a default step's work lists
+        o, d = self.batches[0][0], self.batches[0][1]      # (the caller has run step(0) on every rank: its work lists are current)
         tk = time_kernel(lambda: eng._sdf_forward(o, d))
         fg_rows = int(eng.w["fg_active"][1].item())
         with torch.no_grad():
@@ -297,12 +296,16 @@ def main():
                 head.rend.render(*head.batches[i % nb][:4], background_rgb=bg, cos_anneal_ratio=0.5)
             head.fence()
             extras["forward_only_rays_per_s"] = world * args.batch * nf / (time.time() - t1)
+    head.step(0)                # every rank (the step holds collectives): a default step's work lists for the kernel timings below
+    head.fence()
     roof = head.sdf_kernel_roofline() if rank == 0 else None
     roof_dw = head.dw_roofline() if rank == 0 else None
 
     def other_leg(precision, wd):
         leg = Leg(args, dev, world, rank, precision, wd, nb)
         r = leg.measure(W, K)
+        leg.step(0)
+        leg.fence()
         if rank == 0:
             r["roofline"] = leg.sdf_kernel_roofline()
         if world > 1:

@@ -92,7 +92,7 @@ def _bench(cmd, env=None):
     import json
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
