@@ -165,7 +165,7 @@ class Leg:
         self.last = out
         return dt
 
-    def measure(self, warmup, steps, min_trials=5, min_seconds=1.0, max_trials=60):
+    def measure(self, warmup, steps, min_trials=5, min_seconds=1.0, max_trials=2000):
         for i in range(warmup):
             self.step(i)
         regions = []

@@ -60,9 +60,11 @@ class TrainEngine:
         self.P = B * self.N
         self.Q = B * self.T
         self.wdepth = renderer.depth_network is not None
-        # opt-in (VDN_SIDE_STREAM=1): measured gain 1.9 % of the step; off by default because concurrent kernels blur the
-        # per-kernel rocprof durations the roofline numbers are checked against
-        use_side = os.environ.get("VDN_SIDE_STREAM", "0") == "1" and torch.device(dev).type == "cuda"
+        # The background network runs on a side stream beside the SDF kernels (VDN_SIDE_STREAM=0 puts everything on the caller's
+        # stream, e.g. for a rocprof kernel trace: concurrent kernels inflate each other's durations there). It pays since the
+        # bf16 SDF kernel runs one 128-point workgroup per CU: a work list of ~50 K rows is 1.5 rounds of workgroups, and the
+        # half-empty round's CUs take the background network's workgroups (measured: 1.78 -> 1.65 ms per step).
+        use_side = os.environ.get("VDN_SIDE_STREAM", "1") == "1" and torch.device(dev).type == "cuda"
         self._side = torch.cuda.Stream(device=dev) if use_side else None
         self._ev_fork = torch.cuda.Event() if use_side else None
         self._ev_join = torch.cuda.Event() if use_side else None
