@@ -186,15 +186,30 @@ class Leg:
                 "executed_flop_per_ray": fpr, "executed_model_flops_per_s": rays / med * fpr,
                 "final_loss": float(self.last[0].item())}
 
-    def sdf_kernel_roofline(self):
+    def sdf_kernel_roofline(self, n_lists=6):
         """The fused SDF-MLP kernel (north-star kernel): PE -> 9 layers -> sdf/feature + analytic gradient sweep, timed with HIP
-        events exactly as the timed training step launches it (foreground work list of the last step, training-mode saves),
-        and as render() launches it under no_grad (all 65 536 points, nothing saved)."""
+        events exactly as the timed training step launches it (training-mode saves, over the step's foreground work list) and
+        as render() launches it under no_grad (all 65 536 points, nothing saved). The work list differs from batch to batch
+        (and the kernel runs whole rounds of 128-point workgroups), so the training launch is timed over the lists of
+        `n_lists` different steps: achieved = their FLOPs / their time. Every rank runs the steps (they hold collectives);
+        only rank 0 times."""
         eng, rend = self.trainer.engine, self.rend
         dtype = "f32" if self.precision == "fp32" else "bf16"
-        o, d = self.batches[0][0], self.batches[0][1]      # (the caller has run step(0) on every rank: its work lists are current)
-        tk = time_kernel(lambda: eng._sdf_forward(o, d))
-        fg_rows = int(eng.w["fg_active"][1].item())
+        t_sum, rows_sum, per_list = 0.0, 0, []
+        for j in range(n_lists):
+            self.step(j)
+            self.fence()
+            if self.rank == 0:
+                o, d = self.batches[j % len(self.batches)][0], self.batches[j % len(self.batches)][1]
+                rows = int(eng.w["fg_active"][1].item())
+                t = time_kernel(lambda: eng._sdf_forward(o, d), iters=4)
+                t_sum, rows_sum = t_sum + t, rows_sum + rows
+                per_list.append({"points": rows, "kernel_ms": t * 1e3})
+        self.step(0)
+        self.fence()
+        if self.rank != 0:
+            return None
+        o, d = self.batches[0][0], self.batches[0][1]
         with torch.no_grad():
             tk_inf = time_kernel(lambda: rend.sdf_network._run(1, rays=(o, d, eng.w["mid_z"])))
 
@@ -206,14 +221,15 @@ class Leg:
             return j.get("hbm_bytes_per_launch"), os.path.relpath(tf, ROOT)
         tr_train, src_train = traffic_of("_train")
         tr_inf, src_inf = traffic_of("")
+        rows_mean, tk = rows_sum / float(n_lists), t_sum / n_lists
         if tr_train is not None:
-            tr_train *= fg_rows / float(eng.P)        # PMC figure is for a 65 536-point launch; bytes scale with the rows
-        fl_train, fl_inf = (F_SDF + F_GRAD) * fg_rows, (F_SDF + F_GRAD) * eng.P
+            tr_train *= rows_mean / float(eng.P)      # PMC figure is for a 65 536-point launch; bytes scale with the rows
+        fl_train, fl_inf = (F_SDF + F_GRAD) * rows_mean, (F_SDF + F_GRAD) * eng.P
         name = ("sdf_fwd_kernel<F32,1,4,false>" if dtype == "f32" else "sdf2::sdf_fwd2_kernel<1,true,4,3> (csrc/k_sdf_fwd2.h)")
         return {"bound": "mfma", "kernel": name + ": fused PE + SDF MLP + gradient sweep, training-mode launch of the timed step over its "
-                                                   "foreground work list",
+                                                   "foreground work list (mean over %d steps' lists)" % n_lists,
                 "achieved": fl_train / tk / 1e12, "peak": PEAK[dtype] / 1e12, "unit": "TFLOP/s", "frac": fl_train / tk / PEAK[dtype],
-                "traffic": tr_train, "traffic_source": src_train, "kernel_ms": tk * 1e3, "points": fg_rows,
+                "traffic": tr_train, "traffic_source": src_train, "kernel_ms": tk * 1e3, "points": rows_mean, "per_list": per_list,
                 "inference_launch": {"kernel_ms": tk_inf * 1e3, "points": eng.P, "achieved": fl_inf / tk_inf / 1e12,
                                      "frac": fl_inf / tk_inf / PEAK[dtype], "traffic": tr_inf, "traffic_source": src_inf}}
 
@@ -296,18 +312,13 @@ def main():
                 head.rend.render(*head.batches[i % nb][:4], background_rgb=bg, cos_anneal_ratio=0.5)
             head.fence()
             extras["forward_only_rays_per_s"] = world * args.batch * nf / (time.time() - t1)
-    head.step(0)                # every rank (the step holds collectives): a default step's work lists for the kernel timings below
-    head.fence()
-    roof = head.sdf_kernel_roofline() if rank == 0 else None
+    roof = head.sdf_kernel_roofline()           # every rank takes part (steps hold collectives); rank 0 gets the numbers
     roof_dw = head.dw_roofline() if rank == 0 else None
 
     def other_leg(precision, wd):
         leg = Leg(args, dev, world, rank, precision, wd, nb)
         r = leg.measure(W, K)
-        leg.step(0)
-        leg.fence()
-        if rank == 0:
-            r["roofline"] = leg.sdf_kernel_roofline()
+        r["roofline"] = leg.sdf_kernel_roofline(n_lists=3)
         if world > 1:
             leg.fence()
         del leg
