@@ -40,9 +40,14 @@ VDN_DEV void static_for(F&& f) {
 VDN_DEV int rho(int t, int h) { return (t & 3) + 8 * (t >> 2) + 4 * h; }
 
 // async global -> LDS copy of 16 B per lane; LDS destination = wave-uniform base + lane*16.
+// Inline asm, not __builtin_amdgcn_global_load_lds: with the builtin, hipcc's wait-count pass marks a pending FLAT access
+// and from then on emits s_waitcnt lgkmcnt(0) in front of every LDS consumer - a full LDS round trip before each MFMA
+// group instead of a counted wait (measured on the SDF forward kernel, profiles/README.md round 2). The kernels count
+// these loads themselves (WStream::acquire's vmcnt); the compiler does not see them. M0 (the LDS destination base) is
+// used by nothing else in these kernels.
 VDN_DEV void glds16(const void* gsrc_lane, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+    const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc_lane), "s"(lds) : "memory");
 }
 
 // Hardware transcendental forms (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp each): what the MLP
