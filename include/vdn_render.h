@@ -73,7 +73,7 @@ typedef struct {
     float* normals;            /* [P,3] out (mode 1) */
     void* S;                  /* [8,P,256] workspace: softplus'(pre-activation) per hidden layer (mode 1, f32 entry point).
                                * The bf16 entry point never touches it: it keeps softplus' on the chip (8-bit, LDS + registers) */
-    const float* w8row;        /* [256] row 0 of the last layer's effective weight (mode 1) */
+    const float* w8row;        /* [256] row 0 of the last layer's effective weight (f32 entry point: mode 1; bf16: both modes) */
     /* training-mode saves (mode 1), optional (H == NULL = nothing saved; with H, V is required and PE optional).
      * The f32 entry point saves in the network's own units. The bf16 entry point saves all three in units of
      * 1/(100 log2 e) (H = 100 log2(e) softplus(a), V = 100 log2(e) v, PE = 100 log2(e) encoding): the units its

@@ -22,11 +22,13 @@ def test_bf16_stages_vs_oracle(golden):
     rend = factory.build_renderer(wdepth=True, device=dev, states=st, precision="bf16")
     pts, dirs = g(fx["pts"], dev), g(fx["dirs"], dev)
     out = rend.sdf_network(pts).cpu().numpy()
-    assert np.abs(out[:, 0] - fx["sdf_out"][:, 0]).max() < 2e-2 and np.abs(out[:, 0] - fx["sdf_out"][:, 0]).mean() < 3e-3
+    # sdf: f32 last-layer row + the inputs' bf16 residue in the spare contraction slots (csrc/k_sdf_fwd2.h); what remains is the
+    # operand rounding of the eight hidden bf16 layers
+    assert np.abs(out[:, 0] - fx["sdf_out"][:, 0]).max() < 6e-3 and np.abs(out[:, 0] - fx["sdf_out"][:, 0]).mean() < 1e-3
     assert np.abs(out[:, 1:] - fx["sdf_out"][:, 1:]).max() < 3e-2 * np.abs(fx["sdf_out"][:, 1:]).max()
     nrm = rend.sdf_network.gradient(pts).cpu().numpy()[:, 0]
     assert np.abs(nrm - fx["sdf_grad"]).max() < 5e-2
-    assert np.abs(rend.sdf_network.sdf(pts).cpu().numpy() - fx["sdf_out"][:, :1]).max() < 2e-2
+    assert np.abs(rend.sdf_network.sdf(pts).cpu().numpy() - fx["sdf_out"][:, :1]).max() < 6e-3
     col = rend.color_network(pts, g(fx["sdf_grad"], dev), dirs, g(fx["sdf_out"][:, 1:], dev)).cpu().numpy()
     assert np.abs(col - fx["color"]).max() < 2e-2
     vdn = rend.depth_network(pts, g(fx["sdf_grad"], dev), dirs, g(fx["sdf_out"][:, 1:], dev)).cpu().numpy()
@@ -90,3 +92,45 @@ def test_bf16_gradients_and_training_trajectory(golden):
         t1, t2 = synth.jitter(seed, it, B)
         sc = tr.train_step(o, d, near, far, rgb, t_rand=g(t1, dev), t_rand_out=g(t2, dev))
         assert abs(sc[0].item() - fa["losses"][it]) < 2e-3 * abs(fa["losses"][it]), (it, sc[0].item(), fa["losses"][it])
+
+
+def test_bf16_trained_weights_render_the_same_on_the_fp32_kernels():
+    """Cross-precision check: train on the bf16 path, then render the SAME weights with the fp32 (parity) kernels and with
+    the bf16 kernels. As inv_s grows during training the alpha multiplies the SDF error by it, so agreement at initialisation
+    (test above) does not imply agreement later: the two renders of a held-out view must still agree to >= 45 dB."""
+    from vdn_train import synth, factory
+    from vdn_train.trainer import Trainer
+    dev = torch.device("cuda:0")
+    B, seed, steps = 512, 0, 2000
+    rend = factory.build_renderer(device=dev, precision="bf16")          # the reference's geometric init
+    tr = Trainer(rend, B, dev, conf=dict(warm_up_end=200, end_iter=steps, anneal_end=steps // 4))
+    cams = synth.make_cameras(seed)
+    gg = lambda x: torch.tensor(x).to(dev)
+    order = (synth.uniform(seed, "trainperm", (steps,)) * 40).astype(np.int64) % 40
+    for it in range(steps):
+        img = int(order[it]) if int(order[it]) != 7 else 8           # view 7 is held out
+        o, d = synth.random_pixel_batch(seed, it, img, B, cams=cams, crop=420)
+        near, far = synth.near_far_from_sphere(o, d)
+        tr.train_step(gg(o), gg(d), gg(near), gg(far), gg(synth.target_colors(o, d, 0.5)))
+    inv_s = float(torch.exp(rend.deviation_network.variance * 10).item())
+    assert inv_s > 25.0                                               # it has moved from its initial 20.1
+    ref = factory.build_renderer(device=dev, precision="fp32")
+    for a, b in ((ref.nerf, rend.nerf), (ref.sdf_network, rend.sdf_network), (ref.deviation_network, rend.deviation_network),
+                 (ref.color_network, rend.color_network)):
+        a.load_state_dict({k: v.detach().clone() for k, v in b.state_dict().items()})
+    vx, vy = np.meshgrid(np.linspace(190, 610, 48), np.linspace(190, 610, 48))
+    vo, vd = synth.pixel_rays(cams[7], vx.reshape(-1), vy.reshape(-1))
+    vn, vf = synth.near_far_from_sphere(vo, vd)
+    cols = {}
+    with torch.no_grad():
+        for name, r in (("bf16", rend), ("fp32", ref)):
+            out = []
+            for i in range(0, vo.shape[0], 512):
+                o_ = r.render(gg(vo[i:i + 512]), gg(vd[i:i + 512]), gg(vn[i:i + 512]), gg(vf[i:i + 512]), perturb_overwrite=0,
+                              background_rgb=torch.ones(1, 3, device=dev), cos_anneal_ratio=1.0)
+                out.append(o_["color_fine"])
+            cols[name] = torch.cat(out)
+    mse = ((cols["bf16"] - cols["fp32"]) ** 2).mean().item()
+    psnr = 10.0 * np.log10(1.0 / max(mse, 1e-20))
+    print("bf16-trained weights, inv_s %.1f: bf16 render vs fp32 render %.1f dB" % (inv_s, psnr))
+    assert psnr >= 45.0, (psnr, inv_s)

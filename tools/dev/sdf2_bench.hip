@@ -100,6 +100,9 @@ int main(int argc, char** argv) {
         LayerSpec L{&lin[l], fw[l].km, fw[l].nm, fw[l].sc, 1.0f, true, false};
         append_layer(b_sdf, L, stride); append_layer(b_full, L, stride);
         LayerSpec L2 = L; L2.bias_scale = C1;
+        // residue slots: the 25 spare contraction slots behind the 39 encoded inputs read the first 25 columns again
+        if (l == 0) for (int i = 0; i < 25; ++i) L2.kmap[39 + i] = i;
+        if (l == 4) for (int i = 0; i < 25; ++i) L2.kmap[224 + 39 + i] = 217 + i;
         append_layer(b_sdf2, L2, stride); append_layer(b_full2, L2, stride);
     }
     append_layer(b_sdf, LayerSpec{&lin[8], ident(256, 256), ident(1, 32), 1.0f, 1.0f, true, false}, stride);

@@ -310,8 +310,8 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
     using ST = unsigned short;
     static_assert(NSLOT >= DEPTH + 1, "ring: the chunk being read, the one being opened and DEPTH-1 in flight");
     constexpr int kRing = NSLOT * kStride;
-    constexpr int kW8 = MODE == 1 ? 1024 : 0;          // W8 row 0 (f32) behind the ring
-    constexpr int kLdsTotal = MODE == 1 ? 160 * 1024 : kRing;
+    constexpr int kW8 = 1024;                          // W8 row 0 (f32) behind the ring
+    constexpr int kLdsTotal = MODE == 1 ? 160 * 1024 : kRing + kW8;
     constexpr int NLDS = MODE == 1 ? ((kLdsTotal - kRing - kW8) / (kWaves * 1024) < kSTiles ? (kLdsTotal - kRing - kW8) / (kWaves * 1024) : kSTiles) : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Pipe<NSLOT> pp;
@@ -360,16 +360,24 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
     // tile 8 of X is not touched by anything else, tile 7's copy waits in registers
     bf16x8 pe7[2];
     {
-        float pe[39];
-        posenc<3, 6, false>(xin, pe);
+        float pe39[39], pe[64];
+        posenc<3, 6, false>(xin, pe39);
+        // slots 39..63 of the 64-wide input (zero padding in the first kernel) carry the bf16 rounding residue of the first
+        // 25 encoded values - the raw coordinates and the low octaves - against the same weight columns (kmap of the scaled
+        // streams, vdn_hip/images.py): the network sees those inputs to ~16 bits. A bf16 coordinate alone is an SDF error of
+        // up to 2e-3 at |x| ~ 1, against an alpha that multiplies the SDF by inv_s ~ 1e2 .. 1e4.
 #pragma unroll
-        for (int i = 0; i < 39; ++i) pe[i] *= kC1;
+        for (int i = 0; i < 39; ++i) pe[i] = pe39[i] * kC1;
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) X.set(kt, vals_tile<39>(pe, h, kt));
-        if constexpr (SAVE) {       // saved in the same scaled units as H and V (include/vdn_render.h: VdnSdfArgs)
-            if (a.PE != nullptr) {
+        for (int i = 0; i < 25; ++i) pe[39 + i] = pe[i] - bf16_lo(pack_bf16x2(pe[i], 0.0f));
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt) P::store_tile(reinterpret_cast<ST*>(a.PE), p, 64, kt, h, vals_tile<39>(pe, h, kt), true);
+        for (int kt = 0; kt < 2; ++kt) X.set(kt, vals_tile<64>(pe, h, kt));
+        if constexpr (SAVE) {       // saved in the same scaled units as H and V (include/vdn_render.h: VdnSdfArgs); the residue
+            if (a.PE != nullptr) {  // slots are saved as zeros (the weight-gradient GEMM contracts over the 39 encoded values)
+#pragma unroll
+                for (int i = 39; i < 64; ++i) pe[i] = 0.0f;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) P::store_tile(reinterpret_cast<ST*>(a.PE), p, 64, kt, h, vals_tile<64>(pe, h, kt), true);
             }
         }
         pe7[0] = X.r[0]; pe7[1] = X.r[1];
@@ -377,9 +385,7 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
     }
     // ring start (behind the PE stores, so that nothing but counted operations is younger than a DMA): W8 row 0 into its
     // fixed place (wave 0), chunks 0 .. DEPTH-1 in flight, chunk 0 certified, its opening fragments read
-    if constexpr (MODE == 1) {
-        if (pp.wave == 0) glds16_saddr(reinterpret_cast<const char*>(a.w8row), pp.lane16, smem + kRing);
-    }
+    if (pp.wave == 0) glds16_saddr(reinterpret_cast<const char*>(a.w8row), pp.lane16, smem + kRing);
     static_for<DEPTH>([&](auto i_c) VDN_INL { pp.template issue<decltype(i_c)::value>(); });
     wait_vmcnt<(DEPTH - 1) * kG>();
     __builtin_amdgcn_s_barrier();
@@ -390,6 +396,8 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
     u32x4 sq_prev;              // 255 sigma of the previous chunk's tile: read by the sweep's epilogue, built by a hidden layer's
     u32x4 sq_v7;                // 255 sigma_7 tile while v7 is formed
     unsigned hold0 = 0, hold1 = 0;  // a pair's values waiting for their partners (one 4-value pack / one 8-byte store)
+    f32x4 w8hold;               // W8 row 0 at the features of the pair being worked on
+    float sdf_dot = 0.0f;       // this lane's half of  W8[0,:] . g8  (f32)
     f32x16 UPE[2];              // d sdf / d(PE) tiles (W4^T rows 7,8 and W0^T)
     float n[3] = {0.0f, 0.0f, 0.0f};
     auto pe_backward = [&]() VDN_INL {      // n += J_PE^T u  (transpose Jacobian of the encoding)
@@ -421,6 +429,12 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
                     constexpr int pr = PB + decltype(i_c)::value;       // elements 2pr, 2pr+1
                     const float g0 = softplus_t(acc_prev[2 * pr]);
                     const float g1 = softplus_t(acc_prev[2 * pr + 1]);
+                    if constexpr (L.l == 7) {
+                        // the sdf row of the last layer in f32 on the VALU, from the unrounded activations: 2 FMAs per pair on
+                        // one layer's epilogue, and the output that the alpha multiplies by inv_s loses no bits to bf16
+                        if constexpr ((pr & 1) == 0) w8hold = *reinterpret_cast<const f32x4*>(w8lds + 32 * T + 8 * (pr >> 1) + 4 * h);
+                        sdf_dot = fmaf(g0, w8hold[2 * (pr & 1)], fmaf(g1, w8hold[2 * (pr & 1) + 1], sdf_dot));
+                    }
                     unsigned pk = pack_bf16x2(g0, g1);
                     asm volatile("" : "+v"(pk));
                     u32x4 cur = __builtin_bit_cast(u32x4, D.r[T * 2 + (pr >> 2)]);
@@ -540,7 +554,11 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
             if constexpr (L.kind == SWEEP_SKIP && T >= 7) UPE[T - 7] = acc_cur;
             if constexpr (L.kind == SWEEP_PE) UPE[T] = acc_cur;
             if constexpr (L.kind == LAST && T == L.nt - 1) {
-                if (ok && h == 0) a.sdf[sdf_idx] = acc_cur[0] * inv_scale;
+                // sdf = W8[0,:] . h8 + b8[0]: the f32 dot of layer 7's epilogue (g8 = 100 log2(e) h8), the bias from this
+                // chunk's bias block (row 0); the MFMA's own bf16 value of the row is not used
+                const float b0 = *reinterpret_cast<const float*>(pp.template slot<C>() + L.kt * 2048);
+                const float dot = sdf_dot + __shfl_xor(sdf_dot, 32);
+                if (ok && h == 0) a.sdf[sdf_idx] = fmaf(dot, 1.0f / kC1, b0) * inv_scale;
             }
             acc_prev = acc_cur;
             if constexpr (sweep_tile) sq_prev = sq_next;
@@ -568,7 +586,7 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
 
 template <int MODE, bool SAVE, int NSLOT, int DEPTH, int VID = 0>
 int launch(const VdnSdfArgs* args, hipStream_t stream) {
-    constexpr size_t lds = MODE == 1 ? 160 * 1024 : NSLOT * kStride;
+    constexpr size_t lds = MODE == 1 ? 160 * 1024 : NSLOT * kStride + 1024;
     static bool once = (allow_big_lds(sdf_fwd2_kernel<MODE, SAVE, NSLOT, DEPTH, VID>, lds), true);
     (void)once;
     const int grid = (args->P + kWaves * 32 - 1) / (kWaves * 32);

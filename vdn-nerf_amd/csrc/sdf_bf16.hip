@@ -7,10 +7,10 @@ extern "C" int vdn_sdf_mlp_fwd_bf16(int mode, const VdnSdfArgs* args, void* stre
     if (args == nullptr || args->P <= 0 || args->blob == nullptr) return -1;
     if (args->pts == nullptr && (args->rays_o == nullptr || args->rays_d == nullptr || args->z == nullptr || args->n_per_ray <= 0 ||
                                  args->z_ld < args->n_per_ray || args->sdf_ld < args->n_per_ray)) return -2;
-    if (args->sdf == nullptr) return -3;
-    if (mode == 0) return vdn::sdf2::launch<0, false, 4, 3>(args, stream);
+    if (args->sdf == nullptr || args->w8row == nullptr) return -3;
+    if (mode == 0) return vdn::sdf2::launch<0, false, 3, 2>(args, stream);     // 61 KiB of LDS: two workgroups per CU
     if (mode != 1) return -4;
-    if (!args->feat || !args->normals || !args->w8row) return -3;
+    if (!args->feat || !args->normals) return -3;
     if (args->H != nullptr) {
         if (args->V == nullptr) return -3;
         return vdn::sdf2::launch<1, true, 4, 3>(args, stream);

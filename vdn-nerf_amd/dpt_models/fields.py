@@ -149,6 +149,7 @@ class SDFNetwork(_HipNet):
             sdf = torch.empty(P, dtype=torch.float32, device=dev)
             a.sdf_ld = a.n_per_ray
         a.sdf = sdf.data_ptr()
+        a.w8row = img.weff_view("lin8").data_ptr()
         if mode == 0:
             a.blob = img.blobs["sdf"].data_ptr()
             lib.call("vdn_sdf_mlp_fwd" + self._sfx(), 0, a, _stream())
@@ -162,7 +163,6 @@ class SDFNetwork(_HipNet):
         if self.precision == "fp32":                 # the bf16 kernel keeps softplus' on the chip
             S = torch.empty(8, Pr, 256, dtype=self._store_dtype(), device=dev)
             a.S = S.data_ptr()
-        a.w8row = img.weff_view("lin8").data_ptr()
         lib.call("vdn_sdf_mlp_fwd" + self._sfx(), 1, a, _stream())
         if workspace is not None and S is not None:
             workspace["S"] = S

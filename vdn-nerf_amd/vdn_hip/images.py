@@ -260,6 +260,17 @@ def sdf_streams(d_in, d_out, d_hidden, n_layers, skip_in, multires, scaled=False
         else:
             km, nm, sc = ident_map(256), ident_map(256), 1.0
         fwd.append((name, km, nm, sc))
+    if scaled:
+        # the 25 spare contraction slots behind the 39 encoded inputs (layer 0: 39..63; layer 4: 263..287) read the weight
+        # columns of the first 25 encoded values once more: the kernel feeds them the bf16 rounding residue of those inputs
+        n0, km0, nm0, sc0 = fwd[0]
+        km0 = km0.copy()
+        km0[d0:d0 + 25] = np.arange(25)
+        fwd[0] = (n0, km0, nm0, sc0)
+        n4, km4, nm4, sc4 = fwd[4]
+        km4 = km4.copy()
+        km4[224 + d0:224 + d0 + 25] = (256 - d0) + np.arange(25)
+        fwd[4] = (n4, km4, nm4, sc4)
     bsc = SDF_UNIT if scaled else 1.0
     wsc8 = 1.0 / SDF_UNIT if scaled else 1.0
     swsc = 1.0 / 255.0 if scaled else 1.0
