@@ -54,6 +54,12 @@ typedef struct {
 } VdnChunkDesc;
 int vdn_build_images(const VdnChunkDesc* descs_dev, int n_chunks, void* stream);
 
+/* ---- positional encoding as a stand-alone op: embedder.py:27-36 (Embedder.embed) ----------------------------
+ * out[p, :] = [x, sin(2^0 x), cos(2^0 x), sin(2^1 x), cos(2^1 x), ...]  (each function over all d inputs, then the next),
+ * x = in[p, 0:d]; n_freqs octaves, frequencies 2^k exactly (embedder.py:23). The MLP kernels evaluate the same encoding
+ * in registers; this entry point serves callers of embed_fn (e.g. sdf_network.embed_fn_fine). */
+int vdn_posenc(const float* in, float* out, int64_t P, int32_t d, int32_t n_freqs, void* stream);
+
 /* ---- SDF network: fields.py:72-108 (SDFNetwork.forward / .sdf / .gradient) --------------------
  * mode 0: sdf only (fields.py:91-92; used by the sampler renderer.py:370,201 and the mesh lattice
  *         renderer.py:441-446).  mode 1: sdf + 256-d feature + analytic d sdf/d x. */

@@ -31,7 +31,7 @@ def _gt_feats(rank):
 WDEPTH_CONF = dict(extract_depth=True, depth_start_iter=-1)       # the depth-feature loss is live (dpt_runner.py:239)
 
 
-def _worker(rank, port, q, wdepth=False):
+def _worker(rank, port, q, wdepth=False, backend="gloo"):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "vdn-nerf_amd"))
@@ -39,8 +39,13 @@ def _worker(rank, port, q, wdepth=False):
     from vdn_train import synth, factory
     from vdn_train.trainer import Trainer
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=2)
-    dev = torch.device("cuda:0")
+    # gloo: both ranks on the one GPU of the test box; nccl (= RCCL): one GPU per rank
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=2, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=2)
     rend = factory.build_renderer(wdepth=wdepth, device=dev, states=synth.make_all_states(SEED, wdepth=wdepth))
     tr = Trainer(rend, B, dev, conf=WDEPTH_CONF if wdepth else None, world_size=2, rank=rank)
     g = lambda x: torch.tensor(x).to(dev)
@@ -53,8 +58,7 @@ def _worker(rank, port, q, wdepth=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("wdepth", [False, True])
-def test_two_rank_gradient_equals_single_process_on_concatenated_batch(wdepth):
+def _two_rank_vs_single(wdepth, backend):
     import torch.multiprocessing as mp
     from vdn_train import synth, factory
     from vdn_train.trainer import Trainer
@@ -64,7 +68,7 @@ def test_two_rank_gradient_equals_single_process_on_concatenated_batch(wdepth):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, port, q, wdepth)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, port, q, wdepth, backend)) for r in range(2)]
     for p in procs:
         p.start()
     flat, eik = q.get(timeout=600)
@@ -86,6 +90,18 @@ def test_two_rank_gradient_equals_single_process_on_concatenated_batch(wdepth):
         assert np.abs(ref[-297408:]).max() > 0          # the VDN head's gradient is live
     assert abs(eik - float(sc[3].item())) < 1e-5 * abs(eik)                 # global eikonal term
     assert np.abs(flat - ref).max() < 2e-5 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("wdepth", [False, True])
+def test_two_rank_gradient_equals_single_process_on_concatenated_batch(wdepth):
+    _two_rank_vs_single(wdepth, "gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank; the test box has one")
+def test_two_rank_gradient_over_rccl():
+    """The same equivalence with the gradient all-reduce, the eikonal reduction and the parameter broadcast over RCCL
+    (backend "nccl" on ROCm), one GPU per rank."""
+    _two_rank_vs_single(True, "nccl")
 
 
 def _bench(cmd, env=None):

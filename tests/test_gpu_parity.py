@@ -83,6 +83,27 @@ def test_rendering_and_nerf_stage(env, dev, golden):
     assert relmax(ft.detach().cpu().numpy(), fx["nerf_feat"]) < 1e-5
 
 
+def test_standalone_embedder_vs_reference_vectors(dev, golden):
+    """a1: Embedder.embed as a callable (embedder.py:27-36) against the reference's own encoding vectors, for the three
+    (d, L) the shipped configurations use; order [x, sin(2^0 x), cos(2^0 x), sin(2^1 x), ...]."""
+    from dpt_models.embedder import get_embedder
+    fx = golden("stages")
+    pts = fx["pts"]
+    for key_out, d, L in (("pe_6_3", 3, 6), ("pe_4_3", 3, 4), ("pe_10_4", 4, 10)):
+        x = pts if d == 3 else np.concatenate([pts, pts[:, :1] * 0.5], -1)        # the inputs tests/golden/make_golden.py fed
+        fn, out_dim = get_embedder(L, d)
+        assert out_dim == d * (1 + 2 * L)
+        got = fn(g(x, dev)).cpu().numpy()
+        assert got.shape == fx[key_out].shape
+        assert np.abs(got - fx[key_out]).max() < 2e-6, key_out
+    fn, _ = get_embedder(6, 3)
+    x = torch.rand(5, 7, 3, device=dev)
+    ref = torch.cat([x] + [f(x * 2.0 ** k) for k in range(6) for f in (torch.sin, torch.cos)], -1)
+    assert fn(x).shape == (5, 7, 39) and (fn(x) - ref).abs().max().item() < 1e-5
+    with pytest.raises(RuntimeError):
+        fn(torch.zeros(2, 3))
+
+
 def test_sample_pdf_vs_reference_vectors(dev, golden):
     """a10: the inverse-CDF half of vdn_upsample_round on the reference's OWN sample_pdf vectors (renderer.py:44-74, det=True):
     spdf_bins / spdf_w -> spdf_out, including rows whose CDF is flat over several bins (the denom < 1e-5 -> 1 branch of

@@ -98,6 +98,32 @@ __global__ void build_images_kernel(const ChunkDesc* descs) {
 
 }  // namespace vdn
 
+namespace vdn {
+// one thread per (point, input component): x, then sin / cos of every octave (ocml sincosf: the fp32 parity path's trig)
+__global__ void posenc_kernel(const float* __restrict__ in, float* __restrict__ out, long P, int d, int L) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P * d) return;
+    const long p = i / d;
+    const int c = (int)(i - p * d);
+    const float x = in[i];
+    float* o = out + p * (long)(d * (1 + 2 * L));
+    o[c] = x;
+    for (int k = 0; k < L; ++k) {
+        float s, co;
+        sincosf(x * (float)(1 << k), &s, &co);
+        o[d + 2 * d * k + c] = s;
+        o[d + 2 * d * k + d + c] = co;
+    }
+}
+}  // namespace vdn
+
+extern "C" int vdn_posenc(const float* in, float* out, int64_t P, int32_t d, int32_t n_freqs, void* stream) {
+    if (!in || !out || P <= 0 || d <= 0 || n_freqs < 0 || n_freqs > 24) return -1;
+    const long n = (long)P * d;
+    hipLaunchKernelGGL(vdn::posenc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out, (long)P, d, n_freqs);
+    return (int)hipGetLastError();
+}
+
 extern "C" int vdn_abi_version(void) { return VDN_ABI_VERSION; }
 
 extern "C" int vdn_weightnorm_materialize(const VdnWeightNormDesc* descs_dev, int n_layers, int max_rows, void* stream) {
