@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VDN_ABI_VERSION 6
+#define VDN_ABI_VERSION 7
 
 int vdn_abi_version(void);
 
@@ -51,6 +51,9 @@ typedef struct {
     int32_t kt_count;        /* kmap is indexed from the start of that range. kt_count 0 = whole chunk    */
     int32_t write_bias;      /* 1: also write the chunk's bias/pad block (exactly one descriptor per chunk) */
     float bias_scale;        /* the bias block holds bias_scale * bias[row] */
+    const float* tail;       /* optional: tail_n floats copied to dst + tail_off (behind the bias block, inside the chunk's   */
+    int32_t tail_off;        /* stride): a small constant that rides along with every chunk's DMA - the bf16 SDF streams carry */
+    int32_t tail_n;          /* row 0 of the last layer's weight there (csrc/k_sdf_fwd2.h)                                    */
 } VdnChunkDesc;
 int vdn_build_images(const VdnChunkDesc* descs_dev, int n_chunks, void* stream);
 
@@ -79,7 +82,7 @@ typedef struct {
     float* normals;            /* [P,3] out (mode 1) */
     void* S;                  /* [8,P,256] workspace: softplus'(pre-activation) per hidden layer (mode 1, f32 entry point).
                                * The bf16 entry point never touches it: it keeps softplus' on the chip (8-bit, LDS + registers) */
-    const float* w8row;        /* [256] row 0 of the last layer's effective weight (f32 entry point: mode 1; bf16: both modes) */
+    const float* w8row;        /* [256] row 0 of the last layer's effective weight (f32 entry point, mode 1; the bf16 streams carry it) */
     /* training-mode saves (mode 1), optional (H == NULL = nothing saved; with H, V is required and PE optional).
      * The f32 entry point saves in the network's own units. The bf16 entry point saves all three in units of
      * 1/(100 log2 e) (H = 100 log2(e) softplus(a), V = 100 log2(e) v, PE = 100 log2(e) encoding): the units its

@@ -38,6 +38,7 @@ namespace sdf2 {
 #define VDN_SDF2_ABL 0   // timing-only ablations (development harness), bit mask: 1 no epilogue math, 2 no MFMA, 4 no weight DMA, 8 no chunk barrier
 #endif
 constexpr int kStride = 20480;          // BF16::stride(9)
+constexpr int kTail = 9 * 2048 + 1024;  // row 0 of W8 (f32 x 256) in every chunk's tail (vdn_hip/images.py: SDF_TAIL_OFF)
 constexpr int kWaves = 4;
 constexpr int kG = kStride / 1024 / kWaves;   // global_load_lds instructions per wave per chunk
 constexpr int kPre = VDN_SDF2_PRE;      // weight fragments read ahead of their MFMA
@@ -97,16 +98,22 @@ constexpr int tile_stores(int c) {
         default: return 0;
     }
 }
+// steps whose epilogue stores planes issue their DMA pieces in one burst right behind the barrier, AHEAD of those stores:
+// vmcnt retires in issue order, so a store issued before the awaited DMA would have to be acknowledged by memory before the
+// wait returns. Steps without stores spread the pieces over the MFMA groups (less contention in the CU's memory path).
+template <int MODE, bool SAVE>
+constexpr bool dma_burst(int c) { return tile_stores<MODE, SAVE>(c - 1) > 0; }
 // s_waitcnt vmcnt(N) that retires this wave's DMA of chunk c+1 in step c (before its barrier). Younger than that DMA
-// (issued during step c+1-DEPTH) are the DMAs of chunks c+2 .. c+DEPTH-1 and the stores of steps c+2-DEPTH .. c-1
-// (the stores of step c+1-DEPTH itself interleave with its DMA pieces: not counted, which only waits longer).
+// (issued during step c+1-DEPTH) are the DMAs of chunks c+2 .. c+DEPTH-1, the stores of steps c+2-DEPTH .. c-1, and - when
+// step c+1-DEPTH issued its DMA as a burst ahead of its stores - that step's stores too.
 template <int MODE, bool SAVE, int DEPTH>
 constexpr int wait_count(int c) {
     using PG = Prog<MODE>;
     int n = 0;
     for (int j = c + 2; j <= c + DEPTH - 1; ++j)
         if (j < PG::total) n += kG;
-    for (int j = c + 2 - DEPTH; j <= c - 1; ++j) n += tile_stores<MODE, SAVE>(j - 1);     // step j runs the epilogue of chunk j-1
+    for (int j = c + 1 - DEPTH; j <= c - 1; ++j)
+        if (j >= c + 2 - DEPTH || dma_burst<MODE, SAVE>(j)) n += tile_stores<MODE, SAVE>(j - 1);     // step j runs the epilogue of chunk j-1
     return n < 63 ? n : 63;
 }
 
@@ -215,7 +222,9 @@ VDN_DEV f32x16 chunk_step(Pipe<NSLOT>& pp, const ActT& X, Group&& group) {
             __builtin_amdgcn_sched_barrier(0);
         }
         // DMA of chunk C+DEPTH (into the slot chunk C-1 was read from: every wave is past the barrier), spread over the groups
-        if constexpr (HAS_DMA) {
+        if constexpr (HAS_DMA && dma_burst<MODE, SAVE>(C)) {
+            if constexpr (gi == 0) static_for<kG>([&](auto i_c) VDN_INL { pp.template issue_piece<C + DEPTH, decltype(i_c)::value>(); });
+        } else if constexpr (HAS_DMA) {
 #ifdef VDN_SDF2_STAGGER
             // even waves issue in even groups, odd waves in odd groups: at most two of the four waves' pieces meet in the
             // CU's vector-memory path (the waves run in lockstep, so an unstaggered piece always meets three others)
@@ -310,7 +319,7 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
     using ST = unsigned short;
     static_assert(NSLOT >= DEPTH + 1, "ring: the chunk being read, the one being opened and DEPTH-1 in flight");
     constexpr int kRing = NSLOT * kStride;
-    constexpr int kW8 = 1024;                          // W8 row 0 (f32) behind the ring
+    constexpr int kW8 = 0;                             // (W8 row 0 rides in every chunk's tail: kTail)
     constexpr int kLdsTotal = MODE == 1 ? 160 * 1024 : kRing + kW8;
     constexpr int NLDS = MODE == 1 ? ((kLdsTotal - kRing - kW8) / (kWaves * 1024) < kSTiles ? (kLdsTotal - kRing - kW8) / (kWaves * 1024) : kSTiles) : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -354,7 +363,6 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
     typename P::template Act<9> X, Y;
     SStore<NLDS> SS;
     SS.lds = smem + kRing + kW8 + pp.wave * (NLDS * 1024) + lane * 16;
-    const float* w8lds = reinterpret_cast<const float*>(smem + kRing);
 
     // positional encoding in scaled units: X tiles 0,1 (layer 0) and a copy for the skip input of layer 4 (tiles 7,8):
     // tile 8 of X is not touched by anything else, tile 7's copy waits in registers
@@ -385,7 +393,6 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
     }
     // ring start (behind the PE stores, so that nothing but counted operations is younger than a DMA): W8 row 0 into its
     // fixed place (wave 0), chunks 0 .. DEPTH-1 in flight, chunk 0 certified, its opening fragments read
-    if (pp.wave == 0) glds16_saddr(reinterpret_cast<const char*>(a.w8row), pp.lane16, smem + kRing);
     static_for<DEPTH>([&](auto i_c) VDN_INL { pp.template issue<decltype(i_c)::value>(); });
     wait_vmcnt<(DEPTH - 1) * kG>();
     __builtin_amdgcn_s_barrier();
@@ -432,7 +439,7 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
                     if constexpr (L.l == 7) {
                         // the sdf row of the last layer in f32 on the VALU, from the unrounded activations: 2 FMAs per pair on
                         // one layer's epilogue, and the output that the alpha multiplies by inv_s loses no bits to bf16
-                        if constexpr ((pr & 1) == 0) w8hold = *reinterpret_cast<const f32x4*>(w8lds + 32 * T + 8 * (pr >> 1) + 4 * h);
+                        if constexpr ((pr & 1) == 0) w8hold = *(reinterpret_cast<const f32x4*>(pp.template slot<CP + 1>() + kTail) + (8 * T + 2 * (pr >> 1) + h));
                         sdf_dot = fmaf(g0, w8hold[2 * (pr & 1)], fmaf(g1, w8hold[2 * (pr & 1) + 1], sdf_dot));
                     }
                     unsigned pk = pack_bf16x2(g0, g1);
@@ -471,7 +478,7 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
                             o.x = pack_bf16x2(acc_prev[4 * q], acc_prev[4 * q + 1]);
                             o.y = pack_bf16x2(acc_prev[4 * q + 2], acc_prev[4 * q + 3]);
                             *reinterpret_cast<uint2*>(feat + prow + T * 1024 + 256 * q) = o;
-                            const f32x4 w = *reinterpret_cast<const f32x4*>(w8lds + 32 * T + 8 * q + 4 * h);
+                            const f32x4 w = *(reinterpret_cast<const f32x4*>(pp.template slot<CP + 1>() + kTail) + (8 * T + 2 * q + h));
                             if constexpr (q == 0) sq_v7 = SS.template get<PG::s_tile0(7) + T>();
                             const unsigned sw = sq_v7[q];
                             const float v0 = w[0] * inv_scale * ubyte_f32(sw, 0), v1 = w[1] * inv_scale * ubyte_f32(sw, 1);
@@ -586,7 +593,7 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
 
 template <int MODE, bool SAVE, int NSLOT, int DEPTH, int VID = 0>
 int launch(const VdnSdfArgs* args, hipStream_t stream) {
-    constexpr size_t lds = MODE == 1 ? 160 * 1024 : NSLOT * kStride + 1024;
+    constexpr size_t lds = MODE == 1 ? 160 * 1024 : NSLOT * kStride;
     static bool once = (allow_big_lds(sdf_fwd2_kernel<MODE, SAVE, NSLOT, DEPTH, VID>, lds), true);
     (void)once;
     const int grid = (args->P + kWaves * 32 - 1) / (kWaves * 32);

@@ -1,3 +1,3 @@
-// bf16 instantiation of the background NeRF forward kernel - see k_nerf_fwd.h
-#include "k_nerf_fwd.h"
-extern "C" int vdn_nerf_mlp_fwd_bf16(const VdnNerfArgs* args, void* stream) { return vdn::launch_nerf_fwd<vdn::BF16>(args, stream); }
+// bf16 background NeRF forward: the flat-stream kernel - see k_nerf_fwd2.h
+#include "k_nerf_fwd2.h"
+extern "C" int vdn_nerf_mlp_fwd_bf16(const VdnNerfArgs* args, void* stream) { return vdn::launch_nerf_fwd2(args, stream); }

@@ -94,6 +94,10 @@ __global__ void build_images_kernel(const ChunkDesc* descs) {
             b[i] = bv;
         }
     }
+    if (d.tail != nullptr && d.write_bias) {
+        float* t = reinterpret_cast<float*>(d.dst + d.tail_off);
+        for (int i = threadIdx.x; i < d.tail_n; i += blockDim.x) t[i] = d.tail[i];
+    }
 }
 
 }  // namespace vdn

@@ -7,8 +7,8 @@ extern "C" int vdn_sdf_mlp_fwd_bf16(int mode, const VdnSdfArgs* args, void* stre
     if (args == nullptr || args->P <= 0 || args->blob == nullptr) return -1;
     if (args->pts == nullptr && (args->rays_o == nullptr || args->rays_d == nullptr || args->z == nullptr || args->n_per_ray <= 0 ||
                                  args->z_ld < args->n_per_ray || args->sdf_ld < args->n_per_ray)) return -2;
-    if (args->sdf == nullptr || args->w8row == nullptr) return -3;
-    if (mode == 0) return vdn::sdf2::launch<0, false, 3, 2>(args, stream);     // 61 KiB of LDS: two workgroups per CU
+    if (args->sdf == nullptr) return -3;
+    if (mode == 0) return vdn::sdf2::launch<0, false, 4, 3>(args, stream);     // 80 KiB of LDS: two workgroups per CU
     if (mode != 1) return -4;
     if (!args->feat || !args->normals) return -3;
     if (args->H != nullptr) {

@@ -47,13 +47,14 @@ class Layer:
     (matrix_name, use_bias, rowmap32) covering the whole contraction width, or a list of pieces
     (matrix_name, use_bias, rowmap32, kt_begin, kt_count) when its k-tiles come from several matrices."""
 
-    def __init__(self, kmap, chunks, scale=1.0, transposed=False, bias_scale=1.0):
+    def __init__(self, kmap, chunks, scale=1.0, transposed=False, bias_scale=1.0, tail=None):
         self.kmap = np.asarray(kmap, np.int32)
         assert len(self.kmap) % 32 == 0
         self.chunks = chunks
         self.scale = float(scale)
         self.bias_scale = float(bias_scale)
         self.transposed = transposed
+        self.tail = tail            # (matrix name, byte offset inside the chunk, floats): leading floats of that effective weight
 
     @property
     def kt(self):
@@ -176,6 +177,9 @@ class NetImages:
             ch[i]["k_pad"] = len(L.kmap)
             ch[i]["scale"] = L.scale
             ch[i]["bias_scale"] = L.bias_scale
+            if L.tail is not None:
+                tname, toff, tn = L.tail
+                ch[i]["tail"], ch[i]["tail_off"], ch[i]["tail_n"] = self.weff.data_ptr() + 4 * self.w_off[tname], toff, tn
             ch[i]["fmt"] = self.fmt
             ch[i]["kt_begin"], ch[i]["kt_count"], ch[i]["write_bias"] = kt0, ktc, int(first)
         self.wn_table = torch.from_numpy(wn.view(np.uint8)).to(self.device)
@@ -232,6 +236,7 @@ def refresh_together(images, stream, cache):
 # ---------------------------------------------------------------------------------------------
 
 SDF_UNIT = 100.0 * math.log2(math.e)      # the bf16 SDF kernel computes in units of 1 / (100 log2 e)  (csrc/k_sdf_fwd2.h)
+SDF_TAIL_OFF = 9 * 2048 + 1024            # first byte behind the widest (9 k-tile) chunk's bias block: 1 KiB free in the 20-KiB stride
 
 
 def sdf_streams(d_in, d_out, d_hidden, n_layers, skip_in, multires, scaled=False):
@@ -283,6 +288,11 @@ def sdf_streams(d_in, d_out, d_hidden, n_layers, skip_in, multires, scaled=False
     sweep = [transposed_layer(n, km, nm, sc * swsc) for (n, km, nm, sc) in reversed(fwd[0:8])]
     # adjoint of the forward pass: W8^T, W7^T .. W1^T
     fbar = [transposed_layer("lin8", ident_map(256), nm8)] + [transposed_layer(n, km, nm, sc) for (n, km, nm, sc) in reversed(fwd[1:8])]
+    if scaled:
+        # row 0 of W8 (f32, 256 values) rides in every chunk's unused tail, behind the widest chunk's bias block: the kernel
+        # reads it from whichever slot is current (the f32 sdf row, the sweep's first operand)
+        for L in hidden + [last_sdf, last_full] + sweep:
+            L.tail = ("lin8", SDF_TAIL_OFF, 256)
     return {"sdf": hidden + [last_sdf], "full": hidden + [last_full] + sweep, "fbar": fbar}
 
 
