@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_are_c_layouts():
-    assert ctypes.sizeof(lib.VdnChunkDesc) == 88 and lib.struct_dtype("VdnChunkDesc").itemsize == 88
+    assert ctypes.sizeof(lib.VdnChunkDesc) == 104 and lib.struct_dtype("VdnChunkDesc").itemsize == 104
     assert ctypes.sizeof(lib.VdnWeightNormDesc) == 40
 
 
