@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VDN_ABI_VERSION 7
+#define VDN_ABI_VERSION 8
 
 int vdn_abi_version(void);
 
@@ -360,15 +360,20 @@ typedef struct {
     int32_t P;
     int32_t m_tiles, n_tiles;             /* 32-wide column tiles of A (outputs) and B (inputs); n_tiles may be 0 */
     int32_t splits;
-    int32_t wg_begin;                     /* prefix sum of workgroups over the descriptor list */
+    int32_t wg_begin;                     /* prefix sum of vdn_dw_entry_wgs_*(m_tiles, n_tiles, splits) over the list */
     int32_t _pad;
     float* slab;                          /* [splits, m_tiles*32, n_tiles*32] partial products */
     float* colsum;                        /* [splits, m_tiles*32] partial column sums of A1, or NULL */
     const int32_t* P_dev;                 /* optional device scalar: contract over the first min(P, *P_dev) rows only */
 } VdnDwDesc;
 int vdn_dw_gemm_f32(const VdnDwDesc* descs_dev, int n_desc, int total_wgs, void* stream);
-/* bf16 variant: A/B are bf16 row-major; with two segments `splits` must be even (first half = segment 1). */
+/* bf16 variant: A/B are bf16 planes in the tile-blocked layout of the bf16 chains, rows padded to a multiple of 32 (the
+ * kernel reads whole 32-row blocks and zeroes the rows beyond P itself); with two segments `splits` must be even (first
+ * half = segment 1). One workgroup contracts one K split of a 256 x 256 output block. */
 int vdn_dw_gemm_bf16(const VdnDwDesc* descs_dev, int n_desc, int total_wgs, void* stream);
+/* workgroups one descriptor occupies in the launch (the two kernels tile differently); total_wgs = their sum */
+int vdn_dw_entry_wgs_f32(int m_tiles, int n_tiles, int splits);
+int vdn_dw_entry_wgs_bf16(int m_tiles, int n_tiles, int splits);
 
 /* reduce the K-splits and scatter from image coordinates to the parameter's own layout:
  * target[rmap[i]*t_stride + cmap[j]] (+)= scale * sum_s slab[s,i,j];  btarget[rmap[i]] (+)= bscale * sum_s colsum[s,i] */

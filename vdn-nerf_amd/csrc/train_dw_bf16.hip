@@ -1,180 +1,230 @@
 // Weight-gradient GEMM on gfx950 with bf16 MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulate):
 // dW[m,n] = sum over points of A[p,m] * B[p,n], A/B = bf16 activation planes in the tile-blocked PT32 layout
-// written by the backward chains (mlp_engine.h: points in blocks of 32; within a (block, 32-feature tile):
-// [q(4)][hh(2)][point(32)][e(4)], feature = 32*tile + 8q + 4hh + e).
+// written by the forward / backward chains (mlp_engine.h: points in blocks of 32; within a (block, 32-feature tile):
+// [fq(8)][point(32)][e(4)], feature = 32*tile + 4*fq + e - an 8-byte unit holds 4 consecutive features of one point).
 //
-// The contraction index (points) is the slow index of both operands, while an MFMA lane needs 8 k-values of ONE
-// feature. Loader: one wave-instruction reads 1 KiB contiguous = half a (block, tile): lane (q2, hh, cpair) gets
-// 2 points x 4 features; the same lane position in 4 consecutive blocks gives 8 points x 4 features, which a
-// 16-bit interleave turns into four ready MFMA fragments (k order = (block, point) - identical for A and B, so
-// the contraction is unchanged). Fragments go to LDS as [k-group(16)][feature(128)][16 B] (+16 B pad per group); k-group = cpair.
-// Workgroup = 4 waves = 128 x 128 outputs (wave: 2 x 2 tiles of 32 x 32); stage = 128 points = 8 k-steps; the
-// next stage's global loads are in flight (registers) while the current stage is multiplied out of LDS.
-// K is split across workgroups; partial slabs are reduced by vdn_dw_finalize (train_dw_f32.hip), deterministically.
+// The op is HBM-bound: 2*256*256 flop per 1 KiB of operand rows = 128 flop/B, i.e. ~0.8 PFLOP/s at the achievable
+// 6.3 TB/s - a third of the MFMA peak. So the kernel is built around reading every operand byte exactly once and doing
+// nothing else per byte:
+//  * one workgroup (8 waves) owns a K split of a whole 256 x 256 output block (waves 4(M) x 2(N), 64 x 128 each, 128
+//    accumulator registers): no second reader of any panel, no dependence on L2 hits;
+//  * planes go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, no registers, no VALU): a stage is one block of 32
+//    points x up to 16 feature tiles (32 KiB), NBUF stages form a ring with ONE barrier per stage;
+//  * the contraction index (points) is the slow index of both operands while an MFMA lane wants 8 k-values of one
+//    feature: ds_read_b64_tr_b16 does that transpose inside the LDS read. A DMA lane writes LDS at base + 16*lane but
+//    chooses its own global address, so the LDS image of a tile is re-ordered to [point pair(16)][fq(8)][2 points x 4
+//    features]: the 4 points x 32 features a half-wave's transposing read touches are then 256 contiguous bytes
+//    (conflict-free), and a lane's 16-byte global piece (one fq, two consecutive points) is still contiguous in PT32.
+//    The k order inside a fragment is the same for A and B, so the contraction is unchanged;
+//  * bias gradients (column sums of A) come from the matrix core too: one extra MFMA per m-tile against a fragment of
+//    ones instead of unpacking bf16 pairs on the VALU.
+// K splits are reduced by vdn_dw_finalize (train_dw_f32.hip), deterministically.
 #include "mlp_engine.h"
 #include "vdn_kernels.h"
 
 namespace vdn {
 
-constexpr int kDwStagePts = 128;
-// one operand: [16 k-groups][128 features][8 x bf16]; each k-group is padded by one 16-byte slot: a ds_write_b128 is
-// served in groups of 8 lanes = 8 consecutive k-groups, which at a 2 KiB stride would all hit the same banks
-constexpr int kDwGroupBytes = 128 * 16 + 16;
-constexpr int kDwPanelBytes = 16 * kDwGroupBytes;
+constexpr int kDwTileBytes = 2048;                 // 32 points x 32 features
+constexpr int kDwStageBytes = 16 * kDwTileBytes;   // 8 A tiles, then 8 B tiles
+constexpr int kDwBuf = 4;                          // stages in the ring (3 in flight while one is multiplied)
+constexpr int kDwWaves = 8;
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-__global__ __launch_bounds__(256, 2) void dw_gemm_bf16_kernel(const DwDesc* descs, int n_desc) {
+// the compiler cannot prove a pointer computed from a descriptor it looked up in a loop is wave-uniform: tell it
+VDN_DEV const char* dw_uniform(const char* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const char*)(((unsigned long long)hi << 32) | lo);
+}
+
+VDN_DEV void dw_glds16(const char* base_uniform, unsigned lane_off, unsigned lds_wave_base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" ::"v"(lane_off), "s"(lds_wave_base), "s"(base_uniform) : "memory");
+}
+
+// s_waitcnt vmcnt(n) with a wave-uniform runtime n (the immediate must be a constant)
+VDN_DEV void dw_wait_vm(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+// 8 k-values (points 8h .. 8h+7 of a 16-point k-step) of this lane's feature: two transposing reads of 4 points each
+VDN_DEV bf16x8 dw_frag(const lds_char* p) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 256));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+VDN_DEV int dw_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__global__ __launch_bounds__(512, 1) void dw_gemm_bf16_kernel(const DwDesc* descs, int n_desc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wg = blockIdx.x;
     int di = 0;
     while (di + 1 < n_desc && descs[di + 1].wg_begin <= wg) ++di;
-    const DwDesc d = descs[di];
-    const int local = wg - d.wg_begin;
-    const int mt4 = (d.m_tiles + 3) / 4, nt4 = max((d.n_tiles + 3) / 4, 1);
-    // XCD-aware mapping: workgroup ids are dealt round-robin over the 8 XCDs (observed; used for speed only), so
-    // the tiles of one K split - which read the same A/B panels - are given ids that are equal mod 8 and adjacent in
-    // time: the second reader finds the panel in that XCD's L2 instead of HBM. wg_begin is a multiple of 8.
-    const int ntile = mt4 * nt4;
-    const int slot = local & 7, round = local >> 3;
-    const int split = slot + 8 * (round / ntile);
-    const int tile = round % ntile;
-    if (split >= d.splits) return;
-    const int tm = tile / nt4, tn = tile % nt4;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    const DwDesc& d = descs[dw_uni(di)];
+    // everything that steers control flow is made explicitly wave-uniform (scalar registers, scalar branches): the
+    // transposing LDS reads need EXEC all ones, and the compiler cannot see that values loaded through the descriptor
+    // (and through P_dev) are the same in every lane
+    const int m_tiles = dw_uni(d.m_tiles), n_tiles = dw_uni(d.n_tiles), splits = dw_uni(d.splits);
+    const int local = wg - dw_uni(d.wg_begin);
+    const int mg = (m_tiles + 7) / 8, ng = max((n_tiles + 7) / 8, 1);
+    const int split = local / (mg * ng), blk = local % (mg * ng);
+    if (split >= splits) return;
+    const int tm = blk / ng, tn = blk % ng;
+    const int wave = dw_uni(threadIdx.x >> 6), lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = tm * 4 + wm * 2, n0 = tn * 4 + wn * 2;
-    const bool mv0 = m0 < d.m_tiles, mv1 = m0 + 1 < d.m_tiles;
-    const bool nv0 = n0 < d.n_tiles, nv1 = n0 + 1 < d.n_tiles;
+    // this block's tiles of the operands
+    const int a_t0 = tm * 8, b_t0 = tn * 8;
+    const int nA = min(8, m_tiles - a_t0), nB = max(0, min(8, n_tiles - b_t0));
     // segment / K range of this split: with two segments the first half of the splits covers segment 1
     const bool two = d.A2 != nullptr;
-    const int seg_splits = two ? d.splits / 2 : d.splits;
+    const int seg_splits = two ? splits / 2 : splits;
     const bool seg2 = two && split >= seg_splits;
     const int s_in = seg2 ? split - seg_splits : split;
-    const long P = d.P_dev != nullptr ? min((long)d.P, (long)*d.P_dev) : (long)d.P;
-    long per = (P + seg_splits - 1) / seg_splits;
-    per = (per + kDwStagePts - 1) / kDwStagePts * kDwStagePts;
-    const long k_begin = (long)s_in * per, k_end = min(k_begin + per, P);
-    const unsigned short* A = reinterpret_cast<const unsigned short*>(seg2 ? d.A2 : d.A1);
-    const unsigned short* Bm = reinterpret_cast<const unsigned short*>(seg2 ? d.B2 : d.B1);
-    const int lda = seg2 ? d.lda2 : d.lda1, ldb = seg2 ? d.ldb2 : d.ldb1;
+    int P = dw_uni(d.P);
+    if (d.P_dev != nullptr) P = min(P, dw_uni(*d.P_dev));
+    int per = (P + seg_splits - 1) / seg_splits;
+    per = (per + 127) / 128 * 128;
+    const int k_begin = s_in * per, k_end = min(k_begin + per, P);
+    const char* A = dw_uniform(reinterpret_cast<const char*>(seg2 ? d.A2 : d.A1));
+    const char* Bm = dw_uniform(reinterpret_cast<const char*>(seg2 ? d.B2 : d.B1));
+    const long lda = dw_uni(seg2 ? d.lda2 : d.lda1), ldb = dw_uni(seg2 ? d.ldb2 : d.ldb1);
+    const int n_stages = k_end > k_begin ? (k_end - k_begin + 31) >> 5 : 0;
+    float* slab = d.slab;
+    float* colsum = d.colsum;
 
-    // loader role: waves 0,1 -> operand A feature tiles {0,1},{2,3} of the 128-wide panel; waves 2,3 -> operand B
-    const bool load_b = wave >= 2;
-    const unsigned short* src = load_b ? Bm : A;
-    const int ld = load_b ? ldb : lda;
-    const int ntiles = load_b ? d.n_tiles : d.m_tiles;
-    const int panel_t0 = (load_b ? tn : tm) * 4;
-    const int q2 = lane >> 5, hh = (lane >> 4) & 1, cpair = lane & 15;
-    u32x4 regs[2][2][4];       // [tile-in-pair][Q][block]
-    auto load_stage = [&](long kbase) VDN_INL {
+    // ---- DMA: piece u = (tile u>>1, half u&1) of the stage, 1 KiB each; wave w moves pieces w, w+8, w+16, w+24
+    const int n_pieces = 2 * (nA + nB);
+    const int npw = (n_pieces - wave + kDwWaves - 1) / kDwWaves;             // pieces of this wave per stage (wave-uniform)
+    const unsigned lane_off = (lane & 7) * 256 + (lane >> 3) * 16;           // fq = lane&7, point pair = lane>>3
+    const unsigned lds0 = (unsigned)(size_t)(lds_char*)smem;
+    auto issue_stage = [&](int s) VDN_INL {
+        const long blk32 = (k_begin >> 5) + s;
+        const unsigned buf = lds0 + (s % kDwBuf) * kDwStageBytes;
 #pragma unroll
-        for (int tl = 0; tl < 2; ++tl) {
-            const int t = panel_t0 + (wave & 1) * 2 + tl;
-#pragma unroll
-            for (int Q = 0; Q < 2; ++Q) {
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const long p0 = kbase + 32 * b + 2 * cpair;        // this lane's two points
-                    u32x4 v = {0u, 0u, 0u, 0u};
-                    if (t < ntiles && p0 < k_end) {
-                        v = *reinterpret_cast<const u32x4*>(src + ((kbase >> 5) + b) * (32L * ld) + t * 1024 + (2 * Q + q2) * 256 + hh * 128 + cpair * 8);
-                        if (p0 + 1 >= k_end) { v[2] = 0u; v[3] = 0u; }   // second point beyond the range (padding rows hold garbage)
-                    }
-                    regs[tl][Q][b] = v;
-                }
+        for (int i = 0; i < 4; ++i) {
+            const int u = wave + i * kDwWaves;
+            if (u < n_pieces) {
+                const int t = u >> 1, half = u & 1;
+                const bool isA = t < nA;
+                const char* src = isA ? A + blk32 * (64 * lda) + (long)(a_t0 + t) * 2048
+                                      : Bm + blk32 * (64 * ldb) + (long)(b_t0 + t - nA) * 2048;
+                const int slot = isA ? t : 8 + (t - nA);
+                dw_glds16(src + half * 128, lane_off, buf + slot * kDwTileBytes + half * 1024);
             }
         }
     };
-    auto store_stage = [&]() VDN_INL {
-        char* panel = smem + (load_b ? kDwPanelBytes : 0);
+
+    // ---- fragment addressing: group g = lane>>4 (j = g&1: feature half, h = g>>1: k half), i = lane&15 = 4q'+p
+    const int gi = lane & 15, qp = gi >> 2, pp = gi & 3, jj = (lane >> 4) & 1;
+    const unsigned frag_off = (4 * jj + pp) * 16 + (qp & 1) * 8 + (4 * h + (qp >> 1)) * 128;
+    const lds_char* lbase = (lds_char*)smem + frag_off;
+
+    f32x16 acc[2][4];
+    f32x16 cs[2];
 #pragma unroll
-        for (int tl = 0; tl < 2; ++tl) {
+    for (int i = 0; i < 2; ++i) {
+        cs[i] = f32x16{0};
 #pragma unroll
-            for (int Q = 0; Q < 2; ++Q) {
-                // dwords of a load: d0 = (pt0: e0,e1) d1 = (pt0: e2,e3) d2 = (pt1: e0,e1) d3 = (pt1: e2,e3)
-                u32x4 f0, f1, f2, f3;
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const u32x4 v = regs[tl][Q][b];
-                    f0[b] = (v[0] & 0xFFFFu) | (v[2] << 16);
-                    f1[b] = (v[0] >> 16) | (v[2] & 0xFFFF0000u);
-                    f2[b] = (v[1] & 0xFFFFu) | (v[3] << 16);
-                    f3[b] = (v[1] >> 16) | (v[3] & 0xFFFF0000u);
-                }
-                const int fl = ((wave & 1) * 2 + tl) * 32 + (2 * Q + q2) * 8 + hh * 4;     // panel-local feature of e = 0
-                char* dst = panel + cpair * kDwGroupBytes + fl * 16;
-                *reinterpret_cast<u32x4*>(dst) = f0;
-                *reinterpret_cast<u32x4*>(dst + 16) = f1;
-                *reinterpret_cast<u32x4*>(dst + 32) = f2;
-                *reinterpret_cast<u32x4*>(dst + 48) = f3;
-            }
-        }
-    };
-    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
-    float cs0 = 0.0f, cs1 = 0.0f;
-    const bool do_colsum = d.colsum != nullptr && tn == 0 && wn == 0 && !seg2;
-    auto frag_sum = [](const bf16x8& f) VDN_INL {
-        const u32x4 u = __builtin_bit_cast(u32x4, f);
-        float s = 0.0f;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) s += bf16_lo(u[m]) + bf16_hi(u[m]);
-        return s;
-    };
-    const long n_stages = (k_end - k_begin + kDwStagePts - 1) / kDwStagePts;
-    if (n_stages > 0) load_stage(k_begin);
-    for (long t = 0; t < n_stages; ++t) {
-        __syncthreads();                         // previous stage fully consumed
-        store_stage();
-        __syncthreads();
-        if (t + 1 < n_stages) load_stage(k_begin + (t + 1) * kDwStagePts);
-        const char* pa = smem;
-        const char* pb = smem + kDwPanelBytes;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const int offa = (2 * ks + h) * kDwGroupBytes + (wm * 64 + c) * 16;
-            const int offb = (2 * ks + h) * kDwGroupBytes + (wn * 64 + c) * 16;
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(pa + offa);
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(pa + offa + 32 * 16);
-            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(pb + offb);
-            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(pb + offb + 32 * 16);
-            if (do_colsum) {
-                cs0 += frag_sum(a0);
-                cs1 += frag_sum(a1);
-            }
-            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc00, 0, 0, 0);
-            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc01, 0, 0, 0);
-            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc10, 0, 0, 0);
-            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc11, 0, 0, 0);
-        }
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x16{0};
     }
-    const int M = d.m_tiles * 32, N = d.n_tiles * 32;
-    auto put = [&](const f32x16& acc, int mt, int nt) VDN_INL {
-        float* base = d.slab + ((long)split * M + mt * 32) * N + nt * 32 + c;
+    const bool do_colsum = colsum != nullptr && tn == 0 && wn == 0 && !seg2;
+    // valid tiles of this wave (bit i: m-tile 2wm+i, bit j: n-tile 4wn+j)
+    const int mvm = (2 * wm < nA ? 1 : 0) | (2 * wm + 1 < nA ? 2 : 0);
+    const int nvm = (4 * wn < nB ? 1 : 0) | (4 * wn + 1 < nB ? 2 : 0) | (4 * wn + 2 < nB ? 4 : 0) | (4 * wn + 3 < nB ? 8 : 0);
+    const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+
+    // FULL: all 2 x 4 tiles of this wave exist (the common 256 x 256 block): no per-tile branches in the k-loop
+    auto run = [&](auto full_c) VDN_INL {
+        constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) base[(long)rho(t, h) * N] = acc[t];
+        for (int s = 0; s < kDwBuf - 1; ++s)
+            if (s < n_stages) issue_stage(s);
+        for (int s = 0; s < n_stages; ++s) {
+            // this wave's pieces of stage s have landed once at most the pieces of the stages issued after it are outstanding
+            const int later = min(n_stages - 1 - s, kDwBuf - 2);
+            dw_wait_vm(npw * later);
+            asm volatile("s_barrier" ::: "memory");   // everyone's pieces of stage s are in LDS; stage s-1 is fully consumed
+            if (s + kDwBuf - 1 < n_stages) issue_stage(s + kDwBuf - 1);       // into the buffer stage s-1 used
+            if (s == n_stages - 1 && (k_end & 31)) {
+                // the last block is partial: rows from k_end on hold whatever the producers' padding left there
+                const int valid = k_end & 31;
+                char* buf = smem + (s % kDwBuf) * kDwStageBytes;
+                for (int u = threadIdx.x; u < 16 * 256; u += 512) {          // 8-byte units: [tile][pair][fq][pt&1]
+                    const int pt = ((u >> 4) & 15) * 2 + (u & 1);
+                    if (pt >= valid) *reinterpret_cast<unsigned long long*>(buf + u * 8) = 0ull;
+                }
+                __syncthreads();
+            }
+            const lds_char* st = lbase + (s % kDwBuf) * kDwStageBytes;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 a[2], b[4];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    if (FULL || (mvm >> i & 1)) a[i] = dw_frag(st + (2 * wm + i) * kDwTileBytes + ks * 1024);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (FULL || (nvm >> j & 1)) b[j] = dw_frag(st + (8 + 4 * wn + j) * kDwTileBytes + ks * 1024);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (!FULL && !(mvm >> i & 1)) continue;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (FULL || (nvm >> j & 1)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    if (do_colsum) cs[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], ones, cs[i], 0, 0, 0);
+                }
+            }
+        }
     };
-    if (mv0 && nv0) put(acc00, m0, n0);
-    if (mv0 && nv1) put(acc01, m0, n0 + 1);
-    if (mv1 && nv0) put(acc10, m0 + 1, n0);
-    if (mv1 && nv1) put(acc11, m0 + 1, n0 + 1);
-    if (d.colsum != nullptr && tn == 0 && wn == 0) {
-        cs0 += __shfl_xor(cs0, 32);
-        cs1 += __shfl_xor(cs1, 32);
-        if (h == 0) {
-            if (mv0) d.colsum[(long)split * M + m0 * 32 + c] = cs0;      // zero for segment-2 splits
-            if (mv1) d.colsum[(long)split * M + (m0 + 1) * 32 + c] = cs1;
+    if (mvm == 3 && nvm == 15) run(std::true_type{});
+    else run(std::false_type{});
+
+    const int M = m_tiles * 32, N = n_tiles * 32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (!(mvm >> i & 1)) continue;
+        const int mt = a_t0 + 2 * wm + i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!(nvm >> j & 1)) continue;
+            float* base = slab + ((long)split * M + mt * 32) * N + (b_t0 + 4 * wn + j) * 32 + c;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) base[(long)rho(t, h) * N] = acc[i][j][t];
+        }
+        // every column of the ones-product holds the same sums: lane column 0 of each half writes its 16 rows
+        if (colsum != nullptr && tn == 0 && wn == 0 && c == 0) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) colsum[(long)split * M + mt * 32 + rho(t, h)] = cs[i][t];      // zero for segment-2 splits
         }
     }
 }
 
 }  // namespace vdn
 
+extern "C" int vdn_dw_entry_wgs_bf16(int m_tiles, int n_tiles, int splits) {
+    const int mg = (m_tiles + 7) / 8, ng = n_tiles > 0 ? (n_tiles + 7) / 8 : 1;
+    return splits * mg * ng;
+}
+
 extern "C" int vdn_dw_gemm_bf16(const VdnDwDesc* descs_dev, int n_desc, int total_wgs, void* stream) {
     using namespace vdn;
     if (!descs_dev || n_desc <= 0 || total_wgs <= 0) return -1;
-    static bool once = (allow_big_lds(dw_gemm_bf16_kernel, 2 * kDwPanelBytes), true);
+    static bool once = (allow_big_lds(dw_gemm_bf16_kernel, kDwBuf * kDwStageBytes), true);
     (void)once;
-    hipLaunchKernelGGL(dw_gemm_bf16_kernel, dim3(total_wgs), dim3(256), 2 * kDwPanelBytes, (hipStream_t)stream, descs_dev, n_desc);
+    hipLaunchKernelGGL(dw_gemm_bf16_kernel, dim3(total_wgs), dim3(512), kDwBuf * kDwStageBytes, (hipStream_t)stream, descs_dev, n_desc);
     return (int)hipGetLastError();
 }

@@ -23,8 +23,9 @@ __global__ __launch_bounds__(256, 2) void dw_gemm_f32_kernel(const DwDesc* descs
     const DwDesc d = descs[di];
     const int local = wg - d.wg_begin;
     const int mt4 = (d.m_tiles + 3) / 4, nt4 = max((d.n_tiles + 3) / 4, 1);
-    // same id space as the bf16 kernel (train_dw_bf16.hip): the tiles of one K split share an XCD (ids equal mod 8) and
-    // are adjacent in time, so the second reader of an operand panel finds it in that XCD's L2
+    // XCD-aware id space: workgroup ids are dealt round-robin over the 8 XCDs (observed; used for speed only), so the
+    // tiles of one K split - which read the same A/B panels - get ids that are equal mod 8 and adjacent in time: the
+    // second reader of an operand panel finds it in that XCD's L2. wg_begin is a multiple of 8 (vdn_dw_entry_wgs_f32).
     const int ntile = mt4 * nt4;
     const int slot = local & 7, round = local >> 3;
     const int split = slot + 8 * (round / ntile);
@@ -178,6 +179,11 @@ __global__ void weightnorm_bwd_kernel(const WeightNormBwdDesc* descs) {
 }
 
 }  // namespace vdn
+
+extern "C" int vdn_dw_entry_wgs_f32(int m_tiles, int n_tiles, int splits) {
+    const int mt4 = (m_tiles + 3) / 4, nt4 = n_tiles > 0 ? (n_tiles + 3) / 4 : 1;
+    return 8 * ((splits + 7) / 8) * mt4 * nt4;          // a multiple of 8: see the id space in dw_gemm_f32_kernel
+}
 
 extern "C" int vdn_dw_gemm_f32(const VdnDwDesc* descs_dev, int n_desc, int total_wgs, void* stream) {
     if (!descs_dev || n_desc <= 0 || total_wgs <= 0) return -1;

@@ -107,6 +107,11 @@ def call(fn_name, *args):
         raise VdnError("%s failed with status %d (%s)" % (fn_name, rc, "argument error" if rc < 0 else "hipError_t"))
 
 
+def call_value(fn_name, *args):
+    """Invoke an entry point whose int return is a value, not a status (vdn_abi_version, vdn_dw_entry_wgs_*)."""
+    return int(getattr(load(), fn_name)(*args))
+
+
 def ptr(t):
     """Device pointer of a torch tensor (or None)."""
     return None if t is None else ctypes.c_void_p(t.data_ptr())

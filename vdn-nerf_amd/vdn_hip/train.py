@@ -231,8 +231,7 @@ class TrainEngine:
                 moff += nt * 32
             slab_elems += splits * mt * 32 * nt * 32
             cs_elems += splits * mt * 32
-            ntile = ((mt + 3) // 4) * max((nt + 3) // 4, 1)
-            wg += 8 * ((splits + 7) // 8) * ntile          # XCD-aware id space (see train_dw_bf16.hip)
+            wg += lib.call_value("vdn_dw_entry_wgs" + self.sfx, mt, nt, splits)
         self.dw_total_wgs = wg
         self.maps = torch.from_numpy(np.concatenate(all_maps)).to(dev)
         self.slab = torch.empty(max(slab_elems, 1), dtype=torch.float32, device=dev)
