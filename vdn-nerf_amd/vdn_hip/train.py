@@ -15,7 +15,7 @@ import torch
 
 from . import images, layout, lib
 
-PTS_PER_SPLIT = 4096
+PTS_PER_SPLIT = int(os.environ.get("VDN_DW_SPLIT_PTS", "4096"))        # rows one workgroup of the weight-gradient GEMM contracts
 
 
 def _stream():
@@ -218,9 +218,14 @@ class TrainEngine:
         for i, e in enumerate(ent):
             mt = len(e["rmap"]) // 32
             nt = 0 if e["cmap"] is None else len(e["cmap"]) // 32
-            K = e["Pn"] * (2 if e.get("A2") is not None else 1)
+            # K splits are sized on the static row counts (the work lists shrink them at run time: ~2.3 K foreground and
+            # ~3.4 K background rows per workgroup on the bench scene). Measured alternatives: equal BYTES per workgroup
+            # (long row ranges for narrow operands) is 15-40 % slower - a stage of a narrow entry is latency-, not
+            # bandwidth-bound - and 2048 / 8192 rows per split are 10 % slower (more slab traffic / a coarser tail).
+            segs = 2 if e.get("A2") is not None else 1
+            K = e["Pn"] * segs
             splits = max(1, (K + PTS_PER_SPLIT - 1) // PTS_PER_SPLIT)
-            if e.get("A2") is not None:
+            if segs == 2:
                 splits += splits % 2          # first half of the splits = segment 1, second half = segment 2
             lay.append((mt, nt, splits, slab_elems, cs_elems, moff, wg))
             all_maps.append(np.asarray(e["rmap"], np.int32))
