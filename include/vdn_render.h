@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VDN_ABI_VERSION 8
+#define VDN_ABI_VERSION 9
 
 int vdn_abi_version(void);
 
@@ -95,6 +95,10 @@ typedef struct {
      * are addressed by the dense point id, training saves and deltas by the compact row */
     const int32_t* active_idx;
     const int32_t* n_active;
+    /* optional (mode 1): d sdf / d(encoded input) in the network's own units, the 39 values u with
+     * normal = scale * J_PE(x)^T u (fields.py:97-108) - what the ray adjoint needs for the explicit x-dependence of
+     * J_PE (learnable poses, poses.py:198-208). Rows follow the saves (compact with a work list). */
+    float* U_pe;               /* [P,39] or NULL */
 } VdnSdfArgs;
 int vdn_sdf_mlp_fwd_f32(int mode, const VdnSdfArgs* args_host, void* stream);
 /* bf16-MFMA variant (csrc/k_sdf_fwd2.h): blob holds bf16 chunks (fmt 1) of the SCALED streams (vdn_hip/images.py:
@@ -275,13 +279,20 @@ typedef struct {
      * are addressed by the dense point id, training saves and deltas by the compact row */
     const int32_t* active_idx;
     const int32_t* n_active;
+    /* optional input adjoints for differentiable rays (poses.py:198-208): d loss / d points and d loss / d view_dirs
+     * (through the 4-octave encoding). dirs / rays_d as in VdnRenderNetArgs (dirs [P,3] or rays_d [B,3] with n_per_ray). */
+    const float* dirs; const float* rays_d;
+    int32_t n_per_ray;
+    int32_t acc_pts;           /* 0: overwrite d_pts / d_dirs, 1: add into them */
+    float* d_pts;              /* [P,3] dense point id, or NULL */
+    float* d_dirs;             /* [P,3] or NULL */
 } VdnRenderNetBwdArgs;
 int vdn_rendernet_bwd_f32(const VdnRenderNetBwdArgs* args_host, void* stream);
 int vdn_rendernet_bwd_bf16(const VdnRenderNetBwdArgs* args_host, void* stream);   /* bf16-MFMA variant: bf16 chunk blob, bf16 activation workspaces */
 
 /* backward of the background NeRF (fields.py:324-353). */
 typedef struct {
-    const char* blob;          /* 'bwd' stream: Wout^T, Wviews^T, Whead^T, W7^T .. W1^T */
+    const char* blob;          /* 'bwd' stream: Wout^T, Wviews^T, Whead^T, W7^T .. W1^T, W0^T (the last only read with d_pts) */
     const float* g_density;    /* [P] */
     const float* g_rgb;        /* [P,3] */
     const float* g_feat;       /* [P,96] or NULL */
@@ -295,6 +306,13 @@ typedef struct {
     /* as in VdnNerfArgs: g_* are read at the dense positions, saves and deltas are in compact order */
     const int32_t* active_idx;
     const int32_t* n_active;
+    /* optional input adjoints for differentiable rays: with d_pts, the kernel also runs W0^T and maps the adjoints of
+     * the two encodings back through pts4 = [p / r, 1 / r], r = clip(|p|, 1, 1e10) (renderer.py:112-115) to
+     * d loss / d p and d loss / d view_dir. The points are regenerated from the rays as in VdnNerfArgs. */
+    const float* rays_o; const float* rays_d; const float* z;
+    int32_t n_per_ray;
+    float* d_pts;              /* [P,3] dense point id (rows off the work list are not written), or NULL */
+    float* d_dirs;             /* [P,3] (required with d_pts) */
 } VdnNerfBwdArgs;
 int vdn_nerf_mlp_bwd_f32(const VdnNerfBwdArgs* args_host, void* stream);
 int vdn_nerf_mlp_bwd_bf16(const VdnNerfBwdArgs* args_host, void* stream);   /* bf16-MFMA variant: bf16 chunk blob, bf16 activation workspaces */
@@ -333,7 +351,7 @@ int vdn_sdf_bwd_rbar_f32(const VdnSdfRbarArgs* args_host, void* stream);
 int vdn_sdf_bwd_rbar_bf16(const VdnSdfRbarArgs* args_host, void* stream);   /* bf16-MFMA variant: bf16 chunk blob, bf16 activation workspaces */
 
 typedef struct {
-    const char* blob;          /* 'fbar' stream: W8^T, W7^T .. W1^T */
+    const char* blob;          /* 'fbar' stream: W8^T, W7^T .. W1^T, W0^T (the last only read with d_pts) */
     const float* g_sdf;        /* [P] */
     const void* g_feat;       /* [P,256] */
     const void* S;            /* [8,P,256] softplus' planes, or - with s_from_h - the saved activations H */
@@ -346,6 +364,15 @@ typedef struct {
      * are addressed by the dense point id, training saves and deltas by the compact row */
     const int32_t* active_idx;
     const int32_t* n_active;
+    /* optional input adjoint for differentiable rays: d loss / d point through sdf, feature and normal
+     * (incl. the explicit x-dependence of the encoding's Jacobian in normal = scale J_PE(x)^T u). Needs the points
+     * (pts, or rays + z as in VdnSdfArgs), the upstream g_normals of rbar and U_pe saved by the forward. */
+    const float* pts; const float* rays_o; const float* rays_d; const float* z;
+    int32_t n_per_ray, z_ld;
+    const float* g_normals;    /* [P,3] */
+    const float* U_pe;         /* [P,39] */
+    int32_t acc_pts;           /* 0: overwrite d_pts, 1: add into it */
+    float* d_pts;              /* [P,3] dense point id, or NULL */
 } VdnSdfFbarArgs;
 int vdn_sdf_bwd_fbar_f32(const VdnSdfFbarArgs* args_host, void* stream);
 int vdn_sdf_bwd_fbar_bf16(const VdnSdfFbarArgs* args_host, void* stream);   /* bf16-MFMA variant: bf16 chunk blob, bf16 activation workspaces */
@@ -425,8 +452,38 @@ typedef struct {
     float* d_bg_feat;          /* [B*T,C] or NULL */
     float* d_var_partial;      /* [B] per-ray d loss / d variance */
     float* d_variance;         /* [1] */
+    /* optional, for differentiable rays (all three or none): adjoints of the section lengths and of the ray direction
+     * inside true_cos = rays_d . normal (renderer.py:265) */
+    float* d_dists;            /* [B,N] */
+    float* d_bg_dists;         /* [B,T] (NULL without a background) */
+    float* d_dir_cos;          /* [B,3] */
 } VdnCompositeBwdArgs;
 int vdn_alpha_composite_bwd(const VdnCompositeBwdArgs* args_host, void* stream);
+
+/* ---- adjoint of the ray geometry of render_core / render_core_outside (renderer.py:107-115, 228-237): collects the
+ * per-point input adjoints of the networks and the section-length adjoints of the compositor into
+ * d loss / d rays_o, d rays_d and d loss / d z (inside samples) / d z_out (outside samples), for learnable poses
+ * (poses.py:198-208). Geometry: pts = o + d * mid_z, dirs = d; inside: dists_i = z_{i+1} - z_i (last = sample_dist),
+ * mid_i = z_i + dists_i / 2; background the same over z_feed = [z | z_out] (every outside sample lies beyond the inside
+ * ones, renderer.py:359). One wave per ray. */
+typedef struct {
+    const float* rays_d;       /* [B,3] */
+    const float* mid_z;        /* [B,N] */
+    const float* bg_mid;       /* [B,T] or NULL */
+    const float* d_pts;        /* [B*N,3] inside points */
+    const float* d_dirs;       /* [B*N,3] */
+    const float* d_dists;      /* [B,N] */
+    const float* d_dir_cos;    /* [B,3] */
+    const float* d_bg_pts;     /* [B*T,3] or NULL */
+    const float* d_bg_dirs;    /* [B*T,3] */
+    const float* d_bg_dists;   /* [B,T] */
+    int32_t B, N, T;
+    float* d_rays_o;           /* [B,3] */
+    float* d_rays_d;           /* [B,3] */
+    float* d_z;                /* [B,N] */
+    float* d_z_out;            /* [B,T-N] or NULL */
+} VdnRayAdjointArgs;
+int vdn_ray_adjoint(const VdnRayAdjointArgs* args_host, void* stream);
 
 /* ---- caller semantics of dpt_runner.py:208-243 fused into one launch: loss terms + d loss / d outputs.
  * loss = L1(color)/mask_sum + igr*eik + mask_w*BCE(clip(weight_sum)) + depth_w*L1(feats)/mask_sum.

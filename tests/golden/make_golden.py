@@ -319,6 +319,61 @@ def adam_fixture(fields, renderer, seed=5, B=12, steps=3):
     return fx
 
 
+def raygrad_fixture(fields, renderer):
+    """d loss / d (rays_o, rays_d, near, far) by the REFERENCE's autograd, the way a learnable-pose run differentiates
+    (poses.py:198-208 hands over rays with a graph; dpt_runner.py:201-217 derives near / far from them and calls render):
+    the four inputs are leaves here, so each partial is pinned separately. Two cases: 64 coarse samples only (every depth
+    depends on near / far) and the full 64 + 64 sampler (the reference's own inside depths are stored for injection).
+    Plus known answers of the so(3) helpers the pose modules use (lie_group_helper.py:47-83)."""
+    from vdn_train import synth
+    import importlib.util
+    fx = {}
+    for tag, seed, B, n_imp, cos_anneal in (("n64", 8, 16, 0, 0.3), ("full", 2, 16, 64, 0.5)):
+        torch.set_default_dtype(torch.float32)
+        states = synth.make_all_states(seed, wdepth=False, variance=0.3)
+        rend = build_reference(fields, renderer, states, False, torch.float32, n_importance=n_imp)
+        o, d, near, far = make_rays(seed, B)
+        t_rand, t_rand_out = synth.jitter(seed, 0, B)
+        tt = lambda x: torch.tensor(x, dtype=torch.float32)
+        leaves = [tt(x).requires_grad_(True) for x in (o, d, near, far)]
+        captured = {}
+        orig_core = rend.render_core
+
+        def spy_core(rays_o_, rays_d_, z_vals_, *a, **k):
+            captured["z"] = z_vals_.detach().clone()
+            return orig_core(rays_o_, rays_d_, z_vals_, *a, **k)
+        rend.render_core = spy_core
+        with RandQueue([tt(t_rand), tt(t_rand_out)]):
+            out = rend.render(leaves[0], leaves[1], leaves[2], leaves[3], perturb_overwrite=-1,
+                              background_rgb=torch.ones(1, 3), cos_anneal_ratio=cos_anneal)
+        true_rgb = tt(synth.target_colors(o, d))
+        mask_sum = B + 1e-5
+        loss = (out["color_fine"] - true_rgb).abs().sum() / mask_sum + out["gradient_error"] * 0.1
+        # (with importance sampling `near` is not part of the graph: the inside depths leave a no_grad block, renderer.py:367-386)
+        grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+        fx["%s/near_in_graph" % tag] = int(grads[2] is not None)
+        grads = [torch.zeros_like(x) if gr is None else gr for x, gr in zip(leaves, grads)]
+        for k, v in (("seed", seed), ("B", B), ("n_importance", n_imp), ("cos_anneal", cos_anneal), ("rays_o", o), ("rays_d", d),
+                     ("near", near), ("far", far), ("t_rand", t_rand), ("t_rand_out", t_rand_out), ("true_rgb", true_rgb.numpy()),
+                     ("loss", loss.item()), ("z_vals_inside", captured["z"].numpy()), ("color_fine", out["color_fine"].detach().numpy())):
+            fx["%s/%s" % (tag, k)] = v
+        for nm, gr in zip(("rays_o", "rays_d", "near", "far"), grads):
+            fx["%s/grad_%s" % (tag, nm)] = gr.numpy()
+        print("[raygrad %s] loss %.6f  |d rays_o| %.3e  |d rays_d| %.3e  |d near| %.3e  |d far| %.3e" %
+              ((tag, loss.item()) + tuple(float(gr.abs().max()) for gr in grads)))
+    spec = importlib.util.spec_from_file_location("ref_lie_group_helper", os.path.join(REFERENCE, "dpt_models", "lie_group_helper.py"))
+    lg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lg)
+    assert os.path.realpath(lg.__file__).startswith(REFERENCE + os.sep)
+    rs = (synth.uniform(11, "pose/r", (6, 3)) * 2.0 - 1.0).astype(np.float32)
+    rs[0] = 0.0                                     # the regularised zero rotation (|r| + 1e-15)
+    rs[1] *= 1e-4
+    ts = (synth.uniform(11, "pose/t", (6, 3)) * 2.0 - 1.0).astype(np.float32)
+    fx["pose/r"], fx["pose/t"] = rs, ts
+    fx["pose/c2w"] = np.stack([lg.make_c2w(torch.tensor(r), torch.tensor(t)).numpy() for r, t in zip(rs, ts)])
+    return fx
+
+
 CASES = [
     # name, seed, B, wdepth, variance, cos_anneal, perturb, kwargs
     ("white_v03_c0", 1, 24, False, 0.3, 0.0, 1.0, {}),
@@ -351,6 +406,8 @@ def generate(only=None):
             out[name + "_f64"] = keep
     if want("adam3"):
         out["adam3"] = adam_fixture(fields, renderer)
+    if want("raygrad"):
+        out["raygrad"] = raygrad_fixture(fields, renderer)
     return out
 
 

@@ -33,7 +33,7 @@ def test_generator_imports_the_reference_not_this_repo():
 def test_committed_fixtures_are_the_references_outputs():
     # `stages` holds every per-stage vector (PE, SDF 257-vector, normals, heads, NeRF, sample_pdf rows, lattice);
     # one render case covers the end-to-end dict. The full set takes minutes: `make_golden.py --check-only`.
-    r = subprocess.run([sys.executable, GEN, "--check-only", "--only", "stages,black_v03"],
+    r = subprocess.run([sys.executable, GEN, "--check-only", "--only", "stages,black_v03,raygrad"],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     assert "all bit-identical" in r.stdout

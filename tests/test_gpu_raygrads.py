@@ -1,0 +1,185 @@
+"""Differentiable rays (learnable poses, reference poses.py:198-208 + dpt_runner.py:201-217): d loss / d rays_o, rays_d, near,
+far through NeuSRenderer.render - the hand-written ray adjoint (vdn_ray_adjoint + the networks' input adjoints) - against
+the fp64 oracle's autograd on the same inputs and the reference's own autograd (tests/golden/raygrad.npz). The reference's
+graph: the outside depths depend on far (renderer.py:359); the inside depths depend on (near, far) only when there is no
+importance sampling - otherwise they leave a no_grad block as constants (367-386) and d loss / d near is zero."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_grads import _loss, g
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(fx, dtype=torch.float64):
+    import oracle.neus_oracle as orc
+    from vdn_train import synth
+    wdepth = bool(fx["wdepth"])
+    st = synth.make_all_states(int(fx["seed"]), wdepth=wdepth, variance=float(fx["variance"]))
+    nets = orc.nets_from_numpy(st, dtype=dtype, requires_grad=False)
+    tt = lambda x: torch.tensor(np.asarray(x), dtype=dtype)
+    leaves = [tt(fx[k]).requires_grad_(True) for k in ("rays_o", "rays_d", "near", "far")]
+    o, d, near, far = leaves
+    conf = orc.RendererConf(n_importance=int(fx["n_importance"]))
+    perturb = -1 if fx["perturb"] > 0 else 0
+    # with importance sampling the reference's inside depths come out of a no_grad block (renderer.py:367-386): constants
+    z_inj = tt(fx["z_vals_inside"]) if fx["n_importance"] > 0 else None
+    out = orc.render(nets, o, d, near, far, conf, perturb_overwrite=perturb,
+                     background_rgb=torch.ones(1, 3, dtype=dtype) if fx["white"] else None,
+                     cos_anneal_ratio=float(fx["cos_anneal"]), t_rand=tt(fx["t_rand"]), t_rand_out=tt(fx["t_rand_out"]), z_vals_inject=z_inj)
+    loss = _loss(out, tt(fx["true_rgb"]), tt(fx["gt_feats"]) if wdepth else None, wdepth)
+    grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+    return loss.item(), [torch.zeros_like(x) if gr is None else gr.detach() for x, gr in zip(leaves, grads)]
+
+
+def _gpu(fx, dev, precision="fp32", param_grads=True):
+    from vdn_train import synth, factory
+    wdepth = bool(fx["wdepth"])
+    st = synth.make_all_states(int(fx["seed"]), wdepth=wdepth, variance=float(fx["variance"]))
+    rend = factory.build_renderer(wdepth=wdepth, device=dev, states=st, n_importance=int(fx["n_importance"]), precision=precision)
+    if not param_grads:
+        for p in rend._all_parameters():
+            p.requires_grad_(False)
+    leaves = [g(fx[k], dev).requires_grad_(True) for k in ("rays_o", "rays_d", "near", "far")]
+    o, d, near, far = leaves
+    out = rend.render(o, d, near, far, perturb_overwrite=(-1 if fx["perturb"] > 0 else 0),
+                      background_rgb=torch.ones(1, 3, device=dev) if fx["white"] else None,
+                      cos_anneal_ratio=float(fx["cos_anneal"]), t_rand=g(fx["t_rand"], dev), t_rand_out=g(fx["t_rand_out"], dev),
+                      z_vals_inject=g(fx["z_vals_inside"], dev) if fx["n_importance"] > 0 else None)
+    loss = _loss(out, g(fx["true_rgb"], dev), g(fx["gt_feats"], dev) if wdepth else None, wdepth)
+    loss.backward()
+    return loss.item(), [(torch.zeros_like(x) if x.grad is None else x.grad).detach().cpu().double() for x in leaves], rend
+
+
+@pytest.mark.parametrize("name,param_grads", [("white_n64_v03", True), ("white_v03_c05_det", True), ("white_v03_c0", False), ("wdepth_v03_c05", True)])
+def test_ray_gradients_vs_oracle_fp64(golden, name, param_grads):
+    fx = golden(name)
+    dev = torch.device("cuda:0")
+    loss_o, ref = _oracle(fx)
+    _, ref32 = _oracle(fx, torch.float32)          # what an fp32 autograd reaches: the floor for cancellation-dominated entries
+    loss_g, got, _ = _gpu(fx, dev, param_grads=param_grads)
+    assert abs(loss_g - loss_o) <= 2e-4 * abs(loss_o)
+    report, bad = [], []
+    for nm, a, b, b32 in zip(("rays_o", "rays_d", "near", "far"), got, ref, ref32):
+        scale = b.abs().max().item()
+        err = (a - b).abs().max().item() / (scale + 1e-30)
+        floor = (b32.double() - b).abs().max().item() / (scale + 1e-30)
+        report.append("%s: rel-to-max err %.2e, fp32-autograd floor %.2e (|g|max %.2e)" % (nm, err, floor, scale))
+        if err > max(1e-3, 3 * floor):
+            bad.append(nm)
+    print("\n".join(report))
+    assert not bad, "\n".join(report)
+
+
+def test_ray_gradients_bf16_and_parameter_gradients_unchanged(golden):
+    """The throughput path produces the same ray gradients to bf16 accuracy, and asking for them does not change the
+    parameter gradients (same kernels, the adjoint outputs are extra stores)."""
+    fx = golden("white_v03_c05_det")
+    dev = torch.device("cuda:0")
+    _, ref = _oracle(fx)
+    _, got, rend = _gpu(fx, dev, precision="bf16")
+    rels = {nm: (a - b).norm().item() / (b.norm().item() + 1e-30) for nm, a, b in zip(("rays_o", "rays_d", "near", "far"), got, ref)}
+    print(rels)
+    # near / far gradients are sums over the coarse depths' adjoints with heavy cancellation (|g| ~ 1e-3 against terms ~ 1e-1)
+    assert rels["rays_o"] < 5e-2 and rels["rays_d"] < 5e-2 and rels["near"] < 0.5 and rels["far"] < 0.5, rels
+    with_rays = [p.grad.clone() for p in rend._all_parameters()]
+    from test_gpu_grads import _gpu_grads
+    _, named, _ = _gpu_grads(fx, dev, precision="bf16")
+    for a, (n, p) in zip(with_rays, named):
+        assert torch.equal(a, p.grad), n
+
+
+def test_learnpose_gradients_reach_the_pose_parameters():
+    """dpt_runner.py:197-217 with a learnable camera: LearnPose -> rays (poses.py:198-208) -> near_far_from_sphere
+    (dataset.py:111-118) -> render -> loss; d loss / d (r, t) against the same chain on the fp64 oracle."""
+    import oracle.neus_oracle as orc
+    from dpt_models.poses import LearnPose, LearnIntrin
+    from dpt_models import lie_group_helper as lg
+    from vdn_train import synth, factory
+    dev = torch.device("cuda:0")
+    seed, B = 2, 24
+    cams = synth.make_cameras(seed)
+    c2w0 = torch.tensor(np.asarray(cams[:3], np.float32))
+    H, W, focal = synth.H, synth.W_IMG, 1111.0
+    px = torch.tensor(np.floor(synth.uniform(seed, "lp/x", (B,)) * 400 + 200).astype(np.float32))
+    py = torch.tensor(np.floor(synth.uniform(seed, "lp/y", (B,)) * 400 + 200).astype(np.float32))
+    r0 = torch.tensor(synth.uniform(seed, "lp/r", (3, 3)).astype(np.float32) * 0.02 - 0.01)
+    t0 = torch.tensor(synth.uniform(seed, "lp/t", (3, 3)).astype(np.float32) * 0.02 - 0.01)
+    true_rgb = synth.uniform(seed, "lp/rgb", (B, 3)).astype(np.float32)
+    cam = 1
+
+    def rays_from(pose, K, dtype):
+        p = torch.stack([px, py, torch.ones_like(py)], dim=-1).to(dtype).to(pose.device)
+        p = torch.matmul(torch.inverse(K)[None, :3, :3], p[:, :, None]).squeeze(-1)
+        v = p / torch.linalg.norm(p, ord=2, dim=-1, keepdim=True)
+        v = torch.matmul(pose[None, :3, :3], v[:, :, None]).squeeze(-1)
+        return pose[None, :3, 3].expand(v.shape), v
+
+    # ---- MI355X: the package's modules
+    pose_net = LearnPose(3, True, True, init_c2w=c2w0.clone()).to(dev)
+    with torch.no_grad():
+        pose_net.r.copy_(r0.to(dev)); pose_net.t.copy_(t0.to(dev))
+    intrin = LearnIntrin(H, W, req_grad=False, order=2, init_focal=torch.tensor(focal)).to(dev)
+    st = synth.make_all_states(seed, wdepth=False, variance=0.3)
+    rend = factory.build_renderer(wdepth=False, device=dev, states=st, n_importance=0)
+    ro, rv = rays_from(pose_net(cam), intrin(), torch.float32)
+    a = torch.sum(rv ** 2, dim=-1, keepdim=True); b = 2.0 * torch.sum(ro * rv, dim=-1, keepdim=True)
+    mid = 0.5 * (-b) / a
+    out = rend.render(ro, rv, mid - 1.0, mid + 1.0, perturb_overwrite=0, background_rgb=torch.ones(1, 3, device=dev), cos_anneal_ratio=0.5)
+    loss = _loss(out, g(true_rgb, dev), None, False)
+    loss.backward()
+    got = [pose_net.r.grad[cam].cpu().double(), pose_net.t.grad[cam].cpu().double()]
+    assert pose_net.r.grad[0].abs().max() == 0 and pose_net.t.grad[2].abs().max() == 0      # other cameras untouched
+
+    # ---- fp64 oracle with the same chain
+    dt = torch.float64
+    r = r0.to(dt).clone().requires_grad_(True)
+    t = t0.to(dt).clone().requires_grad_(True)
+    K = intrin().cpu().to(dt)
+
+    def exp64(rv_):
+        zero = torch.zeros(1, dtype=dt)
+        Kx = torch.stack([torch.cat([zero, -rv_[2:3], rv_[1:2]]), torch.cat([rv_[2:3], zero, -rv_[0:1]]), torch.cat([-rv_[1:2], rv_[0:1], zero])])
+        n = rv_.norm() + 1e-15
+        return torch.eye(3, dtype=dt) + (torch.sin(n) / n) * Kx + ((1 - torch.cos(n)) / n ** 2) * (Kx @ Kx)
+    c2w = torch.cat([torch.cat([exp64(r[cam]), t[cam].unsqueeze(1)], dim=1), torch.tensor([[0.0, 0.0, 0.0, 1.0]], dtype=dt)], dim=0) @ c2w0[cam].to(dt)
+    ro64, rv64 = rays_from(c2w, K, dt)
+    near64, far64 = orc.near_far_from_sphere(ro64, rv64)
+    nets = orc.nets_from_numpy(st, dtype=dt, requires_grad=False)
+    oo = orc.render(nets, ro64, rv64, near64, far64, orc.RendererConf(n_importance=0), perturb_overwrite=0,
+                    background_rgb=torch.ones(1, 3, dtype=dt), cos_anneal_ratio=0.5)
+    lo = _loss(oo, torch.tensor(true_rgb, dtype=dt), None, False)
+    gr, gt = torch.autograd.grad(lo, [r, t])
+    assert abs(loss.item() - lo.item()) <= 2e-4 * abs(lo.item())
+    for nm, a_, b_ in (("r", got[0], gr[cam]), ("t", got[1], gt[cam])):
+        rel = (a_ - b_).abs().max().item() / (b_.abs().max().item() + 1e-30)
+        assert rel < 2e-3, (nm, rel, a_, b_)
+    # the rotation helper itself against its fp64 restatement
+    assert (lg.Exp(r0[1]).double() - exp64(r0[1].to(dt))).abs().max() < 1e-6
+
+
+@pytest.mark.parametrize("tag", ["n64", "full"])
+def test_ray_gradients_vs_reference_autograd(golden, tag):
+    """tests/golden/raygrad.npz: the reference's own d loss / d (rays_o, rays_d, near, far) (make_golden.py: raygrad_fixture).
+    Both sides are fp32; near / far gradients are cancellation-dominated sums (their fp32 floor is ~5e-3 of the largest entry)."""
+    from vdn_train import synth, factory
+    fx = {k.split("/", 1)[1]: v for k, v in golden("raygrad").items() if k.startswith(tag + "/")}
+    dev = torch.device("cuda:0")
+    st = synth.make_all_states(int(fx["seed"]), wdepth=False, variance=0.3)
+    rend = factory.build_renderer(wdepth=False, device=dev, states=st, n_importance=int(fx["n_importance"]))
+    leaves = [g(fx[k], dev).requires_grad_(True) for k in ("rays_o", "rays_d", "near", "far")]
+    out = rend.render(*leaves, perturb_overwrite=-1, background_rgb=torch.ones(1, 3, device=dev), cos_anneal_ratio=float(fx["cos_anneal"]),
+                      t_rand=g(fx["t_rand"], dev), t_rand_out=g(fx["t_rand_out"], dev),
+                      z_vals_inject=g(fx["z_vals_inside"], dev) if fx["n_importance"] > 0 else None)
+    assert np.abs(out["color_fine"].detach().cpu().numpy() - fx["color_fine"]).max() < 2e-4
+    loss = _loss(out, g(fx["true_rgb"], dev), None, False)
+    assert abs(loss.item() - float(fx["loss"])) <= 2e-4 * abs(float(fx["loss"]))
+    loss.backward()
+    if not int(fx["near_in_graph"]):
+        assert leaves[2].grad is None or leaves[2].grad.abs().max().item() == 0.0
+    for nm, x, tol in (("rays_o", leaves[0], 1e-3), ("rays_d", leaves[1], 1e-3), ("near", leaves[2], 3e-2), ("far", leaves[3], 3e-2)):
+        ref = fx["grad_" + nm]
+        got = np.zeros_like(ref) if x.grad is None else x.grad.detach().cpu().numpy()
+        scale = np.abs(ref).max()
+        assert np.abs(got - ref).max() <= tol * scale + 1e-12, (nm, np.abs(got - ref).max(), scale)

@@ -91,6 +91,27 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_b
             const float prev = a.acc_normals ? a.d_normals[pd * 3 + d] : 0.0f;
             a.d_normals[pd * 3 + d] = prev + small[30 + d];
         }
+        if (a.d_pts != nullptr) {
+            // differentiable rays: d loss / d points (slots 0..2) and, through the transpose Jacobian of the 4-octave
+            // encoding (slots 3..29 = [dir, sin(2^k dir), cos(2^k dir)]), d loss / d view_dirs
+            const long r = pd / a.n_per_ray;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float dir = a.dirs ? a.dirs[pd * 3 + d] : a.rays_d[r * 3 + d];
+                float g = small[3 + d];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float f = (float)(1 << k);
+                    float sn, co;
+                    sincos_pe<P::kAccurateTrig>(dir * f, sn, co);
+                    g += f * (co * small[3 + 3 + 6 * k + d] - sn * small[3 + 3 + 6 * k + 3 + d]);
+                }
+                const float pp = a.acc_pts ? a.d_pts[pd * 3 + d] : 0.0f;
+                const float pg = a.acc_pts ? a.d_dirs[pd * 3 + d] : 0.0f;
+                a.d_pts[pd * 3 + d] = pp + small[d];
+                a.d_dirs[pd * 3 + d] = pg + g;
+            }
+        }
     }
 }
 
@@ -100,6 +121,7 @@ int launch_rendernet_bwd(const VdnRenderNetBwdArgs* args, void* stream_) {
     if (!args || args->P <= 0 || !args->blob || !args->g_out || !args->out || !args->save_h || !args->delta_out ||
         !args->delta_h || !args->d_feat || !args->d_normals) return -1;
     if (!(args->d_out == 96 || (args->d_out >= 1 && args->d_out <= 4))) return -2;
+    if (args->d_pts && (!args->d_dirs || (!args->dirs && (!args->rays_d || args->n_per_ray <= 0)))) return -3;
     const int ppw = P::kWaves * 32;
     const int grid = (args->P + ppw - 1) / ppw;
     const size_t lds = 3 * P::stride(8);

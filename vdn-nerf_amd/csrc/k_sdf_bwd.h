@@ -134,7 +134,8 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_fbar_ke
     constexpr int kSlot = P::stride(9);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     WStream<P::kWaves, kSlot> ws;
-    ws.init(a.blob, smem, 65);
+    const bool want_pts = a.d_pts != nullptr;      // differentiable rays: two more chunks (W0^T) and the encoding's adjoint
+    ws.init(a.blob, smem, want_pts ? 67 : 65);
     const int lane = ws.lane, c = lane & 31, h = lane >> 5;
     const WorkRow wr = work_row(a.active_idx, a.n_active, a.P, P::kWaves, ws.wave, c);
     if (wr.none) return;
@@ -144,6 +145,37 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_fbar_ke
     const ST* S = reinterpret_cast<const ST*>(a.S);
     const int from_h = a.s_from_h;
     const ST* EX = reinterpret_cast<const ST*>(a.EX);
+    float xin[3] = {0.0f, 0.0f, 0.0f};
+    if (want_pts) {
+        if (a.pts != nullptr) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) xin[d] = a.pts[pd * 3 + d] * a.scale;
+        } else {
+            const long r = pd / a.n_per_ray;
+            const float z = a.z[r * a.z_ld + (pd - r * a.n_per_ray)];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) xin[d] = (a.rays_o[r * 3 + d] + a.rays_d[r * 3 + d] * z) * a.scale;
+        }
+    }
+    // d loss / d xin accumulated from the adjoints of the encoded input (two tiles: the skip layer's PE part, then W0^T ab_0):
+    // J_PE(xin)^T applied at once, so that only three values stay alive across the remaining layers
+    float dx[3] = {0.0f, 0.0f, 0.0f};
+    auto pe_adjoint = [&](const f32x16 (&T2)[2]) VDN_INL {
+        float g[39];
+        tiles_vals<39, 2>(T2, h, g);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) dx[d] += g[d];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const float f = (float)(1 << k);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                float sn, co;
+                sincos_pe<P::kAccurateTrig>(xin[d] * f, sn, co);
+                dx[d] += f * (co * g[3 + 6 * k + d] - sn * g[3 + 6 * k + 3 + d]);
+            }
+        }
+    };
     const ST* g_feat = reinterpret_cast<const ST*>(a.g_feat);
     ST* ab8 = reinterpret_cast<ST*>(a.AB);
     auto ab = [&](int l) VDN_INL { return ab8 + Pn * 288 + (long)(7 - l) * PS; };   // l = 7..0
@@ -187,8 +219,9 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_fbar_ke
     dense<P, 8, 8, false>(ws, Y, 0, ldSE(6), epi(X, 6), 4, 8);     // W7^T
     dense<P, 8, 8, false>(ws, X, 0, ldSE(5), epi(Y, 5), 4, 8);     // W6^T
     dense<P, 8, 8, false>(ws, Y, 0, ldSE(4), epi(X, 4), 4, 8);     // W5^T
-    {   // W4^T: 9 output tiles = [h4 part (7) | PE part (2, no gradient wanted)]
+    {   // W4^T: 9 output tiles = [h4 part (7) | PE part (2: the skip input's adjoint, only wanted for differentiable rays)]
         ST* dst = ab(3);
+        f32x16 PE4[2];
         dense<P, 8, 9, false>(ws, X, 0,
             [&](int nt) VDN_INL {
                 SE r;
@@ -208,12 +241,39 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_fbar_ke
                     for (int t = 0; t < 16; ++t) o[t] = acc[t] * sprime(se.s[t], from_h) + se.e[t];
                     Y.set(nt, o);
                     P::store_tile(dst, p, 256, nt, h, o, ok);
+                } else {
+                    PE4[nt - 7] = acc;
                 }
             });
+        if (want_pts) pe_adjoint(PE4);
     }
     dense<P, 7, 8, false>(ws, Y, 0, ldSE(2), epi(X, 2), 4, 8);     // W3^T
     dense<P, 8, 8, false>(ws, X, 0, ldSE(1), epi(Y, 1), 4, 8);     // W2^T
     dense<P, 8, 8, false>(ws, Y, 0, ldSE(0), epi(X, 0), 4, 8);      // W1^T
+    if (want_pts) {
+        // d loss / d point = scale * d loss / d xin:  J_PE^T (W0^T ab_0 + [W4^T ab_4]_PE)  through the activations, plus the
+        // explicit dependence of normal = scale * J_PE(xin)^T u on xin at fixed u (the u-dependence went through rbar):
+        //   d/d xin_d [ f (cos(f xin_d) u_sin - sin(f xin_d) u_cos) ] = -f^2 (sin u_sin + cos u_cos)
+        f32x16 U0[2];
+        dense<P, 8, 2, false>(ws, X, 0, NoPre{}, [&](int nt, const f32x16& acc, int) VDN_INL { U0[nt] = acc; });   // W0^T
+        pe_adjoint(U0);
+        if (ok && h == 0) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float gn = a.g_normals[pd * 3 + d] * a.scale;
+                float e = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const float f = (float)(1 << k);
+                    float sn, co;
+                    sincos_pe<P::kAccurateTrig>(xin[d] * f, sn, co);
+                    e -= f * f * (sn * a.U_pe[p * 39 + 3 + 6 * k + d] + co * a.U_pe[p * 39 + 3 + 6 * k + 3 + d]);
+                }
+                const float v = (dx[d] + gn * e) * a.scale;
+                a.d_pts[pd * 3 + d] = a.acc_pts ? a.d_pts[pd * 3 + d] + v : v;
+            }
+        }
+    }
 }
 
 template <class P>
@@ -233,6 +293,8 @@ template <class P>
 int launch_sdf_fbar(const VdnSdfFbarArgs* args, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!args || args->P <= 0 || !args->blob || !args->g_sdf || !args->g_feat || !args->S || !args->EX || !args->AB) return -1;
+    if (args->d_pts && (!args->g_normals || !args->U_pe ||
+                        (!args->pts && (!args->rays_o || !args->rays_d || !args->z || args->n_per_ray <= 0 || args->z_ld < args->n_per_ray)))) return -2;
     const int ppw = P::kWaves * 32;
     const size_t lds = 3 * P::stride(9);
     static bool once = (allow_big_lds(sdf_fbar_kernel<P>, lds), true);

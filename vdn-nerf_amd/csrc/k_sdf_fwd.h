@@ -148,9 +148,13 @@ __global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(Sdf
         };
         // d/dx through the positional encoding (transpose Jacobian), accumulated into n[]
         float n[3] = {0.0f, 0.0f, 0.0f};
-        auto pe_backward = [&](const f32x16 (&U2)[2]) VDN_INL {
+        auto pe_backward = [&](const f32x16 (&U2)[2], bool first) VDN_INL {
             float u[39];
             tiles_vals<39, 2>(U2, h, u);
+            if (a.U_pe != nullptr && ok && h == 0) {      // u = u_4[PE part] + u_0 for the ray adjoint (VdnSdfArgs.U_pe)
+#pragma unroll
+                for (int i = 0; i < 39; ++i) a.U_pe[p * 39 + i] = first ? u[i] : a.U_pe[p * 39 + i] + u[i];
+            }
 #pragma unroll
             for (int d = 0; d < 3; ++d) n[d] += u[d];
 #pragma unroll
@@ -182,14 +186,14 @@ __global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(Sdf
                         UPE[nt - 7] = acc;
                     }
                 });
-            pe_backward(UPE);
+            pe_backward(UPE, true);
         }
         dense<P, 7, 8, false>(ws, Y, 0, loadS(2), mulInto(X, 2), est_v, 4);   // W3^T
         dense<P, 8, 8, false>(ws, X, 0, loadS(1), mulInto(Y, 1), est_v, 4);   // W2^T
         dense<P, 8, 8, false>(ws, Y, 0, loadS(0), mulInto(X, 0), est_v, 4);   // W1^T
         f32x16 U0[2];
         dense<P, 8, 2, false>(ws, X, 0, NoPre{}, [&](int nt, const f32x16& acc, int) VDN_INL { U0[nt] = acc; });   // W0^T
-        pe_backward(U0);
+        pe_backward(U0, false);
         if (ok && h == 0) {
 #pragma unroll
             for (int d = 0; d < 3; ++d) a.normals[pd * 3 + d] = n[d] * a.scale;

@@ -407,9 +407,15 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
     float sdf_dot = 0.0f;       // this lane's half of  W8[0,:] . g8  (f32)
     f32x16 UPE[2];              // d sdf / d(PE) tiles (W4^T rows 7,8 and W0^T)
     float n[3] = {0.0f, 0.0f, 0.0f};
-    auto pe_backward = [&]() VDN_INL {      // n += J_PE^T u  (transpose Jacobian of the encoding)
+    auto pe_backward = [&](bool first) VDN_INL {      // n += J_PE^T u  (transpose Jacobian of the encoding)
         float u[39];
         tiles_vals<39, 2>(UPE, h, u);
+        // u = u_4[PE part] + u_0 for the ray adjoint (VdnSdfArgs.U_pe); vector-memory operations the wait counts do not
+        // know of are harmless: they only make a counted wait return later
+        if (a.U_pe != nullptr && ok && h == 0) {
+#pragma unroll
+            for (int i = 0; i < 39; ++i) a.U_pe[p * 39 + i] = first ? u[i] : a.U_pe[p * 39 + i] + u[i];
+        }
 #pragma unroll
         for (int d = 0; d < 3; ++d) n[d] += u[d];
 #pragma unroll
@@ -569,7 +575,7 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
             }
             acc_prev = acc_cur;
             if constexpr (sweep_tile) sq_prev = sq_next;
-            if constexpr ((L.kind == SWEEP_SKIP && T == 8) || (L.kind == SWEEP_PE && T == 1)) pe_backward();
+            if constexpr ((L.kind == SWEEP_SKIP && T == 8) || (L.kind == SWEEP_PE && T == 1)) pe_backward(L.kind == SWEEP_SKIP);
         } else {
             // drain: the last chunk's tile (MODE 0: nothing is pending, the sdf row was stored above)
             epilogue(std::integral_constant<int, CP>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});

@@ -498,4 +498,27 @@ VDN_DEV void tiles_vals(const f32x16 (&T)[NT], int h, float (&vals)[NF]) {
     }
 }
 
+// Adjoint of the positional encoding, one 32-slot tile at a time: `tile` holds d loss / d(encoded input) for slots
+// [32 T0, 32 T0 + 32) of [x (D), sin(2^0 x), cos(2^0 x), sin(2^1 x), ...] (embedder.py:27-36); adds J^T of those slots to dx.
+template <int D, int L, int T0, bool ACCURATE>
+VDN_DEV void pe_adjoint_tile(const f32x16& tile, int h, const float (&x)[D], float (&dx)[D]) {
+    float g[32];
+    const f32x16 t1[1] = {tile};
+    tiles_vals<32, 1>(t1, h, g);
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const int slot = 32 * T0 + j;
+        if (slot >= D * (1 + 2 * L)) continue;
+        if (slot < D) {
+            dx[slot] += g[j];
+        } else {
+            const int k = (slot - D) / (2 * D), w = (slot - D) % (2 * D), d = w % D;
+            const float f = (float)(1 << k);
+            float sn, co;
+            sincos_pe<ACCURATE>(x[d] * f, sn, co);
+            dx[d] += w >= D ? -f * sn * g[j] : f * co * g[j];
+        }
+    }
+}
+
 }  // namespace vdn

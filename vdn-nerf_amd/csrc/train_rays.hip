@@ -130,6 +130,7 @@ __global__ __launch_bounds__(kRW * 64) void composite_bwd_kernel(CompositeBwdArg
         }
     }
     double dvar = 0.0;
+    float ddir[3] = {0.0f, 0.0f, 0.0f};        // sum_i d true_cos_i * normal_i  (true_cos = rays_d . normal, renderer.py:265)
 #pragma unroll
     for (int e = 0; e < kE; ++e) {
         const int i = kE * lane + e;
@@ -172,6 +173,10 @@ __global__ __launch_bounds__(kRW * 64) void composite_bwd_kernel(CompositeBwdArg
             const float dic = (den - dep) * dist * 0.5f;
             const float dtc = dic * ((ra > 0.0f ? 0.5f * (1.0f - car) : 0.0f) + (rb > 0.0f ? car : 0.0f));
             a.d_sdf[q] = dep + den;
+            if (a.d_dists != nullptr) {
+                a.d_dists[q] = (den - dep) * ic * 0.5f;          // en/ep = sdf +- iter_cos * dist / 2
+                ddir[0] += dtc * g0; ddir[1] += dtc * g1; ddir[2] += dtc * g2;
+            }
             // eikonal: d/dn of relax*(|n|-1)^2 / (den+1e-5)
             const float mz = a.mid_z[q];
             const float x = o[0] + d[0] * mz, y = o[1] + d[1] * mz, zz = o[2] + d[2] * mz;
@@ -194,10 +199,77 @@ __global__ __launch_bounds__(kRW * 64) void composite_bwd_kernel(CompositeBwdArg
             const float sp = softplus1(rho_);
             const float dsp = rho_ > 20.0f ? 1.0f : sigmoidf_(rho_);
             a.d_bg_density[qt] = da_bg * expf(-sp * dist) * dist * dsp;
+            if (a.d_bg_dists != nullptr) a.d_bg_dists[qt] = da_bg * expf(-sp * dist) * sp;
         }
     }
     dvar = wsum_d(dvar);
     if (lane == 0) a.d_var_partial[r] = s_unclipped ? (float)(dvar * 10.0 * (double)inv_s) : 0.0f;
+    if (a.d_dir_cos != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float s = (float)wsum_d((double)ddir[k]);
+            if (lane == 0) a.d_dir_cos[r * 3 + k] = s;
+        }
+    }
+}
+
+// Adjoint of the ray geometry (include/vdn_render.h: VdnRayAdjointArgs), one wave per ray, sample i = kE * lane + e.
+//   d o = sum_i d pts_i;  d d = sum_i (d pts_i mid_i + d dirs_i) + d dir_cos;  d mid_i = d pts_i . d
+//   mid_i = (z_i + z_{i+1}) / 2 and dists_i = z_{i+1} - z_i for i < n-1;  mid_{n-1} = z_{n-1} + sample_dist / 2, dists_{n-1} const
+//   =>  d z_i = (d mid_i + d mid_{i-1}) / 2 - d dists_i + d dists_{i-1}      (terms with index -1 absent; i = n-1: d mid_i whole)
+__global__ __launch_bounds__(kRW * 64) void ray_adjoint_kernel(RayAdjointArgs a) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * kRW + wave;
+    if (r >= a.B) return;
+    const float d0 = a.rays_d[r * 3], d1 = a.rays_d[r * 3 + 1], d2 = a.rays_d[r * 3 + 2];
+    double so[3] = {0.0, 0.0, 0.0}, sd[3] = {0.0, 0.0, 0.0};
+    auto pass = [&](const float* dpts, const float* ddirs, const float* ddists, const float* mid, int n, float* dz_a, int n_a,
+                    float* dz_b) VDN_INL {
+        float dm[kE], dl[kE];
+#pragma unroll
+        for (int e = 0; e < kE; ++e) {
+            const int i = kE * lane + e;
+            dm[e] = 0.0f; dl[e] = 0.0f;
+            if (i < n) {
+                const long q = (long)r * n + i;
+                const float px = dpts[q * 3], py = dpts[q * 3 + 1], pz = dpts[q * 3 + 2];
+                const float m = mid[q];
+                so[0] += px; so[1] += py; so[2] += pz;
+                sd[0] += (double)(px * m + ddirs[q * 3]); sd[1] += (double)(py * m + ddirs[q * 3 + 1]); sd[2] += (double)(pz * m + ddirs[q * 3 + 2]);
+                dm[e] = px * d0 + py * d1 + pz * d2;
+                dl[e] = ddists[q];
+            }
+        }
+        // values of sample i-1: the previous element, or the previous lane's last element
+        const float pm = __shfl_up(dm[kE - 1], 1), pl = __shfl_up(dl[kE - 1], 1);
+#pragma unroll
+        for (int e = 0; e < kE; ++e) {
+            const int i = kE * lane + e;
+            if (i >= n) continue;
+            const float dm_prev = i == 0 ? 0.0f : (e == 0 ? pm : dm[e - 1]);
+            const float dl_prev = i == 0 ? 0.0f : (e == 0 ? pl : dl[e - 1]);
+            const float v = i == n - 1 ? dm[e] + 0.5f * dm_prev + dl_prev : 0.5f * (dm[e] + dm_prev) - dl[e] + dl_prev;
+            if (i < n_a) dz_a[(long)r * n_a + i] += v;
+            else if (dz_b != nullptr) dz_b[(long)r * (n - n_a) + (i - n_a)] += v;
+        }
+    };
+    const int N = a.N, T = a.T;
+#pragma unroll
+    for (int e = 0; e < kE; ++e) {
+        const int i = kE * lane + e;
+        if (i < N) a.d_z[(long)r * N + i] = 0.0f;
+        if (a.d_z_out != nullptr && i >= N && i < T) a.d_z_out[(long)r * (T - N) + (i - N)] = 0.0f;
+    }
+    pass(a.d_pts, a.d_dirs, a.d_dists, a.mid_z, N, a.d_z, N, nullptr);
+    if (a.d_bg_pts != nullptr) pass(a.d_bg_pts, a.d_bg_dirs, a.d_bg_dists, a.bg_mid, T, a.d_z, N, a.d_z_out);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double o = wsum_d(so[k]), dd = wsum_d(sd[k]);
+        if (lane == 0) {
+            a.d_rays_o[r * 3 + k] = (float)o;
+            a.d_rays_d[r * 3 + k] = (float)dd + a.d_dir_cos[r * 3 + k];
+        }
+    }
 }
 
 __global__ void variance_reduce_kernel(const float* partial, int B, float* out) {
@@ -217,7 +289,17 @@ extern "C" int vdn_alpha_composite_bwd(const VdnCompositeBwdArgs* a, void* strea
     if (!a->d_sdf || !a->d_normals || !a->d_color || !a->d_var_partial || !a->d_variance) return -3;
     if (a->T > a->N && (!a->bg_density || !a->bg_rgb || !a->bg_dists || !a->d_bg_density || !a->d_bg_rgb)) return -4;
     if (a->d_feat && (!a->feat || a->feat_ch <= 0)) return -5;
+    if ((a->d_dists != nullptr) != (a->d_dir_cos != nullptr) || (a->d_bg_dists && !a->d_dists)) return -6;
     hipLaunchKernelGGL(composite_bwd_kernel, dim3((a->B + kRW - 1) / kRW), dim3(kRW * 64), 0, (hipStream_t)stream, *a);
     hipLaunchKernelGGL(variance_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a->d_var_partial, a->B, a->d_variance);
+    return (int)hipGetLastError();
+}
+
+extern "C" int vdn_ray_adjoint(const VdnRayAdjointArgs* a, void* stream) {
+    using namespace vdn;
+    if (!a || a->B <= 0 || a->N <= 0 || a->T < a->N || a->T > kMaxTB) return -1;
+    if (!a->rays_d || !a->mid_z || !a->d_pts || !a->d_dirs || !a->d_dists || !a->d_dir_cos || !a->d_rays_o || !a->d_rays_d || !a->d_z) return -2;
+    if (a->T > a->N && a->d_bg_pts && (!a->bg_mid || !a->d_bg_dirs || !a->d_bg_dists || !a->d_z_out)) return -3;
+    hipLaunchKernelGGL(ray_adjoint_kernel, dim3((a->B + kRW - 1) / kRW), dim3(kRW * 64), 0, (hipStream_t)stream, *a);
     return (int)hipGetLastError();
 }

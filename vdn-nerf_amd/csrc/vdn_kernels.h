@@ -23,6 +23,7 @@ using DwFinalizeDesc = ::VdnDwFinalizeDesc;
 using WeightNormBwdDesc = ::VdnWeightNormBwdDesc;
 using CompositeBwdArgs = ::VdnCompositeBwdArgs;
 using LossArgs = ::VdnLossArgs;
+using RayAdjointArgs = ::VdnRayAdjointArgs;
 using GenRaysArgs = ::VdnGenRaysArgs;
 
 // Kernels needing more than 64 KiB of dynamic LDS opt in once per process.

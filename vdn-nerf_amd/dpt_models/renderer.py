@@ -85,7 +85,10 @@ class _RenderCoreFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, engine, rays_o, rays_d, z, z_out, bgc, car, *params):
-        w = engine.forward(rays_o, rays_d, z, z_out, bgc, car)
+        # differentiable rays (learnable poses, poses.py:198-208): the backward then also returns d loss / d rays_o, rays_d
+        # and d loss / d z, d z_out (render() chains the latter to near / far)
+        ctx.ray_grads = any(ctx.needs_input_grad[1:5])
+        w = engine.forward(rays_o, rays_d, z, z_out, bgc, car, ray_grads=ctx.ray_grads)
         ctx.engine, ctx.generation, ctx.n_params = engine, engine.generation, len(params)
         color, weights, eik = w["color"].clone(), w["weights"].clone(), w["eik"][0].clone()
         feats = w["feat_out"].clone() if w["feat_out"] is not None else color.new_zeros(0)
@@ -104,7 +107,13 @@ class _RenderCoreFn(torch.autograd.Function):
         eng.backward(g_color, g_feats, g_weights, g_eik)
         flat = eng.param_grads(clone=True)        # clones: the engine's buffers are reused by the next step
         assert len(flat) == ctx.n_params
-        return (None,) * 7 + tuple(flat)
+        rays = (None,) * 4
+        if ctx.ray_grads:
+            w = eng.w
+            rays = (w["d_rays_o"].clone(), w["d_rays_d"].clone(), w["d_z"].clone(),
+                    w["d_z_out"].clone() if "d_z_out" in w else None)
+            rays = tuple(g if need else None for g, need in zip(rays, ctx.needs_input_grad[1:5]))
+        return (None,) + rays + (None, None) + tuple(flat)
 
 
 class NeuSRenderer:
@@ -221,6 +230,8 @@ class NeuSRenderer:
         B, dev = rays_o.shape[0], rays_o.device
         if near.numel() != B or far.numel() != B:
             raise ValueError("near / far must hold one value per ray")
+        # learnable poses (poses.py:198-208): rays, near and far may carry a graph; the sampler works on detached copies
+        attached = (rays_o, rays_d, near, far) if (torch.is_grad_enabled() and any(t.requires_grad for t in (rays_o, rays_d, near, far))) else None
         rays_o = rays_o.detach().contiguous()
         rays_d = rays_d.detach().contiguous()
         near = near.detach().reshape(B).contiguous()
@@ -236,7 +247,9 @@ class NeuSRenderer:
 
         z, z_out = self._sample(rays_o, rays_d, near, far, perturb, t_rand, t_rand_out, z_vals_inject)
         params = self._all_parameters()
-        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        if torch.is_grad_enabled() and (attached is not None or any(p.requires_grad for p in params)):
+            if attached is not None:
+                rays_o, rays_d, z, z_out = self._attach_rays(attached, near, far, z, z_out)
             return self._render_train(rays_o, rays_d, z, z_out, background_rgb, cos_anneal_ratio, params)
         dists, mid_z = self._sections(z, N, sample_dist)
 
@@ -310,6 +323,29 @@ class NeuSRenderer:
             if m is not None:
                 ps += list(m.parameters())
         return ps
+
+    def _attach_rays(self, attached, near_d, far_d, z, z_out):
+        """Re-attach the sampler's detached depths to near / far exactly where the reference's graph has them:
+        * z_vals = near + (far - near) * linspace (+ a jitter independent of them) is built with autograd on
+          (renderer.py:335-349), but with importance sampling the whole up-sampling loop - including cat_z_vals, which
+          REPLACES z_vals by the sorted concatenation - runs under torch.no_grad() (367-386): the inside depths that reach
+          render_core then carry no graph at all. Only with n_importance = 0 do they depend on (near, far), with weights
+          (1 - t_i, t_i);
+        * z_vals_outside = far / flip(...) + 1 / n_samples (359) is outside the no_grad block: far * c_k + const.
+        The values stay the kernels' own: only zero-valued differences carrying the graph are added."""
+        rays_o, rays_d, near, far = attached
+        B, dev = z.shape[0], z.device
+        S = self.n_samples
+        near, far = near.reshape(B, 1), far.reshape(B, 1)
+        z_att = z
+        if self.n_importance == 0:
+            zc = near + (far - near) * self._consts(dev)["lin_samples"][None, :]   # renderer.py:335-336 (graph only)
+            z_att = z + (zc - zc.detach())
+        z_out_att = z_out
+        if z_out is not None:
+            c = (z_out - 1.0 / S) / far_d.reshape(B, 1)                            # z_out = far * c + 1 / n_samples (renderer.py:359)
+            z_out_att = z_out + (far - far.detach()) * c
+        return rays_o.contiguous(), rays_d.contiguous(), z_att, z_out_att
 
     def _render_train(self, rays_o, rays_d, z, z_out, background_rgb, cos_anneal_ratio, params):
         """Training path: same outputs, differentiable wrt every network parameter (dpt_runner.py:253)."""

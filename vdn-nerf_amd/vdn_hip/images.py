@@ -287,7 +287,9 @@ def sdf_streams(d_in, d_out, d_hidden, n_layers, skip_in, multires, scaled=False
     last_full = dense_layer("lin8", ident_map(256), nm8, True, wsc8)
     sweep = [transposed_layer(n, km, nm, sc * swsc) for (n, km, nm, sc) in reversed(fwd[0:8])]
     # adjoint of the forward pass: W8^T, W7^T .. W1^T
+    # (+ W0^T at the end: the adjoint of the encoded input, only read when the rays are differentiable; unscaled kmap)
     fbar = [transposed_layer("lin8", ident_map(256), nm8)] + [transposed_layer(n, km, nm, sc) for (n, km, nm, sc) in reversed(fwd[1:8])]
+    fbar.append(transposed_layer("lin0", ident_map(d0, 64), ident_map(256), 1.0))
     if scaled:
         # row 0 of W8 (f32, 256 values) rides in every chunk's unused tail, behind the widest chunk's bias block: the kernel
         # reads it from whichever slot is current (the f32 sdf row, the sweep's first operand)
@@ -360,4 +362,6 @@ def nerf_streams(D, W, d_in, d_in_view, multires, multires_view, skips, rgb_dims
     bwd += [transposed_layer("pts_linears.%d" % i, ident_map(256), ident_map(256)) for i in (7, 6)]
     bwd.append(transposed_layer("pts_linears.5", km5, ident_map(256)))
     bwd += [transposed_layer("pts_linears.%d" % i, ident_map(256), ident_map(256)) for i in (4, 3, 2, 1)]
+    # W0^T: the adjoint of the encoded point, only read when the rays are differentiable (vdn_nerf_mlp_bwd with d_pts)
+    bwd.append(transposed_layer("pts_linears.0", ident_map(ch, 96), ident_map(256)))
     return {"fwd": layers, "bwd": bwd, "_km5": km5, "_kmv": kmv}

@@ -297,7 +297,19 @@ class TrainEngine:
         return tuple(p.data_ptr() for net in self.nets.values() for p in net.module.parameters())
 
     # ------------------------------------------------------------------------------------------
-    def forward(self, rays_o, rays_d, z, z_out, background_rgb, cos_anneal_ratio, skip_far=False):
+    def _ray_workspaces(self):
+        """Buffers of the ray adjoint (differentiable rays_o / rays_d / z, poses.py:198-208), allocated on first use."""
+        w, B, N, T, P, Q, dev = self.w, self.B, self.N, self.T, self.P, self.Q, self.dev
+        if "U_pe" not in w:
+            f = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
+            w["U_pe"], w["d_pts"], w["d_dirs"] = f(P, 39), f(P, 3), f(P, 3)
+            w["d_dists"], w["d_dir_cos"] = f(B, N), f(B, 3)
+            w["d_rays_o"], w["d_rays_d"], w["d_z"] = f(B, 3), f(B, 3), f(B, N)
+            if self.r.n_outside > 0:
+                w["d_bg_pts"], w["d_bg_dirs"], w["d_bg_dists"], w["d_z_out"] = f(Q, 3), f(Q, 3), f(B, T), f(B, T - N)
+        return w
+
+    def forward(self, rays_o, rays_d, z, z_out, background_rgb, cos_anneal_ratio, skip_far=False, ray_grads=False):
         """Differentiable part of render() at detached z [B,N] (+ z_out [B,O]); returns the output tensors.
         skip_far (the Trainer's hot loop): inside samples beyond the relaxed sphere (|p| >= 1.2: inside_sphere = 0 and
         relax_inside_sphere = 0, renderer.py:284-286) enter the loss only through exact zeros, so the SDF / colour / VDN
@@ -305,6 +317,11 @@ class TrainEngine:
         `gradients` for every sample)."""
         r, w, B, N, T = self.r, self.w, self.B, self.N, self.T
         st = _stream()
+        if ray_grads and skip_far:
+            raise ValueError("ray gradients need every inside sample evaluated (skip_far=False)")
+        self._ray_grads = bool(ray_grads)
+        if ray_grads:
+            self._ray_workspaces()
         for net in self.nets.values():
             net.img = net.module._images()           # refresh weight images if parameters changed
         if self._ptr_key() != self._param_ptrs:
@@ -416,6 +433,8 @@ class TrainEngine:
             s.S = w["S"].data_ptr()
         s.w8row = img.weff_view("lin8").data_ptr()
         s.H, s.V, s.PE = w["H"].data_ptr(), w["V"].data_ptr(), w["PE"].data_ptr()
+        if getattr(self, "_ray_grads", False):
+            s.U_pe = w["U_pe"].data_ptr()
         lib.call("vdn_sdf_mlp_fwd" + self.sfx, 1, self._fg(s), _stream())
 
     def _dw_rows(self):
@@ -486,6 +505,11 @@ class TrainEngine:
                     w["d_bg_feat"].zero_()
         c.d_var_partial = w["d_var_partial"].data_ptr()
         c.d_variance = self.grad_views[id(r.deviation_network.variance)].data_ptr()
+        rg = getattr(self, "_ray_grads", False)
+        if rg:
+            c.d_dists, c.d_dir_cos = w["d_dists"].data_ptr(), w["d_dir_cos"].data_ptr()
+            if r.n_outside > 0:
+                c.d_bg_dists = w["d_bg_dists"].data_ptr()
         lib.call("vdn_alpha_composite_bwd", c, st)
         if r.n_outside > 0:                      # NeRF backward on the side stream, beside the heads' and the SDF backward
             nb = lib.VdnNerfBwdArgs()
@@ -497,6 +521,12 @@ class TrainEngine:
             nb.P = self.Q
             if self._bg_compact:
                 nb.active_idx, nb.n_active = w["bg_active"][0].data_ptr(), w["bg_active"][1].data_ptr()
+            if rg:
+                # samples off the work list enter the loss through exact zeros: their adjoints stay zero
+                w["d_bg_pts"].zero_()
+                w["d_bg_dirs"].zero_()
+                nb.rays_o, nb.rays_d, nb.z, nb.n_per_ray = rays_o.data_ptr(), rays_d.data_ptr(), w["bg_mid"].data_ptr(), self.T
+                nb.d_pts, nb.d_dirs = w["d_bg_pts"].data_ptr(), w["d_bg_dirs"].data_ptr()
             self._fork()
             lib.call("vdn_nerf_mlp_bwd" + self.sfx, nb, self._side_handle(st))
             self._side_done()
@@ -509,6 +539,9 @@ class TrainEngine:
             b.d_feat, b.d_normals = w["d_featvec"].data_ptr(), w["d_normals"].data_ptr()
             b.acc_feat, b.acc_normals = int(accumulate), 1
             b.P, b.d_out, b.squeeze_out = self.P, d_out, int(module.squeeze_out)
+            if rg:
+                b.rays_d, b.n_per_ray, b.acc_pts = rays_d.data_ptr(), self.N, int(accumulate)
+                b.d_pts, b.d_dirs = w["d_pts"].data_ptr(), w["d_dirs"].data_ptr()
             lib.call("vdn_rendernet_bwd" + self.sfx, self._fg(b), st)
         # d_normals already holds the alpha + eikonal parts: the heads add their input gradients into it;
         # d_featvec is overwritten by the first head and accumulated by the second
@@ -533,6 +566,9 @@ class TrainEngine:
         fb.blob = img.blobs["fbar"].data_ptr()
         fb.g_sdf, fb.g_feat, fb.S, fb.EX, fb.AB = w["d_sdf"].data_ptr(), w["d_featvec"].data_ptr(), s_planes.data_ptr(), w["EX"].data_ptr(), w["AB"].data_ptr()
         fb.P, fb.scale, fb.s_from_h = self.P, float(r.sdf_network.scale), s_from_h
+        if rg:
+            fb.rays_o, fb.rays_d, fb.z, fb.n_per_ray, fb.z_ld = rays_o.data_ptr(), rays_d.data_ptr(), w["mid_z"].data_ptr(), self.N, self.N
+            fb.g_normals, fb.U_pe, fb.acc_pts, fb.d_pts = w["d_normals"].data_ptr(), w["U_pe"].data_ptr(), 1, w["d_pts"].data_ptr()
         lib.call("vdn_sdf_bwd_fbar" + self.sfx, self._fg(fb), st)
 
         self._join()
@@ -540,6 +576,16 @@ class TrainEngine:
         lib.call("vdn_dw_finalize", lib.ptr(self.fin_table), self.n_dw, self.fin_max_M, 0, st)
         lib.call("vdn_dw_finalize", lib.ptr(self.fin_table), self.n_dw, self.fin_max_M, 1, st)
         lib.call("vdn_weightnorm_bwd", lib.ptr(self.wn_table), self.n_wn, self.wn_max_rows, st)
+        if rg:
+            ra = lib.VdnRayAdjointArgs()
+            ra.rays_d, ra.mid_z = rays_d.data_ptr(), w["mid_z"].data_ptr()
+            ra.d_pts, ra.d_dirs, ra.d_dists, ra.d_dir_cos = (w[k].data_ptr() for k in ("d_pts", "d_dirs", "d_dists", "d_dir_cos"))
+            ra.B, ra.N, ra.T = self.B, self.N, self.T
+            if r.n_outside > 0:
+                ra.bg_mid = w["bg_mid"].data_ptr()
+                ra.d_bg_pts, ra.d_bg_dirs, ra.d_bg_dists, ra.d_z_out = (w[k].data_ptr() for k in ("d_bg_pts", "d_bg_dirs", "d_bg_dists", "d_z_out"))
+            ra.d_rays_o, ra.d_rays_d, ra.d_z = w["d_rays_o"].data_ptr(), w["d_rays_d"].data_ptr(), w["d_z"].data_ptr()
+            lib.call("vdn_ray_adjoint", ra, st)
         # gradients now sit in self.grad_flat (views per parameter in self.grad_views)
         return self.grad_flat
 
