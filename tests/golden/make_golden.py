@@ -65,24 +65,30 @@ def import_reference():
     return mods["fields"], mods["renderer"], mods["embedder"]
 
 
-def build_reference(fields, renderer, states, wdepth, dtype, n_importance=64, n_outside=32):
+MODE_KW = {"idr": dict(mode="idr", d_in=9, multires_view=4), "no_normal": dict(mode="no_normal", d_in=6, multires_view=4),
+           "no_view_dir": dict(mode="no_view_dir", d_in=6, multires_view=0)}
+
+
+def build_reference(fields, renderer, states, wdepth, dtype, n_importance=64, n_outside=32, color_mode="idr", weight_norm=True):
+    from vdn_train import synth
     tt = lambda d: {k: torch.tensor(v, dtype=dtype) for k, v in d.items()}
+    vs = lambda key, mode: synth.variant_state(states[key], mode, weight_norm)
     nerf = fields.NeRF(D=8, d_in=4, d_in_view=3, W=256, multires=10, multires_view=4, output_ch=4, skips=[4],
                        rgb_dims=3, use_viewdirs=True, gen_depth_feats=wdepth, dpt_dim=96).to(dtype)
     sdf = fields.SDFNetwork(d_out=257, d_in=3, d_hidden=256, n_layers=8, skip_in=[4], multires=6, bias=0.5,
-                            scale=1.0, geometric_init=True, weight_norm=True).to(dtype)
+                            scale=1.0, geometric_init=True, weight_norm=weight_norm).to(dtype)
     var = fields.SingleVarianceNetwork(init_val=0.3).to(dtype)
-    col = fields.RenderingNetwork(d_feature=256, mode="idr", d_in=9, d_out=3, d_hidden=256, n_layers=4,
-                                  weight_norm=True, multires_view=4, squeeze_out=True).to(dtype)
+    col = fields.RenderingNetwork(d_feature=256, d_out=3, d_hidden=256, n_layers=4, weight_norm=weight_norm, squeeze_out=True,
+                                  **MODE_KW[color_mode]).to(dtype)
     vdn = None
     if wdepth:
-        vdn = fields.RenderingNetwork(d_feature=256, mode="idr", d_in=9, d_out=96, d_hidden=256, n_layers=4,
-                                      weight_norm=True, multires_view=4, squeeze_out=True).to(dtype)
-        vdn.load_state_dict(tt(states["depth_network_fine"]))
+        vdn = fields.RenderingNetwork(d_feature=256, d_out=96, d_hidden=256, n_layers=4, weight_norm=weight_norm, squeeze_out=True,
+                                      **MODE_KW[color_mode]).to(dtype)
+        vdn.load_state_dict(tt(vs("depth_network_fine", color_mode)))
     nerf.load_state_dict(tt(states["nerf"]))
-    sdf.load_state_dict(tt(states["sdf_network_fine"]))
+    sdf.load_state_dict(tt(vs("sdf_network_fine", "idr")))
     var.load_state_dict(tt(states["variance_network_fine"]))
-    col.load_state_dict(tt(states["color_network_fine"]))
+    col.load_state_dict(tt(vs("color_network_fine", color_mode)))
     rend = renderer.NeuSRenderer(nerf, sdf, var, col, vdn, n_samples=64, n_importance=n_importance,
                                  n_outside=n_outside, up_sample_steps=4, perturb=1.0)
     return rend
@@ -125,12 +131,12 @@ def rel(a, b):
 
 
 def run_case(fields, renderer, name, seed, B, wdepth, variance, cos_anneal, perturb, dtype=torch.float32,
-             n_importance=64, with_grads=True, white=True, depth_before_color=False):
+             n_importance=64, with_grads=True, white=True, depth_before_color=False, color_mode="idr", weight_norm=True):
     from vdn_train import synth
     import oracle.neus_oracle as orc
     torch.set_default_dtype(dtype)
     states = synth.make_all_states(seed, wdepth=wdepth, variance=variance)
-    rend = build_reference(fields, renderer, states, wdepth, dtype, n_importance=n_importance)
+    rend = build_reference(fields, renderer, states, wdepth, dtype, n_importance=n_importance, color_mode=color_mode, weight_norm=weight_norm)
     o, d, near, far = make_rays(seed, B)
     t_rand, t_rand_out = synth.jitter(seed, 0, B)
     tt = lambda x: torch.tensor(x, dtype=dtype)
@@ -183,6 +189,13 @@ def run_case(fields, renderer, name, seed, B, wdepth, variance, cos_anneal, pert
             idx = np.unique(np.linspace(0, gf.numel() - 1, 16).astype(np.int64))
             fx["grad_idx/" + n] = idx
             fx["grad_val/" + n] = gf[idx].numpy()
+    fx["z_vals_inside"] = captured["z"].numpy()          # the REFERENCE's inside z (input of render_core)
+    if color_mode != "idr" or not weight_norm:
+        fx["color_mode"], fx["weight_norm"] = color_mode, weight_norm
+        # constructor variants outside the shipped configurations: the oracle restates the shipped ones only; the fixture is
+        # the reference's outputs and gradient samples
+        torch.set_default_dtype(torch.float32)
+        return fx, {}
     # ---- oracle cross-check
     nets = orc.nets_from_numpy(states, dtype=dtype, requires_grad=with_grads)
     conf = orc.RendererConf(n_importance=n_importance)
@@ -383,6 +396,9 @@ CASES = [
     ("wdepth_v065_c1", 7, 16, True, 0.65, 1.0, 1.0, {}),
     ("white_n64_v03", 8, 24, False, 0.3, 0.3, 1.0, {"n_importance": 0}),
     ("black_v03", 9, 16, False, 0.3, 1.0, 1.0, {"white": False, "with_grads": False}),
+    # constructor variants no shipped configuration uses (fields.py:154-158, 65-66 / 141-142)
+    ("white_nonormal_plain", 10, 16, False, 0.3, 0.5, 1.0, {"color_mode": "no_normal", "weight_norm": False}),
+    ("wdepth_noviewdir", 11, 12, True, 0.3, 0.5, 1.0, {"color_mode": "no_view_dir"}),
 ]
 F64_COMPANIONS = ("white_v03_c0", "white_v065_c1", "wdepth_v065_c1")
 

@@ -1,0 +1,104 @@
+"""Constructor variants outside the shipped configurations (reference fields.py:154-158 RenderingNetwork modes 'no_normal' /
+'no_view_dir'; fields.py:65-66, 141-142 weight_norm=False) against the REFERENCE's own outputs and gradient samples
+(tests/golden/white_nonormal_plain.npz, wdepth_noviewdir.npz; make_golden.py CASES). The kernels are the shipped ones:
+a mode is a column selection of the first layer's image, weight_norm=False the plain-matrix path the NeRF already uses."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import relmax
+from test_gpu_grads import _loss, g
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(fx, dev, precision="fp32"):
+    from vdn_train import synth, factory
+    wdepth = bool(fx["wdepth"])
+    st = synth.make_all_states(int(fx["seed"]), wdepth=wdepth, variance=float(fx["variance"]))
+    return factory.build_renderer(wdepth=wdepth, device=dev, states=st, precision=precision, color_mode=str(fx["color_mode"]),
+                                  weight_norm=bool(fx["weight_norm"]))
+
+
+def _render(rend, fx, dev, inject):
+    return rend.render(g(fx["rays_o"], dev), g(fx["rays_d"], dev), g(fx["near"], dev), g(fx["far"], dev), perturb_overwrite=-1,
+                       background_rgb=torch.ones(1, 3, device=dev), cos_anneal_ratio=float(fx["cos_anneal"]),
+                       t_rand=g(fx["t_rand"], dev), t_rand_out=g(fx["t_rand_out"], dev),
+                       z_vals_inject=g(fx["z_vals_inside"], dev) if inject else None)
+
+
+@pytest.mark.parametrize("name", ["white_nonormal_plain", "wdepth_noviewdir"])
+def test_variant_render_and_gradients_vs_reference(golden, name):
+    fx = golden(name)
+    dev = torch.device("cuda:0")
+    rend = _build(fx, dev)
+    keys = [n for n, _ in rend.color_network.named_parameters()]
+    assert ("lin0.weight" in keys) == (not bool(fx["weight_norm"])) and ("lin0.weight_g" in keys) == bool(fx["weight_norm"])
+    with torch.no_grad():
+        out = _render(rend, fx, dev, inject=False)
+    for k in ["color_fine", "weight_sum", "s_val", "z_vals", "gradient_error"] + (["render_feats"] if fx["wdepth"] else []):
+        assert relmax(out[k].cpu().numpy(), fx["out_" + k]) < 1e-4, k
+    out = _render(rend, fx, dev, inject=True)
+    for k in ("weights", "cdf_fine", "gradients", "color_fine"):
+        assert relmax(out[k].detach().cpu().numpy(), fx["out_" + k]) < 1e-4, k
+    wdepth = bool(fx["wdepth"])
+    loss = _loss(out, g(fx["true_rgb"], dev), g(fx["gt_feats"], dev) if wdepth else None, wdepth)
+    assert abs(loss.item() - float(fx["loss"])) < 2e-5 * abs(float(fx["loss"]))
+    loss.backward()
+    worst = []
+    for key, mod in (("nerf", rend.nerf), ("sdf", rend.sdf_network), ("variance", rend.deviation_network),
+                     ("color", rend.color_network), ("vdn", rend.depth_network)):
+        if mod is None:
+            continue
+        for n, p in mod.named_parameters():
+            full = key + "." + n if key != "variance" else "variance"
+            rn = float(fx["grad_norm/" + full])
+            if rn == 0.0:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, full
+                continue
+            gv = p.grad.detach().cpu().reshape(-1)[torch.as_tensor(fx["grad_idx/" + full])].numpy()
+            rv = fx["grad_val/" + full]
+            e_norm = abs(float(p.grad.norm()) - rn) / rn
+            e_val = np.abs(gv - rv).max() / (np.abs(rv).max() + 1e-30)
+            worst.append((max(e_norm, e_val), full, rn))
+    worst.sort(reverse=True)
+    # the reference's samples are fp32 autograd: tiny, cancellation-dominated tensors (the background NeRF's first layers,
+    # |g| ~ 1e-5) carry its own noise; everything else is at 1e-3 of the tensor's norm / largest sampled entry
+    bad = [w for w in worst if w[0] > (1e-3 if w[2] > 1e-3 else 5e-2)]
+    assert not bad, worst[:8]
+
+
+def test_variant_modules_standalone_forward(golden):
+    """RenderingNetwork.forward / SDFNetwork.forward as stand-alone modules in the variant forms agree with the same
+    modules in the shipped form fed the equivalent inputs (the variants are column selections / re-parametrisations)."""
+    from vdn_train import synth
+    from dpt_models.fields import RenderingNetwork, SDFNetwork
+    dev = torch.device("cuda:0")
+    st = synth.make_all_states(3, wdepth=False, variance=0.3)
+    tt = lambda d: {k: torch.as_tensor(v) for k, v in d.items()}
+    P = 77
+    pts, nrm, dirs = (g(synth.uniform(3, "var/" + k, (P, 3)) * 2 - 1, dev) for k in ("p", "n", "d"))
+    feat = g(synth.uniform(3, "var/f", (P, 256)) * 2 - 1, dev)
+    base = RenderingNetwork(d_feature=256, mode="idr", d_in=9, d_out=3, d_hidden=256, n_layers=4, weight_norm=True, multires_view=4).to(dev)
+    base.load_state_dict(tt(st["color_network_fine"]))
+    plain = RenderingNetwork(d_feature=256, mode="idr", d_in=9, d_out=3, d_hidden=256, n_layers=4, weight_norm=False, multires_view=4).to(dev)
+    plain.load_state_dict(tt(synth.variant_state(st["color_network_fine"], "idr", False)))
+    assert sorted(plain.state_dict()) == sorted("lin%d.%s" % (l, k) for l in range(5) for k in ("weight", "bias"))
+    assert relmax(plain(pts, nrm, dirs, feat).cpu().numpy(), base(pts, nrm, dirs, feat).cpu().numpy()) < 2e-6
+    # 'no_normal' = an idr network whose normals' columns are zero (zero columns leave the weight-norm row norms unchanged)
+    vst = synth.variant_state(st["color_network_fine"], "no_normal", True)
+    nn_ = RenderingNetwork(d_feature=256, mode="no_normal", d_in=6, d_out=3, d_hidden=256, n_layers=4, weight_norm=True, multires_view=4).to(dev)
+    nn_.load_state_dict(tt(vst))
+    wide = dict(vst)
+    v = vst["lin0.weight_v"]
+    wide["lin0.weight_v"] = np.concatenate([v[:, :30], np.zeros((256, 3), np.float32), v[:, 30:]], axis=1)
+    base.load_state_dict(tt(wide))
+    assert relmax(nn_(pts, nrm, dirs, feat).cpu().numpy(), base(pts, nrm, dirs, feat).cpu().numpy()) < 2e-6
+    sdf_w = SDFNetwork(d_out=257, d_in=3, d_hidden=256, n_layers=8, skip_in=[4], multires=6, bias=0.5, scale=1.0, weight_norm=True).to(dev)
+    sdf_w.load_state_dict(tt(st["sdf_network_fine"]))
+    sdf_p = SDFNetwork(d_out=257, d_in=3, d_hidden=256, n_layers=8, skip_in=[4], multires=6, bias=0.5, scale=1.0, weight_norm=False).to(dev)
+    sdf_p.load_state_dict(tt(synth.variant_state(st["sdf_network_fine"], "idr", False)))
+    assert relmax(sdf_p(pts).cpu().numpy(), sdf_w(pts).cpu().numpy()) < 2e-6
+    assert relmax(sdf_p.gradient(pts).cpu().numpy(), sdf_w.gradient(pts).cpu().numpy()) < 2e-6
+    with pytest.raises(ValueError):
+        RenderingNetwork(d_feature=256, mode="no_view_dir", d_in=6, d_out=3, d_hidden=256, n_layers=4, multires_view=4).to(dev)(pts, nrm, dirs, feat)

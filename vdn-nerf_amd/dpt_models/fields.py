@@ -95,8 +95,6 @@ class SDFNetwork(_HipNet):
         self.conf = dict(d_in=d_in, d_out=d_out, d_hidden=d_hidden, n_layers=n_layers, skip_in=tuple(skip_in),
                          multires=multires)
         self.weight_norm = weight_norm
-        if not weight_norm:
-            raise ValueError("SDFNetwork(weight_norm=False) is not used by any shipped configuration")
         # Same construction order and RNG draws as the reference (fields.py:37-68): nn.Linear's own
         # init first, then the geometric init of IDR.
         for l in range(self.num_layers - 1):
@@ -118,7 +116,8 @@ class SDFNetwork(_HipNet):
                 else:
                     torch.nn.init.constant_(lin.bias, 0.0)
                     torch.nn.init.normal_(lin.weight, 0.0, np.sqrt(2) / np.sqrt(out_dim))
-            setattr(self, "lin" + str(l), _WNLinear(lin))
+            # fields.py:65-68: weight_norm(lin) re-parametrises (bias, weight_g, weight_v); without it the nn.Linear itself
+            setattr(self, "lin" + str(l), _WNLinear(lin) if weight_norm else _PlainLinear(lin))
 
     def _matrices(self):
         return {"lin%d" % l: getattr(self, "lin%d" % l).triple() for l in range(self.num_layers - 1)}
@@ -205,10 +204,9 @@ class RenderingNetwork(_HipNet):
         self.num_layers = len(dims)
         self.conf = dict(d_feature=d_feature, mode=mode, d_in=d_in, d_out=d_out, d_hidden=d_hidden,
                          n_layers=n_layers, multires_view=multires_view)
-        if not weight_norm:
-            raise ValueError("RenderingNetwork(weight_norm=False) is not used by any shipped configuration")
-        for l in range(self.num_layers - 1):
-            setattr(self, "lin" + str(l), _WNLinear(nn.Linear(dims[l], dims[l + 1])))   # fields.py:137-144
+        for l in range(self.num_layers - 1):                                            # fields.py:137-144
+            lin = nn.Linear(dims[l], dims[l + 1])
+            setattr(self, "lin" + str(l), _WNLinear(lin) if weight_norm else _PlainLinear(lin))
 
     def _matrices(self):
         return {"lin%d" % l: getattr(self, "lin%d" % l).triple() for l in range(self.num_layers - 1)}

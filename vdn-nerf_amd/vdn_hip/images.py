@@ -309,13 +309,27 @@ def sdf_layer_maps():
 
 
 def rendering_streams(d_feature, mode, d_in, d_out, d_hidden, n_layers, multires_view):
-    if not (d_feature == 256 and mode == "idr" and d_in == 9 and d_hidden == 256 and n_layers == 4 and
-            multires_view == 4 and (d_out == 96 or 1 <= d_out <= 4)):
-        raise ValueError("RenderingNetwork: the HIP kernels implement mode='idr', d_feature=256, d_in=9, "
-                         "d_hidden=256, n_layers=4, multires_view=4, d_out in {1..4, 96} only")
+    """The kernels assemble [feature(256) | points(3), PE4(view)(27), normals(3)] (slots 0..288). The reference's three
+    modes (fields.py:154-158) are column selections of that input: a slot the mode leaves out maps to no weight column
+    (-1: a zero row of the image, no weight gradient, a zero input adjoint) - 'no_normal' = [points, view, feature] needs
+    multires_view = 4; 'no_view_dir' = [points, normals, feature] only exists with multires_view = 0 in the reference
+    (with an encoder its first layer is sized for view columns it is never given, fields.py:132-135 vs 156)."""
+    family = {("idr", 9, 4), ("no_normal", 6, 4), ("no_view_dir", 6, 0)}
+    if not (d_feature == 256 and (mode, d_in, multires_view) in family and d_hidden == 256 and n_layers == 4 and
+            (d_out == 96 or 1 <= d_out <= 4)):
+        raise ValueError("RenderingNetwork: the HIP kernels implement d_feature=256, d_hidden=256, n_layers=4, d_out in {1..4, 96} "
+                         "with (mode, d_in, multires_view) in %s only" % sorted(family))
     km0 = np.full(320, -1, np.int32)
-    km0[:256] = 33 + np.arange(256)      # feature vector columns
-    km0[256:289] = np.arange(33)         # points(3), PE(view)(27), normals(3)
+    if mode == "idr":
+        km0[:256] = 33 + np.arange(256)      # feature vector columns
+        km0[256:289] = np.arange(33)         # points(3), PE(view)(27), normals(3)
+    elif mode == "no_normal":
+        km0[:256] = 30 + np.arange(256)
+        km0[256:286] = np.arange(30)         # points(3), PE(view)(27); the normals' slots read nothing
+    else:
+        km0[:256] = 6 + np.arange(256)
+        km0[256:259] = np.arange(3)          # points(3)
+        km0[286:289] = 3 + np.arange(3)      # normals(3); the encoded view's slots read nothing
     layers = [dense_layer("lin0", km0, ident_map(256))]
     for l in (1, 2, 3):
         layers.append(dense_layer("lin%d" % l, ident_map(256), ident_map(256)))

@@ -288,9 +288,9 @@ class TrainEngine:
         for i, (g, v, inv, dwe, dg, dv) in enumerate(rows):
             wn[i]["g"], wn[i]["v"], wn[i]["inv_norm"], wn[i]["dw_eff"] = g.data_ptr(), v.data_ptr(), inv.data_ptr(), dwe.data_ptr()
             wn[i]["dg"], wn[i]["dv"], wn[i]["rows"], wn[i]["cols"] = dg.data_ptr(), dv.data_ptr(), v.shape[0], v.shape[1]
-        self.wn_table = torch.from_numpy(wn.view(np.uint8)).to(dev)
+        self.wn_table = torch.from_numpy(wn.view(np.uint8).copy() if len(rows) else np.zeros(8, np.uint8)).to(dev)
         self.n_wn = len(rows)
-        self.wn_max_rows = max(r[1].shape[0] for r in rows)
+        self.wn_max_rows = max([r[1].shape[0] for r in rows] + [1])
         self._param_ptrs = self._ptr_key()
 
     def _ptr_key(self):
@@ -575,7 +575,8 @@ class TrainEngine:
         self._launch_dw()
         lib.call("vdn_dw_finalize", lib.ptr(self.fin_table), self.n_dw, self.fin_max_M, 0, st)
         lib.call("vdn_dw_finalize", lib.ptr(self.fin_table), self.n_dw, self.fin_max_M, 1, st)
-        lib.call("vdn_weightnorm_bwd", lib.ptr(self.wn_table), self.n_wn, self.wn_max_rows, st)
+        if self.n_wn:
+            lib.call("vdn_weightnorm_bwd", lib.ptr(self.wn_table), self.n_wn, self.wn_max_rows, st)
         if rg:
             ra = lib.VdnRayAdjointArgs()
             ra.rays_d, ra.mid_z = rays_d.data_ptr(), w["mid_z"].data_ptr()

@@ -19,25 +19,33 @@ CONF = {
 }
 
 
-def build_renderer(wdepth=False, device="cuda", states=None, precision="fp32", **renderer_overrides):
+MODE_KW = {"idr": dict(mode="idr", d_in=9, multires_view=4), "no_normal": dict(mode="no_normal", d_in=6, multires_view=4),
+           "no_view_dir": dict(mode="no_view_dir", d_in=6, multires_view=0)}
+
+
+def build_renderer(wdepth=False, device="cuda", states=None, precision="fp32", color_mode="idr", weight_norm=True,
+                   **renderer_overrides):
     """-> NeuSRenderer with its five networks on `device`. `states`: vdn_train.synth.make_all_states()-style
-    dict of numpy arrays (checkpoint key names of dpt_runner.py:366-375)."""
+    dict of numpy arrays (checkpoint key names of dpt_runner.py:366-375), always in the shipped (idr, weight-normed)
+    form: `color_mode` / `weight_norm` select the other constructor variants of fields.py:113-176 / 10-21 and the
+    states are re-expressed for them (synth.variant_state)."""
+    from vdn_train import synth
     nerf_kw = dict(CONF["nerf"])
     if wdepth:
         nerf_kw.update(gen_depth_feats=True, dpt_dim=96)
     nerf = NeRF(**nerf_kw)
-    sdf = SDFNetwork(**CONF["sdf_network"])
+    sdf = SDFNetwork(**dict(CONF["sdf_network"], weight_norm=weight_norm))
     var = SingleVarianceNetwork(**CONF["variance_network"])
-    col = RenderingNetwork(**CONF["rendering_network"])
-    vdn = RenderingNetwork(**CONF["depth_extract_network"]) if wdepth else None
+    col = RenderingNetwork(**dict(CONF["rendering_network"], weight_norm=weight_norm, **MODE_KW[color_mode]))
+    vdn = RenderingNetwork(**dict(CONF["depth_extract_network"], weight_norm=weight_norm, **MODE_KW[color_mode])) if wdepth else None
     if states is not None:
         tt = lambda d: {k: torch.as_tensor(v) for k, v in d.items()}
         nerf.load_state_dict(tt(states["nerf"]))
-        sdf.load_state_dict(tt(states["sdf_network_fine"]))
+        sdf.load_state_dict(tt(synth.variant_state(states["sdf_network_fine"], "idr", weight_norm)))
         var.load_state_dict(tt(states["variance_network_fine"]))
-        col.load_state_dict(tt(states["color_network_fine"]))
+        col.load_state_dict(tt(synth.variant_state(states["color_network_fine"], color_mode, weight_norm)))
         if wdepth:
-            vdn.load_state_dict(tt(states["depth_network_fine"]))
+            vdn.load_state_dict(tt(synth.variant_state(states["depth_network_fine"], color_mode, weight_norm)))
     for m in (nerf, sdf, col, vdn):
         if m is not None:
             m.precision = precision          # "fp32" (parity) or "bf16" (throughput)

@@ -145,6 +145,27 @@ def make_nerf_state(seed=0, D=8, W=256, d_in=4, d_in_view=3, multires=10, multir
     return sd
 
 
+def variant_state(state, mode="idr", weight_norm=True):
+    """Re-express a weight-normed state dict (lin{l}.bias / weight_g / weight_v) for the other constructor variants of
+    the reference (fields.py:113-176): `mode` drops the first layer's columns of the input the mode leaves out
+    ('no_normal': normals, columns 30..32; 'no_view_dir': the 27 encoded view columns 3..29 - that mode only exists with
+    multires_view = 0, whose raw 3 view columns are not an input either); weight_norm=False stores the effective matrix
+    g * v / |v| under the plain nn.Linear keys (lin{l}.weight, lin{l}.bias). Deterministic: generator and tests share it."""
+    out = {}
+    layers = sorted({k.split(".")[0] for k in state})
+    for name in layers:
+        g, v, b = (np.asarray(state[name + "." + k], np.float32) for k in ("weight_g", "weight_v", "bias"))
+        if name == "lin0" and mode != "idr":
+            keep = [c for c in range(v.shape[1]) if not ((30 <= c < 33) if mode == "no_normal" else (3 <= c < 30))]
+            v = np.ascontiguousarray(v[:, keep])
+        if weight_norm:
+            out[name + ".bias"], out[name + ".weight_g"], out[name + ".weight_v"] = b, g, v
+        else:
+            out[name + ".weight"] = (g * v / np.linalg.norm(v.astype(np.float64), axis=1, keepdims=True)).astype(np.float32)
+            out[name + ".bias"] = b
+    return out
+
+
 def make_all_states(seed=0, wdepth=False, variance=0.3, dense_noise=0.02):
     """All networks of one experiment: keys mirror dpt_runner.py:366-375's checkpoint dict."""
     st = {
