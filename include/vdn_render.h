@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VDN_ABI_VERSION 9
+#define VDN_ABI_VERSION 10
 
 int vdn_abi_version(void);
 
@@ -442,6 +442,7 @@ typedef struct {
     const float* g_feat;       /* [B,C] */
     const float* g_weights;    /* [B,T] */
     const float* g_eik;        /* [1] d loss / d gradient_error */
+    const float* g_cdf;        /* [B,N] d loss / d cdf_fine (= prev_cdf, renderer.py:276,322), or NULL */
     /* outputs */
     float* d_sdf;              /* [B*N] */
     float* d_normals;          /* [B*N,3] alpha + eikonal parts */

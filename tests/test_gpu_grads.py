@@ -416,3 +416,43 @@ def test_trainer_ragged_batches(B, precision):
     tol = 2e-5 if precision == "fp32" else 2e-3          # bf16: the work lists change which rows share a dW split
     for p, gr in zip(rend._all_parameters(), got):
         assert (p.grad - gr).abs().max().item() <= tol * p.grad.abs().max().item() + 1e-12
+
+
+def test_gradients_cdf_and_s_val_outputs_are_attached(golden):
+    """renderer.py:426-439 returns `gradients`, `cdf_fine` and `s_val` with their graph; a loss built on them must
+    differentiate like the reference's (the runner's own loss does not use them)."""
+    import oracle.neus_oracle as orc
+    from vdn_train import synth, factory
+    fx = golden("white_v03_c05_det")
+    dev = torch.device("cuda:0")
+    B = int(fx["B"])
+    w1 = synth.uniform(5, "aux/w1", (B, 128, 3)).astype(np.float32) - 0.5
+    w2 = synth.uniform(5, "aux/w2", (B, 128)).astype(np.float32) - 0.5
+
+    def extra(out, tt):
+        return (out["gradients"] * tt(w1)).sum() * 0.01 + (out["cdf_fine"] * tt(w2)).sum() * 0.05 + out["s_val"].sum() * 3.0
+
+    st = synth.make_all_states(int(fx["seed"]), wdepth=False, variance=float(fx["variance"]))
+    rend = factory.build_renderer(wdepth=False, device=dev, states=st)
+    out = rend.render(g(fx["rays_o"], dev), g(fx["rays_d"], dev), g(fx["near"], dev), g(fx["far"], dev), perturb_overwrite=0,
+                      background_rgb=torch.ones(1, 3, device=dev), cos_anneal_ratio=float(fx["cos_anneal"]),
+                      z_vals_inject=g(fx["z_vals_inside"], dev))
+    assert out["gradients"].requires_grad and out["cdf_fine"].requires_grad and out["s_val"].requires_grad
+    loss = _loss(out, g(fx["true_rgb"], dev), None, False) + extra(out, lambda x: g(x, dev))
+    loss.backward()
+    named = [(k + "." + n if k != "variance" else "variance", p)
+             for k, m in (("nerf", rend.nerf), ("sdf", rend.sdf_network), ("variance", rend.deviation_network), ("color", rend.color_network))
+             for n, p in m.named_parameters()]
+    refs = []
+    for dtype in (torch.float64, torch.float32):
+        nets = orc.nets_from_numpy(st, dtype=dtype, requires_grad=True)
+        tt = lambda x: torch.tensor(np.asarray(x), dtype=dtype)
+        oo = orc.render(nets, tt(fx["rays_o"]), tt(fx["rays_d"]), tt(fx["near"]), tt(fx["far"]), orc.RendererConf(n_importance=64),
+                        perturb_overwrite=0, background_rgb=torch.ones(1, 3, dtype=dtype), cos_anneal_ratio=float(fx["cos_anneal"]),
+                        z_vals_inject=tt(fx["z_vals_inside"]))
+        lo = _loss(oo, tt(fx["true_rgb"]), None, False) + extra(oo, tt)
+        pn = orc.all_params(nets)
+        gs = torch.autograd.grad(lo, [p for _, p in pn], allow_unused=True)
+        refs.append((lo.item(), {n: (torch.zeros_like(p) if gr is None else gr).detach() for (n, p), gr in zip(pn, gs)}))
+    assert abs(loss.item() - refs[0][0]) < 5e-5 * abs(refs[0][0])
+    _compare(named, refs[0][1], 1e-4, refs[1][1])

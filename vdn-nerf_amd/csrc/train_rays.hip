@@ -165,7 +165,8 @@ __global__ __launch_bounds__(kRW * 64) void composite_bwd_kernel(CompositeBwdArg
             const float pc = sigmoidf_(ep * inv_s), nc = sigmoidf_(en * inv_s);
             const float raw = ((pc - nc) + 1e-5f) / (pc + 1e-5f);
             const float graw = (raw >= 0.0f && raw <= 1.0f) ? da_in : 0.0f;
-            const float dpc = graw * (nc / ((pc + 1e-5f) * (pc + 1e-5f)));
+            float dpc = graw * (nc / ((pc + 1e-5f) * (pc + 1e-5f)));
+            if (a.g_cdf != nullptr) dpc += a.g_cdf[q];           // cdf_fine is prev_cdf itself (renderer.py:276, 322)
             const float dnc = -graw / (pc + 1e-5f);
             const float dzp = dpc * pc * (1.0f - pc), dzn = dnc * nc * (1.0f - nc);    // wrt ep*s, en*s
             const float dep = dzp * inv_s, den = dzn * inv_s;

@@ -88,23 +88,26 @@ class _RenderCoreFn(torch.autograd.Function):
         # differentiable rays (learnable poses, poses.py:198-208): the backward then also returns d loss / d rays_o, rays_d
         # and d loss / d z, d z_out (render() chains the latter to near / far)
         ctx.ray_grads = any(ctx.needs_input_grad[1:5])
+        ctx.set_materialize_grads(False)          # unused outputs (cdf_fine, gradients ...) arrive as None, not as zero tensors
         w = engine.forward(rays_o, rays_d, z, z_out, bgc, car, ray_grads=ctx.ray_grads)
         ctx.engine, ctx.generation, ctx.n_params = engine, engine.generation, len(params)
         color, weights, eik = w["color"].clone(), w["weights"].clone(), w["eik"][0].clone()
         feats = w["feat_out"].clone() if w["feat_out"] is not None else color.new_zeros(0)
-        aux = (w["cdf"].clone(), w["inside"].clone(), w["normals"].view(engine.B, engine.N, 3).clone(), w["s_val"].clone(),
+        # cdf_fine and gradients stay attached as in the reference (renderer.py:426-439; its own loss never uses them)
+        cdf, normals = w["cdf"].clone(), w["normals"].view(engine.B, engine.N, 3).clone()
+        aux = (w["inside"].clone(), w["s_val"].clone(),
                (w["bg_mid"] if engine.r.n_outside > 0 else w["mid_z"]).clone(), w["eik"][1:3].clone())
         ctx.mark_non_differentiable(*aux)
-        return (color, feats, weights, eik) + aux
+        return (color, feats, weights, eik, cdf, normals) + aux
 
     @staticmethod
-    def backward(ctx, g_color, g_feats, g_weights, g_eik, *unused):
+    def backward(ctx, g_color, g_feats, g_weights, g_eik, g_cdf, g_normals, *unused):
         eng = ctx.engine
         if eng.generation != ctx.generation:
             raise RuntimeError("NeuSRenderer.render was called again before this result's backward(): the training "
                                "engine keeps the activations of the latest forward only")
         g_feats = g_feats if (g_feats is not None and g_feats.numel() > 0) else None
-        eng.backward(g_color, g_feats, g_weights, g_eik)
+        eng.backward(g_color, g_feats, g_weights, g_eik, g_cdf=g_cdf, g_gradients=g_normals)
         flat = eng.param_grads(clone=True)        # clones: the engine's buffers are reused by the next step
         assert len(flat) == ctx.n_params
         rays = (None,) * 4
@@ -363,9 +366,15 @@ class NeuSRenderer:
             if bgc.numel() != 3:
                 raise ValueError("background_rgb must have 3 values")
         z = z.contiguous()
-        color, feats, weights, eik, cdf, inside, normals, s_val, z_ret, eik_terms = _RenderCoreFn.apply(
+        color, feats, weights, eik, cdf, normals, inside, s_val, z_ret, eik_terms = _RenderCoreFn.apply(
             eng, rays_o, rays_d, z, z_out, bgc, float(cos_anneal_ratio), *params)
         self.last_eikonal_terms = eik_terms
+        var = self.deviation_network.variance
+        if var.requires_grad:
+            # s_val = mean over the samples of 1 / inv_s (renderer.py:324, 420): a function of the variance parameter alone
+            inv_s = torch.exp(var * 10.0).clip(1e-6, 1e6)
+            s_graph = (1.0 / inv_s).reshape(1, 1).expand(B, 1)
+            s_val = s_val + (s_graph - s_graph.detach())
         return {
             "render_feats": feats if self.depth_network is not None else None,
             "color_fine": color,

@@ -479,14 +479,18 @@ class TrainEngine:
         return c
 
     # ------------------------------------------------------------------------------------------
-    def backward(self, g_color, g_feat, g_weights, g_eik):
-        """Upstream grads (any may be None) -> list of parameter grads (clones) per network."""
+    def backward(self, g_color, g_feat, g_weights, g_eik, g_cdf=None, g_gradients=None):
+        """Upstream grads (any may be None) -> list of parameter grads (clones) per network. g_cdf [B,N] / g_gradients
+        [B,N,3]: adjoints of the `cdf_fine` / `gradients` outputs (the reference returns them attached, renderer.py:426-439)."""
         r, w, st = self.r, self.w, _stream()
         rays_o, rays_d, background_rgb, car, z = self._ctx
         c = self._composite_common(lib.VdnCompositeBwdArgs(), rays_o, rays_d, background_rgb, car)
         c.alpha, c.weights, c.eik = w["alpha"].data_ptr(), w["weights"].data_ptr(), w["eik"].data_ptr()
-        keep = [t.contiguous() if t is not None else None for t in (g_color, g_feat, g_weights, g_eik)]
-        g_color, g_feat, g_weights, g_eik = keep
+        keep = [t.contiguous() if t is not None else None for t in (g_color, g_feat, g_weights, g_eik, g_cdf, g_gradients)]
+        g_color, g_feat, g_weights, g_eik, g_cdf, g_gradients = keep
+        if (g_cdf is not None or g_gradients is not None) and self._fg_compact:
+            raise ValueError("adjoints of cdf_fine / gradients need every inside sample evaluated (skip_far=False)")
+        c.g_cdf = g_cdf.data_ptr() if g_cdf is not None else None
         c.g_color = g_color.data_ptr() if g_color is not None else None
         c.g_feat = g_feat.data_ptr() if (g_feat is not None and self.wdepth) else None
         c.g_weights = g_weights.data_ptr() if g_weights is not None else None
@@ -511,6 +515,8 @@ class TrainEngine:
             if r.n_outside > 0:
                 c.d_bg_dists = w["d_bg_dists"].data_ptr()
         lib.call("vdn_alpha_composite_bwd", c, st)
+        if g_gradients is not None:              # `gradients` is the SDF normal itself: its adjoint joins the alpha / eikonal parts
+            w["d_normals"].add_(g_gradients.reshape(self.P, 3))
         if r.n_outside > 0:                      # NeRF backward on the side stream, beside the heads' and the SDF backward
             nb = lib.VdnNerfBwdArgs()
             nb.blob = self.nets["nerf"].img.blobs["bwd"].data_ptr()
