@@ -102,6 +102,11 @@ def test_bf16_trained_weights_render_the_same_on_the_fp32_kernels():
     from vdn_train.trainer import Trainer
     dev = torch.device("cuda:0")
     B, seed, steps = 512, 0, 2000
+    # Seeded: the geometric init and the per-ray jitter come from torch's generators, and whether the variance takes off within
+    # 2 000 steps of this scene depends on the draw - 5 of 32 seeds stay at inv_s ~ 20 (tests/probes/inv_s_growth.py), on
+    # the fp32 kernels exactly as on the bf16 ones (same seeds, same trajectories), so it is the optimisation's basin, not
+    # the precision. With a fixed seed the run is bit-reproducible across processes (same probe).
+    torch.manual_seed(0)
     rend = factory.build_renderer(device=dev, precision="bf16")          # the reference's geometric init
     tr = Trainer(rend, B, dev, conf=dict(warm_up_end=200, end_iter=steps, anneal_end=steps // 4))
     cams = synth.make_cameras(seed)
