@@ -183,3 +183,51 @@ def test_ray_gradients_vs_reference_autograd(golden, tag):
         got = np.zeros_like(ref) if x.grad is None else x.grad.detach().cpu().numpy()
         scale = np.abs(ref).max()
         assert np.abs(got - ref).max() <= tol * scale + 1e-12, (nm, np.abs(got - ref).max(), scale)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_pose_refinement_recovers_a_perturbed_camera(precision):
+    """What the learnable poses are for (the reference's `*_learn_*` runs): with the networks frozen, targets rendered from the
+    true camera and a LearnPose that starts at the unperturbed initial pose, Adam on (r, t) through the ray adjoint finds the
+    true camera (tests/probes/pose_refine.py prints the trajectory)."""
+    from vdn_train import synth, factory
+    from dpt_models.poses import LearnPose
+    from dpt_models.lie_group_helper import make_c2w
+    dev = torch.device("cuda:0")
+    seed, B, steps, cam = 0, 512, 200, 2
+    st = synth.make_all_states(seed, wdepth=False, variance=0.3)
+    rend = factory.build_renderer(device=dev, states=st, precision=precision)
+    for p in rend._all_parameters():
+        p.requires_grad_(False)
+    cams = torch.tensor(np.asarray(synth.make_cameras(seed)[:4], np.float32)).to(dev)
+    Kinv = torch.tensor(synth.intrinsics_inv().astype(np.float32)).to(dev)
+    pose_net = LearnPose(4, True, True, init_c2w=cams.clone()).to(dev)
+    true_r, true_t = torch.tensor([0.02, -0.015, 0.01], device=dev), torch.tensor([0.05, -0.04, 0.03], device=dev)
+    true_pose = make_c2w(true_r, true_t) @ cams[cam]
+
+    def rays(pose, px, py):
+        p = torch.matmul(Kinv[None], torch.stack([px, py, torch.ones_like(py)], dim=-1)[:, :, None]).squeeze(-1)
+        v = torch.matmul(pose[None, :3, :3], (p / torch.linalg.norm(p, ord=2, dim=-1, keepdim=True))[:, :, None]).squeeze(-1)
+        o = pose[None, :3, 3].expand(v.shape)
+        mid = 0.5 * (-(2.0 * (o * v).sum(-1, keepdim=True))) / (v * v).sum(-1, keepdim=True)        # dataset.py:111-118
+        return o, v, mid - 1.0, mid + 1.0
+
+    kw = dict(perturb_overwrite=0, background_rgb=torch.ones(1, 3, device=dev), cos_anneal_ratio=1.0)
+    opt = torch.optim.Adam([pose_net.r, pose_net.t], lr=2e-3)
+    gen = torch.Generator(device="cpu").manual_seed(1)
+    err0 = (true_r.norm().item(), true_t.norm().item())
+    first = None
+    for it in range(steps):
+        px = (torch.rand(B, generator=gen) * 500 + 150).floor().to(dev)
+        py = (torch.rand(B, generator=gen) * 500 + 150).floor().to(dev)
+        with torch.no_grad():
+            target = rend.render(*rays(true_pose, px, py), **kw)["color_fine"]
+        loss = (rend.render(*rays(pose_net(cam), px, py), **kw)["color_fine"] - target).abs().mean()
+        first = loss.item() if first is None else first
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    er = (pose_net.r[cam].detach() - true_r).norm().item()
+    et = (pose_net.t[cam].detach() - true_t).norm().item()
+    assert loss.item() < 0.05 * first and er < 0.1 * err0[0] and et < 0.1 * err0[1], (first, loss.item(), er, et, err0)
+    assert pose_net.r.grad[0].abs().max() == 0 and pose_net.t.grad[3].abs().max() == 0
