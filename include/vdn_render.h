@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VDN_ABI_VERSION 10
+#define VDN_ABI_VERSION 11
 
 int vdn_abi_version(void);
 
@@ -128,6 +128,10 @@ typedef struct {
      * are addressed by the dense point id, training saves and deltas by the compact row */
     const int32_t* active_idx;
     const int32_t* n_active;
+    /* optional: 96 more feature columns appended to the feature vector - render(depth_before_color=True) feeds the colour
+     * network cat([feature_vector, VDN output]) (renderer.py:247-248; a d_feature = 352 network, blob with a 13-k-tile first layer) */
+    const float* extra;        /* [P,96] dense point id, or NULL */
+    void* save_extra;          /* [P,96] plane of `extra` for the weight-gradient GEMM (training) or NULL */
 } VdnRenderNetArgs;
 int vdn_rendernet_fwd_f32(const VdnRenderNetArgs* args_host, void* stream);
 int vdn_rendernet_fwd_bf16(const VdnRenderNetArgs* args_host, void* stream);   /* bf16-MFMA variant: bf16 chunk blob, bf16 activation workspaces */
@@ -286,6 +290,9 @@ typedef struct {
     int32_t acc_pts;           /* 0: overwrite d_pts / d_dirs, 1: add into them */
     float* d_pts;              /* [P,3] dense point id, or NULL */
     float* d_dirs;             /* [P,3] or NULL */
+    /* d_feature = 352 network (VdnRenderNetArgs.extra): d loss / d extra is ADDED into d_extra (the VDN head's output adjoint,
+     * which the compositor wrote first) */
+    float* d_extra;            /* [P,96] dense point id, or NULL for the 256-feature network */
 } VdnRenderNetBwdArgs;
 int vdn_rendernet_bwd_f32(const VdnRenderNetBwdArgs* args_host, void* stream);
 int vdn_rendernet_bwd_bf16(const VdnRenderNetBwdArgs* args_host, void* stream);   /* bf16-MFMA variant: bf16 chunk blob, bf16 activation workspaces */

@@ -69,7 +69,8 @@ MODE_KW = {"idr": dict(mode="idr", d_in=9, multires_view=4), "no_normal": dict(m
            "no_view_dir": dict(mode="no_view_dir", d_in=6, multires_view=0)}
 
 
-def build_reference(fields, renderer, states, wdepth, dtype, n_importance=64, n_outside=32, color_mode="idr", weight_norm=True):
+def build_reference(fields, renderer, states, wdepth, dtype, n_importance=64, n_outside=32, color_mode="idr", weight_norm=True,
+                    depth_before_color=False):
     from vdn_train import synth
     tt = lambda d: {k: torch.tensor(v, dtype=dtype) for k, v in d.items()}
     vs = lambda key, mode: synth.variant_state(states[key], mode, weight_norm)
@@ -78,8 +79,8 @@ def build_reference(fields, renderer, states, wdepth, dtype, n_importance=64, n_
     sdf = fields.SDFNetwork(d_out=257, d_in=3, d_hidden=256, n_layers=8, skip_in=[4], multires=6, bias=0.5,
                             scale=1.0, geometric_init=True, weight_norm=weight_norm).to(dtype)
     var = fields.SingleVarianceNetwork(init_val=0.3).to(dtype)
-    col = fields.RenderingNetwork(d_feature=256, d_out=3, d_hidden=256, n_layers=4, weight_norm=weight_norm, squeeze_out=True,
-                                  **MODE_KW[color_mode]).to(dtype)
+    col = fields.RenderingNetwork(d_feature=352 if depth_before_color else 256, d_out=3, d_hidden=256, n_layers=4,
+                                  weight_norm=weight_norm, squeeze_out=True, **MODE_KW[color_mode]).to(dtype)
     vdn = None
     if wdepth:
         vdn = fields.RenderingNetwork(d_feature=256, d_out=96, d_hidden=256, n_layers=4, weight_norm=weight_norm, squeeze_out=True,
@@ -135,8 +136,9 @@ def run_case(fields, renderer, name, seed, B, wdepth, variance, cos_anneal, pert
     from vdn_train import synth
     import oracle.neus_oracle as orc
     torch.set_default_dtype(dtype)
-    states = synth.make_all_states(seed, wdepth=wdepth, variance=variance)
-    rend = build_reference(fields, renderer, states, wdepth, dtype, n_importance=n_importance, color_mode=color_mode, weight_norm=weight_norm)
+    states = synth.make_all_states(seed, wdepth=wdepth, variance=variance, depth_before_color=depth_before_color)
+    rend = build_reference(fields, renderer, states, wdepth, dtype, n_importance=n_importance, color_mode=color_mode, weight_norm=weight_norm,
+                           depth_before_color=depth_before_color)
     o, d, near, far = make_rays(seed, B)
     t_rand, t_rand_out = synth.jitter(seed, 0, B)
     tt = lambda x: torch.tensor(x, dtype=dtype)
@@ -190,6 +192,8 @@ def run_case(fields, renderer, name, seed, B, wdepth, variance, cos_anneal, pert
             fx["grad_idx/" + n] = idx
             fx["grad_val/" + n] = gf[idx].numpy()
     fx["z_vals_inside"] = captured["z"].numpy()          # the REFERENCE's inside z (input of render_core)
+    if depth_before_color:
+        fx["depth_before_color"] = True
     if color_mode != "idr" or not weight_norm:
         fx["color_mode"], fx["weight_norm"] = color_mode, weight_norm
         # constructor variants outside the shipped configurations: the oracle restates the shipped ones only; the fixture is
@@ -399,6 +403,8 @@ CASES = [
     # constructor variants no shipped configuration uses (fields.py:154-158, 65-66 / 141-142)
     ("white_nonormal_plain", 10, 16, False, 0.3, 0.5, 1.0, {"color_mode": "no_normal", "weight_norm": False}),
     ("wdepth_noviewdir", 11, 12, True, 0.3, 0.5, 1.0, {"color_mode": "no_view_dir"}),
+    # renderer.py:247-248: the colour network fed cat([feature_vector, VDN output]) (no shipped configuration sets it)
+    ("wdepth_dbc", 12, 12, True, 0.3, 0.5, 1.0, {"depth_before_color": True}),
 ]
 F64_COMPANIONS = ("white_v03_c0", "white_v065_c1", "wdepth_v065_c1")
 

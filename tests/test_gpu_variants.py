@@ -102,3 +102,52 @@ def test_variant_modules_standalone_forward(golden):
     assert relmax(sdf_p.gradient(pts).cpu().numpy(), sdf_w.gradient(pts).cpu().numpy()) < 2e-6
     with pytest.raises(ValueError):
         RenderingNetwork(d_feature=256, mode="no_view_dir", d_in=6, d_out=3, d_hidden=256, n_layers=4, multires_view=4).to(dev)(pts, nrm, dirs, feat)
+
+
+def test_depth_before_color_vs_reference_and_oracle(golden):
+    """render(depth_before_color=True) (renderer.py:247-248): the colour network is a d_feature = 352 one, fed
+    cat([feature_vector, VDN output]); its input adjoint w.r.t. the VDN channels joins the VDN head's output adjoint.
+    Outputs vs the reference (tests/golden/wdepth_dbc.npz), every parameter gradient vs the fp64 oracle's autograd."""
+    import oracle.neus_oracle as orc
+    from vdn_train import synth, factory
+    from test_gpu_grads import _compare
+    fx = golden("wdepth_dbc")
+    dev = torch.device("cuda:0")
+    st = synth.make_all_states(int(fx["seed"]), wdepth=True, variance=float(fx["variance"]), depth_before_color=True)
+    rend = factory.build_renderer(wdepth=True, device=dev, states=st, depth_before_color=True)
+    kw = dict(perturb_overwrite=-1, background_rgb=torch.ones(1, 3, device=dev), cos_anneal_ratio=float(fx["cos_anneal"]),
+              t_rand=g(fx["t_rand"], dev), t_rand_out=g(fx["t_rand_out"], dev), depth_before_color=True)
+    rays = [g(fx[k], dev) for k in ("rays_o", "rays_d", "near", "far")]
+    with pytest.raises(ValueError):
+        rend.render(*rays, **dict(kw, depth_before_color=False))
+    with torch.no_grad():
+        out = rend.render(*rays, **kw)
+    for k in ("color_fine", "render_feats", "weight_sum", "gradient_error"):
+        assert relmax(out[k].cpu().numpy(), fx["out_" + k]) < 1e-4, k
+    out = rend.render(*rays, z_vals_inject=g(fx["z_vals_inside"], dev), **kw)
+    for k in ("weights", "gradients", "color_fine", "render_feats"):
+        assert relmax(out[k].detach().cpu().numpy(), fx["out_" + k]) < 1e-4, k
+    loss = _loss(out, g(fx["true_rgb"], dev), g(fx["gt_feats"], dev), True)
+    assert abs(loss.item() - float(fx["loss"])) < 2e-5 * abs(float(fx["loss"]))
+    loss.backward()
+    named = [(k + "." + n if k != "variance" else "variance", p)
+             for k, m in (("nerf", rend.nerf), ("sdf", rend.sdf_network), ("variance", rend.deviation_network), ("color", rend.color_network),
+                          ("vdn", rend.depth_network)) for n, p in m.named_parameters()]
+    refs = []
+    for dtype in (torch.float64, torch.float32):
+        nets = orc.nets_from_numpy(st, dtype=dtype, requires_grad=True)
+        tt = lambda x: torch.tensor(np.asarray(x), dtype=dtype)
+        oo = orc.render(nets, tt(fx["rays_o"]), tt(fx["rays_d"]), tt(fx["near"]), tt(fx["far"]), orc.RendererConf(n_importance=64),
+                        perturb_overwrite=-1, background_rgb=torch.ones(1, 3, dtype=dtype), cos_anneal_ratio=float(fx["cos_anneal"]),
+                        depth_before_color=True, t_rand=tt(fx["t_rand"]), t_rand_out=tt(fx["t_rand_out"]), z_vals_inject=tt(fx["z_vals_inside"]))
+        lo = _loss(oo, tt(fx["true_rgb"]), tt(fx["gt_feats"]), True)
+        pn = orc.all_params(nets)
+        gs = torch.autograd.grad(lo, [p for _, p in pn], allow_unused=True)
+        refs.append({n: (torch.zeros_like(p) if gr is None else gr).detach() for (n, p), gr in zip(pn, gs)})
+    _compare(named, refs[0], 1e-4, refs[1])
+    # the throughput path takes the same route
+    rb = factory.build_renderer(wdepth=True, device=dev, states=st, depth_before_color=True, precision="bf16")
+    with torch.no_grad():
+        ob = rb.render(*rays, z_vals_inject=g(fx["z_vals_inside"], dev), **kw)
+    mse = ((ob["color_fine"].cpu() - torch.tensor(fx["out_color_fine"])) ** 2).mean().item()
+    assert 10.0 * np.log10(1.0 / max(mse, 1e-20)) > 40.0

@@ -8,13 +8,13 @@
 
 namespace vdn {
 
-template <class P, int NT_OUT>
+template <class P, int NT_OUT, int EX = 0>      // EX: extra input tiles of the d_feature = 352 network (k_render_fwd.h)
 __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_bwd_kernel(RenderNetBwdArgs a) {
     using ST = typename P::store_t;
     constexpr int kSlot = P::stride(8);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     WStream<P::kWaves, kSlot> ws;
-    ws.init(a.blob, smem, 42);
+    ws.init(a.blob, smem, 42 + EX);
     const int lane = ws.lane, c = lane & 31, h = lane >> 5;
     const WorkRow wr = work_row(a.active_idx, a.n_active, a.P, P::kWaves, ws.wave, c);
     if (wr.none) return;
@@ -70,8 +70,15 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_b
     dense<P, 8, 8, false>(ws, X, 0, ldH(1), mask_store(Y, 1), 4, 4);        // W2^T
     dense<P, 8, 8, false>(ws, Y, 0, ldH(0), mask_store(X, 0), 4, 4);        // W1^T
     f32x16 SM[2];
-    dense<P, 8, 10, false>(ws, X, 0, NoPre{}, [&](int nt, const f32x16& acc, int) VDN_INL {   // W0^T
-        if (nt < 8) {
+    dense<P, 8, 10 + EX, false>(ws, X, 0, NoPre{}, [&](int nt, const f32x16& acc, int) VDN_INL {   // W0^T
+        if (nt >= 10) {
+            if constexpr (EX > 0) {         // adjoint of the appended VDN channels: joins the VDN head's output adjoint
+                f32x16 o = F32::load_tile(a.d_extra, pd, 32 * EX, nt - 10, h);
+#pragma unroll
+                for (int t = 0; t < 16; ++t) o[t] += acc[t];
+                F32::store_tile(a.d_extra, pd, 32 * EX, nt - 10, h, o, ok);
+            }
+        } else if (nt < 8) {
             f32x16 o = acc;
             if (a.acc_feat) {
                 const f32x16 prev = P::load_tile(d_feat, p, 256, nt, h);
@@ -125,8 +132,14 @@ int launch_rendernet_bwd(const VdnRenderNetBwdArgs* args, void* stream_) {
     const int ppw = P::kWaves * 32;
     const int grid = (args->P + ppw - 1) / ppw;
     const size_t lds = 3 * P::stride(8);
-    static bool once = (allow_big_lds(rendernet_bwd_kernel<P, 1>, lds), allow_big_lds(rendernet_bwd_kernel<P, 3>, lds), true);
+    static bool once = (allow_big_lds(rendernet_bwd_kernel<P, 1>, lds), allow_big_lds(rendernet_bwd_kernel<P, 3>, lds),
+                        allow_big_lds(rendernet_bwd_kernel<P, 1, 3>, lds), true);
     (void)once;
+    if (args->d_extra != nullptr) {
+        if (args->d_out == 96) return -4;
+        hipLaunchKernelGGL((rendernet_bwd_kernel<P, 1, 3>), dim3(grid), dim3(P::kWaves * 64), lds, stream, *args);
+        return (int)hipGetLastError();
+    }
     if (args->d_out == 96)
         hipLaunchKernelGGL((rendernet_bwd_kernel<P, 3>), dim3(grid), dim3(P::kWaves * 64), lds, stream, *args);
     else

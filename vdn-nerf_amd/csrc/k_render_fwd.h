@@ -9,12 +9,14 @@
 
 namespace vdn {
 
-template <class P, int NT_OUT>   // 1: d_out <= 4 (colour); 3: d_out = 96 (VDN head)
+// EX: extra feature tiles behind the 10 standard input tiles (3 = the 96 VDN channels of depth_before_color, renderer.py:247-248)
+template <class P, int NT_OUT, int EX = 0>   // NT_OUT 1: d_out <= 4 (colour); 3: d_out = 96 (VDN head)
 __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_fwd_kernel(RenderNetArgs a) {
     using ST = typename P::store_t;
-    constexpr int kSlot = P::stride(10);
+    constexpr int kSlot = P::stride(10 + EX);
+    constexpr int kNSlot = 3 * kSlot > 160 * 1024 ? 2 : 3;      // the 13-k-tile f32 chunks are 56 KiB: two ring slots
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    WStream<P::kWaves, kSlot> ws;
+    WStream<P::kWaves, kSlot, kNSlot> ws;
     ws.init(a.blob, smem, 32 + NT_OUT);
     const int lane = ws.lane, c = lane & 31, h = lane >> 5;
     const WorkRow wr = work_row(a.active_idx, a.n_active, a.P, P::kWaves, ws.wave, c);
@@ -27,10 +29,18 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_f
     ST* save_small = reinterpret_cast<ST*>(a.save_small);
     const long PS = P::plane(a.P, 256);
 
-    typename P::template Act<10> X;
+    typename P::template Act<10 + EX> X;
     typename P::template Act<8> Y;
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt) X.set(kt, P::load_tile(feat, p, 256, kt, h));
+    if constexpr (EX > 0) {
+#pragma unroll
+        for (int kt = 0; kt < EX; ++kt) {
+            const f32x16 t16 = F32::load_tile(a.extra, pd, 32 * EX, kt, h);
+            X.set(10 + kt, t16);
+            if (a.save_extra != nullptr) P::store_tile(reinterpret_cast<ST*>(a.save_extra), p, 32 * EX, kt, h, t16, ok);
+        }
+    }
     {
         float small[33];
         float dir[3];
@@ -64,7 +74,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_f
     const int est = save_h != nullptr ? 4 : 0;
     ws.all_issue = __any(ok);
     ws.start();
-    dense<P, 10, 8, true>(ws, X, 0, NoPre{}, relu_into(Y, 0), est);
+    dense<P, 10 + EX, 8, true>(ws, X, 0, NoPre{}, relu_into(Y, 0), est);
     dense<P, 8, 8, true>(ws, Y, 0, NoPre{}, relu_into(X, 1), est);
     dense<P, 8, 8, true>(ws, X, 0, NoPre{}, relu_into(Y, 2), est);
     dense<P, 8, 8, true>(ws, Y, 0, NoPre{}, relu_into(X, 3), est);
@@ -91,6 +101,14 @@ int launch_rendernet_fwd(const VdnRenderNetArgs* args, void* stream_) {
     if (!(args->d_out == 96 || (args->d_out >= 1 && args->d_out <= 4))) return -2;
     const int ppw = P::kWaves * 32;
     const int grid = (args->P + ppw - 1) / ppw;
+    if (args->extra != nullptr) {
+        if (args->d_out == 96) return -3;          // only the colour head takes the VDN channels
+        const size_t lds3 = (3 * P::stride(13) > 160 * 1024 ? 2 : 3) * P::stride(13);
+        static bool once3 = (allow_big_lds(rendernet_fwd_kernel<P, 1, 3>, lds3), true);
+        (void)once3;
+        hipLaunchKernelGGL((rendernet_fwd_kernel<P, 1, 3>), dim3(grid), dim3(P::kWaves * 64), lds3, stream, *args);
+        return (int)hipGetLastError();
+    }
     const size_t lds = 3 * P::stride(10);
     static bool once = (allow_big_lds(rendernet_fwd_kernel<P, 1>, lds), allow_big_lds(rendernet_fwd_kernel<P, 3>, lds), true);
     (void)once;

@@ -214,9 +214,15 @@ class RenderingNetwork(_HipNet):
     def _streams(self):
         return images.rendering_streams(**self.conf)
 
-    def _run(self, normals, feat, pts=None, dirs=None, rays=None):
+    def _run(self, normals, feat, pts=None, dirs=None, rays=None, extra=None):
+        """`extra` [P,96]: the VDN channels appended to the feature vector (d_feature = 352, renderer.py:247-248)."""
+        if (extra is not None) != (self.conf["d_feature"] == 352):
+            raise ValueError("a d_feature = %d network %s the 96 appended VDN channels" %
+                             (self.conf["d_feature"], "needs" if extra is None else "does not take"))
         img = self._images()
         a = lib.VdnRenderNetArgs()
+        if extra is not None:
+            a.extra = extra.data_ptr()
         P, dev = normals.shape[0], normals.device
         a.blob = img.blobs["fwd"].data_ptr()
         a.normals, a.feat = normals.data_ptr(), feat.data_ptr()
@@ -236,10 +242,14 @@ class RenderingNetwork(_HipNet):
             _require_gpu(t, "RenderingNetwork " + n)
         if points.shape[0] == 0:
             return points.new_zeros(0, self.conf["d_out"])
-        fv = feature_vectors.detach().contiguous()
+        fv = feature_vectors.detach()
+        extra = None
+        if self.conf["d_feature"] == 352:
+            fv, extra = fv[:, :256], fv[:, 256:].contiguous()
+        fv = fv.contiguous()
         if self.precision == "bf16":
             fv = layout.to_pt32(fv)
-        return self._run(normals.detach().contiguous(), fv, pts=points.detach().contiguous(), dirs=view_dirs.detach().contiguous())
+        return self._run(normals.detach().contiguous(), fv, pts=points.detach().contiguous(), dirs=view_dirs.detach().contiguous(), extra=extra)
 
 
 class NeRF(_HipNet):

@@ -225,9 +225,11 @@ class NeuSRenderer:
                depth_before_color=False, t_rand=None, t_rand_out=None, z_vals_inject=None):
         for t, n in ((rays_o, "rays_o"), (rays_d, "rays_d"), (near, "near"), (far, "far")):
             _require_gpu(t, "NeuSRenderer.render " + n)
-        if depth_before_color:
-            raise ValueError("depth_before_color=True (352-wide colour-net feature) is not used by any shipped "
-                             "configuration and has no kernel")
+        if depth_before_color and self.depth_network is None:
+            depth_before_color = False               # renderer.py:245-248: only inside `if self.depth_network is not None`
+        if bool(depth_before_color) != (self.color_network.conf["d_feature"] == 352):
+            raise ValueError("depth_before_color=%s needs a colour network with d_feature = %d (renderer.py:247-248: it is fed "
+                             "cat([feature_vector, VDN output]))" % (bool(depth_before_color), 352 if depth_before_color else 256))
         if rays_o.dim() != 2 or rays_o.shape[1] != 3 or rays_d.shape != rays_o.shape:
             raise ValueError("rays_o / rays_d must be [B,3]")
         B, dev = rays_o.shape[0], rays_o.device
@@ -272,7 +274,8 @@ class NeuSRenderer:
         sampled_feat = None
         if self.depth_network is not None:                                       # renderer.py:245-249
             sampled_feat = self.depth_network._run(normals, feat, rays=(rays_o, rays_d, mid_z))
-        sampled_color = self.color_network._run(normals, feat, rays=(rays_o, rays_d, mid_z))        # renderer.py:251
+        sampled_color = self.color_network._run(normals, feat, rays=(rays_o, rays_d, mid_z),        # renderer.py:247-251
+                                                extra=sampled_feat if depth_before_color else None)
 
         a = lib.VdnCompositeArgs()
         f32 = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)

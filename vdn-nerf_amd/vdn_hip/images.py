@@ -315,11 +315,15 @@ def rendering_streams(d_feature, mode, d_in, d_out, d_hidden, n_layers, multires
     multires_view = 4; 'no_view_dir' = [points, normals, feature] only exists with multires_view = 0 in the reference
     (with an encoder its first layer is sized for view columns it is never given, fields.py:132-135 vs 156)."""
     family = {("idr", 9, 4), ("no_normal", 6, 4), ("no_view_dir", 6, 0)}
-    if not (d_feature == 256 and (mode, d_in, multires_view) in family and d_hidden == 256 and n_layers == 4 and
-            (d_out == 96 or 1 <= d_out <= 4)):
-        raise ValueError("RenderingNetwork: the HIP kernels implement d_feature=256, d_hidden=256, n_layers=4, d_out in {1..4, 96} "
-                         "with (mode, d_in, multires_view) in %s only" % sorted(family))
-    km0 = np.full(320, -1, np.int32)
+    # d_feature = 352: the colour network of render(depth_before_color=True), fed cat([feature_vector, VDN output])
+    # (renderer.py:247-248): 3 more input tiles behind the standard 10, weight columns behind the 256 feature columns
+    if not (d_feature in (256, 352) and (mode, d_in, multires_view) in family and d_hidden == 256 and n_layers == 4 and
+            (d_out == 96 or 1 <= d_out <= 4) and not (d_feature == 352 and d_out == 96)):
+        raise ValueError("RenderingNetwork: the HIP kernels implement d_feature in {256, 352 (d_out <= 4)}, d_hidden=256, n_layers=4, "
+                         "d_out in {1..4, 96} with (mode, d_in, multires_view) in %s only" % sorted(family))
+    km0 = np.full(320 if d_feature == 256 else 416, -1, np.int32)
+    if d_feature == 352:
+        km0[320:416] = ((d_in - 3 + 27) if multires_view else d_in) + 256 + np.arange(96)
     if mode == "idr":
         km0[:256] = 33 + np.arange(256)      # feature vector columns
         km0[256:289] = np.arange(33)         # points(3), PE(view)(27), normals(3)

@@ -60,6 +60,10 @@ class TrainEngine:
         self.P = B * self.N
         self.Q = B * self.T
         self.wdepth = renderer.depth_network is not None
+        # render(depth_before_color=True): the colour network is a d_feature = 352 one, fed the VDN head's output too
+        self.dbc = renderer.color_network.conf["d_feature"] == 352
+        if self.dbc and not self.wdepth:
+            raise ValueError("a d_feature = 352 colour network needs a depth_network (renderer.py:245-248)")
         # The background network runs on a side stream beside the SDF kernels (VDN_SIDE_STREAM=0 puts everything on the caller's
         # stream, e.g. for a rocprof kernel trace: concurrent kernels inflate each other's durations there). It pays since the
         # bf16 SDF kernel runs one 128-point workgroup per CU: a work list of ~50 K rows is 1.5 rounds of workgroups, and the
@@ -98,6 +102,8 @@ class TrainEngine:
         w["col_out"], w["col_h"], w["col_small"] = fz(P, 3), fs(4, Pp, 256), fs(Pp, 64)
         if self.wdepth:
             w["vdn_out"], w["vdn_h"], w["vdn_small"] = fz(P, 96), fs(4, Pp, 256), fs(Pp, 64)
+        if self.dbc:
+            w["col_extra"] = fs(Pp, 96)
         if O > 0:
             w["z_feed"], w["bg_dists"], w["bg_mid"] = f(B, T), f(B, T), f(B, T)
             # zero-initialised: points the active list skips keep finite values (the compositor multiplies them by zero)
@@ -180,7 +186,9 @@ class TrainEngine:
             km0 = self.nets[net].img.streams["fwd"][0].kmap
             pad = 96 if d_out == 96 else 32
             ent.append(dict(net=net, name="lin0", rmap=images.ident_map(256), cmap=km0[:256], scale=1.0, A=sl(dh, 0), B=whole(w["feat"]), bias=True, Pn=P))
-            ent.append(dict(net=net, name="lin0", rmap=images.ident_map(256), cmap=km0[256:], scale=1.0, A=sl(dh, 0), B=whole(small), bias=False, Pn=P))
+            ent.append(dict(net=net, name="lin0", rmap=images.ident_map(256), cmap=km0[256:320], scale=1.0, A=sl(dh, 0), B=whole(small), bias=False, Pn=P))
+            if len(km0) > 320:        # d_feature = 352: the appended VDN channels
+                ent.append(dict(net=net, name="lin0", rmap=images.ident_map(256), cmap=km0[320:], scale=1.0, A=sl(dh, 0), B=whole(w["col_extra"]), bias=False, Pn=P))
             for l in (1, 2, 3):
                 ent.append(dict(net=net, name="lin%d" % l, rmap=images.ident_map(256), cmap=images.ident_map(256), scale=1.0,
                                 A=sl(dh, l), B=sl(save_h, l - 1), bias=True, Pn=P))
@@ -377,6 +385,8 @@ class TrainEngine:
             c.normals, c.feat, c.out = w["normals"].data_ptr(), w["feat"].data_ptr(), out.data_ptr()
             c.save_h, c.save_small = save_h.data_ptr(), small.data_ptr()
             c.P, c.d_out, c.squeeze_out = self.P, d_out, int(module.squeeze_out)
+            if net == "color" and self.dbc:          # renderer.py:247-248
+                c.extra, c.save_extra = w["vdn_out"].data_ptr(), w["col_extra"].data_ptr()
             lib.call("vdn_rendernet_fwd" + self.sfx, self._fg(c), st)
         if self.wdepth:
             rnet("vdn", w["vdn_out"], w["vdn_h"], w["vdn_small"], 96, r.depth_network)
@@ -545,6 +555,8 @@ class TrainEngine:
             b.d_feat, b.d_normals = w["d_featvec"].data_ptr(), w["d_normals"].data_ptr()
             b.acc_feat, b.acc_normals = int(accumulate), 1
             b.P, b.d_out, b.squeeze_out = self.P, d_out, int(module.squeeze_out)
+            if net == "color" and self.dbc:          # d loss / d (VDN output) through the colour network joins the compositor's
+                b.d_extra = w["d_vdn"].data_ptr()
             if rg:
                 b.rays_d, b.n_per_ray, b.acc_pts = rays_d.data_ptr(), self.N, int(accumulate)
                 b.d_pts, b.d_dirs = w["d_pts"].data_ptr(), w["d_dirs"].data_ptr()

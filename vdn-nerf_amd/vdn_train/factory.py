@@ -24,7 +24,7 @@ MODE_KW = {"idr": dict(mode="idr", d_in=9, multires_view=4), "no_normal": dict(m
 
 
 def build_renderer(wdepth=False, device="cuda", states=None, precision="fp32", color_mode="idr", weight_norm=True,
-                   **renderer_overrides):
+                   depth_before_color=False, **renderer_overrides):
     """-> NeuSRenderer with its five networks on `device`. `states`: vdn_train.synth.make_all_states()-style
     dict of numpy arrays (checkpoint key names of dpt_runner.py:366-375), always in the shipped (idr, weight-normed)
     form: `color_mode` / `weight_norm` select the other constructor variants of fields.py:113-176 / 10-21 and the
@@ -36,7 +36,9 @@ def build_renderer(wdepth=False, device="cuda", states=None, precision="fp32", c
     nerf = NeRF(**nerf_kw)
     sdf = SDFNetwork(**dict(CONF["sdf_network"], weight_norm=weight_norm))
     var = SingleVarianceNetwork(**CONF["variance_network"])
-    col = RenderingNetwork(**dict(CONF["rendering_network"], weight_norm=weight_norm, **MODE_KW[color_mode]))
+    # depth_before_color: render() then feeds the colour network cat([feature_vector, VDN output]) (renderer.py:247-248)
+    col = RenderingNetwork(**dict(CONF["rendering_network"], weight_norm=weight_norm, **MODE_KW[color_mode],
+                                  **(dict(d_feature=352) if depth_before_color else {})))
     vdn = RenderingNetwork(**dict(CONF["depth_extract_network"], weight_norm=weight_norm, **MODE_KW[color_mode])) if wdepth else None
     if states is not None:
         tt = lambda d: {k: torch.as_tensor(v) for k, v in d.items()}

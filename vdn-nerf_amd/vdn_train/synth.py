@@ -166,13 +166,14 @@ def variant_state(state, mode="idr", weight_norm=True):
     return out
 
 
-def make_all_states(seed=0, wdepth=False, variance=0.3, dense_noise=0.02):
-    """All networks of one experiment: keys mirror dpt_runner.py:366-375's checkpoint dict."""
+def make_all_states(seed=0, wdepth=False, variance=0.3, dense_noise=0.02, depth_before_color=False):
+    """All networks of one experiment: keys mirror dpt_runner.py:366-375's checkpoint dict. depth_before_color: the colour
+    network takes the 96 VDN channels behind the feature vector (d_feature = 352, renderer.py:247-248)."""
     st = {
         "nerf": make_nerf_state(seed, gen_depth_feats=wdepth),
         "sdf_network_fine": make_sdf_state(seed, dense_noise=dense_noise),
         "variance_network_fine": {"variance": np.asarray(variance, dtype=np.float32)},
-        "color_network_fine": make_rendering_state(seed, "color", d_out=3),
+        "color_network_fine": make_rendering_state(seed, "color", d_out=3, d_feature=352 if depth_before_color else 256),
         "depth_network_fine": make_rendering_state(seed, "vdn", d_out=96) if wdepth else None,
     }
     return st
