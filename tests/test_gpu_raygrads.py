@@ -231,3 +231,31 @@ def test_pose_refinement_recovers_a_perturbed_camera(precision):
     et = (pose_net.t[cam].detach() - true_t).norm().item()
     assert loss.item() < 0.05 * first and er < 0.1 * err0[0] and et < 0.1 * err0[1], (first, loss.item(), er, et, err0)
     assert pose_net.r.grad[0].abs().max() == 0 and pose_net.t.grad[3].abs().max() == 0
+
+
+def test_learnable_rays_equal_the_fixed_pose_generator_and_carry_the_graph():
+    """dpt_models.poses.LearnableRays (the learnable branch of RaysGenerator, poses.py:168-212) with a zero pose delta and the
+    same intrinsics produces the fixed-pose generator's rays (vdn_gen_rays) and pixel data, with a graph to the pose."""
+    from vdn_train import synth
+    from vdn_train.rays import RaysGenerator
+    from dpt_models.poses import LearnPose, LearnIntrin, LearnableRays
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(5)
+    n, H, W, C = 3, 48, 64, 4
+    images, masks, feats = rng.rand(n, H, W, 3).astype(np.float32), (rng.rand(n, H, W, 3) > 0.3).astype(np.float32), rng.rand(n, H, W, C).astype(np.float32)
+    cams = np.asarray(synth.make_cameras(5, n=n), np.float32)
+    intrin = LearnIntrin(H, W, req_grad=False, order=2, init_focal=torch.tensor(70.0)).to(dev)
+    K = intrin().cpu().numpy()
+    fixed = RaysGenerator(images, masks, cams, K, depth_feats=feats, device=dev)
+    pose_net = LearnPose(n, True, True, init_c2w=torch.tensor(cams)).to(dev)
+    lr = LearnableRays(pose_net, intrin, fixed)
+    px, py = rng.randint(0, W, 96).astype(np.float32), rng.randint(0, H, 96).astype(np.float32)
+    a = lr.gen_random_rays_at(1, 96, pixels=(px, py))
+    b = fixed.gen_random_rays_at(1, 96, pixels=(px, py))
+    assert a.shape == b.shape == (96, 10 + C) and a.requires_grad
+    assert (a[:, :6] - b[:, :6]).abs().max().item() < 2e-6 and torch.equal(a[:, 6:], b[:, 6:])
+    a[:, :6].sum().backward()
+    assert pose_net.t.grad[1].abs().sum() > 0 and pose_net.r.grad[1].abs().sum() > 0 and pose_net.r.grad[0].abs().sum() == 0
+    o, v = lr.gen_rays_at(2, resolution_level=2)
+    o2, v2 = fixed.gen_rays_at(2, resolution_level=2)
+    assert o.shape == (H // 2, W // 2, 3) and (v - v2).abs().max().item() < 2e-6 and (o - o2).abs().max().item() < 1e-6
