@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VDN_ABI_VERSION 11
+#define VDN_ABI_VERSION 12
 
 int vdn_abi_version(void);
 
@@ -575,6 +575,23 @@ typedef struct {
     int32_t* n_active;         /* [1] out */
     int32_t* ray_counts;       /* [B] scratch */
 } VdnForegroundActiveArgs;
+
+/* The per-ray preparation of a training step in two launches instead of six: the sections of the inside depths and of
+ * z_feed (vdn_sections twice), and both work lists (vdn_foreground_active, vdn_background_active: count pass + fill pass
+ * each). Same results element for element. fg_active_idx == NULL skips the foreground list (every inside sample is
+ * evaluated: the caller then sets its own row count). */
+typedef struct {
+    const float* rays_o; const float* rays_d;
+    const float* z;            /* [B,z_ld] sorted inside depths */
+    const float* z_feed;       /* [B,T] sorted [inside | outside] depths (vdn_merge_sorted) */
+    int32_t B, N, T, z_ld;
+    float sample_dist, fg_radius;
+    float* dists; float* mid_z;            /* [B,N] out */
+    float* bg_dists; float* bg_mid;        /* [B,T] out */
+    int32_t* fg_active_idx; int32_t* fg_n_active; int32_t* fg_ray_counts;     /* as VdnForegroundActiveArgs, or NULL */
+    int32_t* bg_active_idx; int32_t* bg_n_active; int32_t* bg_ray_counts;     /* as VdnBackgroundActiveArgs */
+} VdnTrainPrepArgs;
+int vdn_train_prep(const VdnTrainPrepArgs* args_host, void* stream);
 int vdn_foreground_active(const VdnForegroundActiveArgs* args_host, void* stream);
 
 /* ---- iso-surface of the lattice u = -sdf (device marching tetrahedra) ---------------------------------------------

@@ -621,3 +621,53 @@ def test_merge_sorted_kernel_vs_stable_sort(dev, sorted_old):
     want_z, idx = torch.sort(cat_z, dim=-1, stable=True)
     assert torch.equal(z[:, :M + K].cpu(), want_z)
     assert torch.equal(s[:, :M + K].cpu(), torch.gather(cat_s, 1, idx))
+
+
+def test_train_prep_equals_the_separate_launches(dev):
+    """vdn_train_prep (sections of both depth sets + both work lists in two launches) against vdn_sections x 2,
+    vdn_foreground_active and vdn_background_active: bit for bit, with and without the foreground list."""
+    from vdn_hip import lib
+    from vdn_train import synth
+    B, N, O = 37, 128, 32
+    T = N + O
+    o, d = synth.random_pixel_batch(4, 0, 3, B, crop=520)
+    near, far = synth.near_far_from_sphere(o, d)
+    rng = np.random.RandomState(4)
+    z = np.sort(near + (far - near) * rng.rand(B, N).astype(np.float32), axis=1).astype(np.float32)
+    z_out = np.sort(far + 0.02 + 3.0 * rng.rand(B, O).astype(np.float32), axis=1).astype(np.float32)
+    st = torch.cuda.current_stream().cuda_stream
+    zt, zf = g(z, dev), g(np.concatenate([z, z_out], 1), dev)
+    ro, rd = g(o, dev), g(d, dev)
+    f = lambda *s: torch.full(s, -7.0, dtype=torch.float32, device=dev)
+    i32 = lambda *s: torch.full(s, -7, dtype=torch.int32, device=dev)
+    ref = dict(dists=f(B, N), mid=f(B, N), bdists=f(B, T), bmid=f(B, T), fg=(i32(B * N), i32(1), i32(B)), bg=(i32(B * T), i32(1), i32(B)))
+    for zz, dd, mm, n in ((zt, ref["dists"], ref["mid"], N), (zf, ref["bdists"], ref["bmid"], T)):
+        a = lib.VdnSectionArgs()
+        a.z, a.dists, a.mid_z, a.sample_dist, a.B, a.n, a.ld = zz.data_ptr(), dd.data_ptr(), mm.data_ptr(), 2.0 / 64, B, n, n
+        lib.call("vdn_sections", a, st)
+    fa = lib.VdnForegroundActiveArgs()
+    fa.rays_o, fa.rays_d, fa.mid_z, fa.B, fa.N, fa.radius = ro.data_ptr(), rd.data_ptr(), ref["mid"].data_ptr(), B, N, 1.2
+    fa.active_idx, fa.n_active, fa.ray_counts = (t.data_ptr() for t in ref["fg"])
+    lib.call("vdn_foreground_active", fa, st)
+    ba = lib.VdnBackgroundActiveArgs()
+    ba.rays_o, ba.rays_d, ba.mid_z, ba.B, ba.N, ba.T = ro.data_ptr(), rd.data_ptr(), ref["mid"].data_ptr(), B, N, T
+    ba.active_idx, ba.n_active, ba.ray_counts = (t.data_ptr() for t in ref["bg"])
+    lib.call("vdn_background_active", ba, st)
+    for with_fg in (True, False):
+        got = dict(dists=f(B, N), mid=f(B, N), bdists=f(B, T), bmid=f(B, T), fg=(i32(B * N), i32(1), i32(B)), bg=(i32(B * T), i32(1), i32(B)))
+        tp = lib.VdnTrainPrepArgs()
+        tp.rays_o, tp.rays_d, tp.z, tp.z_feed = ro.data_ptr(), rd.data_ptr(), zt.data_ptr(), zf.data_ptr()
+        tp.B, tp.N, tp.T, tp.z_ld, tp.sample_dist, tp.fg_radius = B, N, T, N, 2.0 / 64, 1.2
+        tp.dists, tp.mid_z, tp.bg_dists, tp.bg_mid = (got[k].data_ptr() for k in ("dists", "mid", "bdists", "bmid"))
+        if with_fg:
+            tp.fg_active_idx, tp.fg_n_active, tp.fg_ray_counts = (t.data_ptr() for t in got["fg"])
+        tp.bg_active_idx, tp.bg_n_active, tp.bg_ray_counts = (t.data_ptr() for t in got["bg"])
+        lib.call("vdn_train_prep", tp, st)
+        for k in ("dists", "mid", "bdists", "bmid"):
+            assert torch.equal(got[k], ref[k]), k
+        for k in ("fg", "bg") if with_fg else ("bg",):
+            n = int(ref[k][1].item())
+            assert int(got[k][1].item()) == n and 0 < n < ref[k][0].numel()
+            assert torch.equal(got[k][0][:n], ref[k][0][:n]) and torch.equal(got[k][2], ref[k][2]), k
+        if not with_fg:
+            assert int(got["fg"][1].item()) == -7

@@ -586,6 +586,80 @@ extern "C" int vdn_foreground_active(const VdnForegroundActiveArgs* a, void* str
     return launch_active(j, stream);
 }
 
+// The training step's per-ray preparation fused (include/vdn_render.h: VdnTrainPrepArgs): every one of the launches it
+// replaces costs ~4.5 us of fixed time for a few hundred bytes per ray. Pass 0: both section sets + both per-ray counts;
+// pass 1 (blocks [0, nb): foreground, [nb, 2 nb): background): the fill passes. Same expressions as sections_kernel /
+// active_list_kernel (this file is built with -ffp-contract=off: the norm tests are the compositor's own).
+template <int PASS>
+__global__ __launch_bounds__(kRayWaves * 64) void train_prep_kernel(TrainPrepArgs a) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nb = (a.B + kRayWaves - 1) / kRayWaves;
+    const bool second = PASS == 1 && (int)blockIdx.x >= nb;
+    const int r = ((int)blockIdx.x - (second ? nb : 0)) * kRayWaves + wave;
+    if (r >= a.B) return;
+    float o[3], d[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        o[k] = a.rays_o[r * 3 + k];
+        d[k] = a.rays_d[r * 3 + k];
+    }
+    if (PASS == 0) {
+        for (int i = lane; i < a.N; i += 64) {
+            const float z0 = a.z[(long)r * a.z_ld + i];
+            const float dist = (i + 1 < a.N) ? a.z[(long)r * a.z_ld + i + 1] - z0 : a.sample_dist;
+            a.dists[(long)r * a.N + i] = dist;
+            a.mid_z[(long)r * a.N + i] = z0 + dist * 0.5f;
+        }
+        for (int i = lane; i < a.T; i += 64) {
+            const float z0 = a.z_feed[(long)r * a.T + i];
+            const float dist = (i + 1 < a.T) ? a.z_feed[(long)r * a.T + i + 1] - z0 : a.sample_dist;
+            a.bg_dists[(long)r * a.T + i] = dist;
+            a.bg_mid[(long)r * a.T + i] = z0 + dist * 0.5f;
+        }
+        __builtin_amdgcn_s_waitcnt(0);          // this wave reads back its own mid_z row below
+        __builtin_amdgcn_wave_barrier();
+    }
+    // the two lists: foreground (inside samples with |p| < radius) and background (not inside the unit sphere, plus every
+    // outside sample)
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        if (PASS == 1 && (which == 1) != second) continue;
+        if (which == 0 && a.fg_active_idx == nullptr) continue;
+        const ActiveJob j = which == 0
+            ? ActiveJob{a.rays_o, a.rays_d, a.mid_z, a.B, a.N, a.N, a.fg_radius, false, a.fg_active_idx, a.fg_n_active, a.fg_ray_counts}
+            : ActiveJob{a.rays_o, a.rays_d, a.mid_z, a.B, a.N, a.T, 1.0f, true, a.bg_active_idx, a.bg_n_active, a.bg_ray_counts};
+        int base = 0;
+        if (PASS == 1) {
+            int acc = 0;
+            for (int i = lane; i < r; i += 64) acc += j.ray_counts[i];
+            base = (int)wave_sum((double)acc);
+        }
+        int n = 0;
+        for (int s0 = 0; s0 < j.T; s0 += 64) {
+            const int s = s0 + lane;
+            const bool act = s < j.T && sample_active(j, r, s, o, d);
+            const unsigned long long m = __ballot(act);
+            if (PASS == 1 && act) j.active_idx[base + n + __popcll(m & ((1ull << lane) - 1ull))] = r * j.T + s;
+            n += __popcll(m);
+        }
+        if (lane == 0) {
+            if (PASS == 0) j.ray_counts[r] = n;
+            else if (r == j.B - 1) j.n_active[0] = base + n;
+        }
+    }
+}
+
+extern "C" int vdn_train_prep(const VdnTrainPrepArgs* a, void* stream) {
+    if (!a || a->B <= 0 || a->N <= 0 || a->T <= a->N || a->T > kMaxT || a->z_ld < a->N) return -1;
+    if (!a->rays_o || !a->rays_d || !a->z || !a->z_feed || !a->dists || !a->mid_z || !a->bg_dists || !a->bg_mid) return -2;
+    if (!a->bg_active_idx || !a->bg_n_active || !a->bg_ray_counts) return -3;
+    if (a->fg_active_idx && (!a->fg_n_active || !a->fg_ray_counts || !(a->fg_radius > 0.0f))) return -4;
+    const int nb = (a->B + kRayWaves - 1) / kRayWaves;
+    hipLaunchKernelGGL(train_prep_kernel<0>, dim3(nb), dim3(kRayWaves * 64), 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(train_prep_kernel<1>, dim3(2 * nb), dim3(kRayWaves * 64), 0, (hipStream_t)stream, *a);
+    return (int)hipGetLastError();
+}
+
 extern "C" int vdn_sections(const VdnSectionArgs* a, void* stream) {
     if (!a || a->B <= 0 || a->n <= 0 || !a->z || !a->dists || !a->mid_z || a->ld < a->n) return -1;
     const int n = a->B * a->n;

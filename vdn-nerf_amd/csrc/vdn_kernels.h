@@ -24,6 +24,7 @@ using WeightNormBwdDesc = ::VdnWeightNormBwdDesc;
 using CompositeBwdArgs = ::VdnCompositeBwdArgs;
 using LossArgs = ::VdnLossArgs;
 using RayAdjointArgs = ::VdnRayAdjointArgs;
+using TrainPrepArgs = ::VdnTrainPrepArgs;
 using GenRaysArgs = ::VdnGenRaysArgs;
 
 // Kernels needing more than 64 KiB of dynamic LDS opt in once per process.

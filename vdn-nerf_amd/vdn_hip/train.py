@@ -335,28 +335,44 @@ class TrainEngine:
         if self._ptr_key() != self._param_ptrs:
             raise RuntimeError("parameters were re-allocated after the training engine was built; rebuild it")
         sample_dist = 2.0 / r.n_samples
-        a = lib.VdnSectionArgs()
-        a.z, a.dists, a.mid_z, a.sample_dist, a.B, a.n, a.ld = z.data_ptr(), w["dists"].data_ptr(), w["mid_z"].data_ptr(), sample_dist, B, N, z.stride(0)
-        lib.call("vdn_sections", a, st)
+        O = r.n_outside
         # without a background pass (n_outside = 0) render_core does not blend with inside_sphere (renderer.py:289): every
         # foreground sample counts, nothing may be skipped
-        self._fg_compact = bool(skip_far) and r.n_outside > 0 and os.environ.get("VDN_FG_COMPACT", "1") != "0"
-        if self._fg_compact:
-            fa = lib.VdnForegroundActiveArgs()
-            fa.rays_o, fa.rays_d, fa.mid_z, fa.B, fa.N, fa.radius = rays_o.data_ptr(), rays_d.data_ptr(), w["mid_z"].data_ptr(), B, N, 1.2
-            fa.active_idx, fa.n_active, fa.ray_counts = (t.data_ptr() for t in w["fg_active"])
-            lib.call("vdn_foreground_active", fa, st)
-        else:
-            w["fg_active"][1].fill_(self.P)               # the dW GEMM's device-side row count
-        O = r.n_outside
+        self._fg_compact = bool(skip_far) and O > 0 and os.environ.get("VDN_FG_COMPACT", "1") != "0"
+        from dpt_models.renderer import background_active, bg_compaction
+        self._bg_compact = O > 0 and bg_compaction()
+        fused_prep = self._bg_compact and os.environ.get("VDN_FUSED_PREP", "1") != "0"
         if O > 0:
             m = lib.VdnMergeArgs()
             m.z, m.new_z, m.z_out = z.data_ptr(), z_out.data_ptr(), w["z_feed"].data_ptr()
             m.B, m.M, m.K, m.ld, m.ld_out = B, N, O, z.stride(0), T
             lib.call("vdn_merge_sorted", m, st)
+        if fused_prep:
+            # sections of both depth sets + both work lists in two launches (vdn_train_prep) instead of six
+            tp = lib.VdnTrainPrepArgs()
+            tp.rays_o, tp.rays_d, tp.z, tp.z_feed = rays_o.data_ptr(), rays_d.data_ptr(), z.data_ptr(), w["z_feed"].data_ptr()
+            tp.B, tp.N, tp.T, tp.z_ld, tp.sample_dist, tp.fg_radius = B, N, T, z.stride(0), sample_dist, 1.2
+            tp.dists, tp.mid_z, tp.bg_dists, tp.bg_mid = (w[k].data_ptr() for k in ("dists", "mid_z", "bg_dists", "bg_mid"))
+            if self._fg_compact:
+                tp.fg_active_idx, tp.fg_n_active, tp.fg_ray_counts = (t.data_ptr() for t in w["fg_active"])
+            tp.bg_active_idx, tp.bg_n_active, tp.bg_ray_counts = (t.data_ptr() for t in w["bg_active"])
+            lib.call("vdn_train_prep", tp, st)
+        else:
             a = lib.VdnSectionArgs()
-            a.z, a.dists, a.mid_z, a.sample_dist, a.B, a.n, a.ld = w["z_feed"].data_ptr(), w["bg_dists"].data_ptr(), w["bg_mid"].data_ptr(), sample_dist, B, T, T
+            a.z, a.dists, a.mid_z, a.sample_dist, a.B, a.n, a.ld = z.data_ptr(), w["dists"].data_ptr(), w["mid_z"].data_ptr(), sample_dist, B, N, z.stride(0)
             lib.call("vdn_sections", a, st)
+            if self._fg_compact:
+                fa = lib.VdnForegroundActiveArgs()
+                fa.rays_o, fa.rays_d, fa.mid_z, fa.B, fa.N, fa.radius = rays_o.data_ptr(), rays_d.data_ptr(), w["mid_z"].data_ptr(), B, N, 1.2
+                fa.active_idx, fa.n_active, fa.ray_counts = (t.data_ptr() for t in w["fg_active"])
+                lib.call("vdn_foreground_active", fa, st)
+        if not self._fg_compact:
+            w["fg_active"][1].fill_(self.P)               # the dW GEMM's device-side row count
+        if O > 0:
+            if not fused_prep:
+                a = lib.VdnSectionArgs()
+                a.z, a.dists, a.mid_z, a.sample_dist, a.B, a.n, a.ld = w["z_feed"].data_ptr(), w["bg_dists"].data_ptr(), w["bg_mid"].data_ptr(), sample_dist, B, T, T
+                lib.call("vdn_sections", a, st)
             n = lib.VdnNerfArgs()
             n.blob = self.nets["nerf"].img.blobs["fwd"].data_ptr()
             n.rays_o, n.rays_d, n.z, n.n_per_ray, n.P = rays_o.data_ptr(), rays_d.data_ptr(), w["bg_mid"].data_ptr(), T, self.Q
@@ -364,10 +380,9 @@ class TrainEngine:
             n.feat = w["bg_feat"].data_ptr() if w["bg_feat"] is not None else None
             n.save_h, n.save_pe, n.save_feature, n.save_vpe, n.save_hv = (w[k].data_ptr() for k in ("nf_h", "nf_pe", "nf_feature", "nf_vpe", "nf_hv"))
             # only the background samples the compositor does not multiply by zero (saves are in compact order)
-            from dpt_models.renderer import background_active, bg_compaction
-            self._bg_compact = bg_compaction()
             if self._bg_compact:
-                background_active(rays_o, rays_d, w["mid_z"], T, out=w["bg_active"])
+                if not fused_prep:
+                    background_active(rays_o, rays_d, w["mid_z"], T, out=w["bg_active"])
                 n.active_idx, n.n_active = w["bg_active"][0].data_ptr(), w["bg_active"][1].data_ptr()
             else:
                 w["bg_active"][1].fill_(self.Q)           # the dW GEMM's device-side row count
