@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VDN_ABI_VERSION 12
+#define VDN_ABI_VERSION 13
 
 int vdn_abi_version(void);
 
@@ -215,6 +215,10 @@ typedef struct {
     int32_t B, M, K, ld, ld_out;
 } VdnMergeArgs;
 int vdn_merge_sorted(const VdnMergeArgs* args_host, void* stream);
+/* vdn_merge_sorted (with sdf) followed by vdn_upsample_round on the merged rows (M = merge.M + merge.K; the upsample args'
+ * z / sdf / ld are ignored: the rows are handed over on chip) - cat_z_vals of round i and up_sample of round i+1
+ * (renderer.py:372-386) in one launch. Same results as the two calls. */
+int vdn_merge_upsample(const VdnMergeArgs* merge_host, const VdnUpsampleArgs* upsample_host, void* stream);
 
 /* renderer.py:228-230 / 107-109: dists = diff(z) with last = sample_dist; mid_z = z + dists/2. */
 typedef struct {

@@ -89,21 +89,9 @@ __global__ void coarse_z_kernel(CoarseArgs a) {
 // ------------------------------------------------------------------------------------------
 // one up-sampling round: z[M], sdf[M] -> n_imp new z per ray  (renderer.py:147-191, 44-74)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kRayWaves * 64) void upsample_kernel(UpsampleArgs a) {
-    __shared__ float s_z[kRayWaves][kMaxT], s_sdf[kRayWaves][kMaxT], s_cdf[kRayWaves][kMaxT];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int r = blockIdx.x * kRayWaves + wave;
-    if (r >= a.B) return;            // whole wave exits together; no block-level barrier is used
-    const int M = a.M;
-    float* z = s_z[wave];
-    float* sd = s_sdf[wave];
-    float* cdf = s_cdf[wave];
+// the round itself, on a ray whose z / sdf rows (M entries) sit in LDS; cdf: M floats of scratch
+VDN_DEV void upsample_row(const UpsampleArgs& a, int r, int lane, int M, const float* z, const float* sd, float* cdf) {
     const bool given_w = a.weights != nullptr;
-    for (int i = lane; i < M; i += 64) {
-        z[i] = a.z[(long)r * a.ld + i];
-        sd[i] = given_w ? 0.0f : a.sdf[(long)r * a.ld + i];
-    }
-    __builtin_amdgcn_wave_barrier();
     float o[3] = {0.0f, 0.0f, 0.0f}, d[3] = {0.0f, 0.0f, 0.0f};
     if (!given_w) {
 #pragma unroll
@@ -184,18 +172,30 @@ __global__ __launch_bounds__(kRayWaves * 64) void upsample_kernel(UpsampleArgs a
     }
 }
 
+__global__ __launch_bounds__(kRayWaves * 64) void upsample_kernel(UpsampleArgs a) {
+    __shared__ float s_z[kRayWaves][kMaxT], s_sdf[kRayWaves][kMaxT], s_cdf[kRayWaves][kMaxT];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * kRayWaves + wave;
+    if (r >= a.B) return;            // whole wave exits together; no block-level barrier is used
+    const int M = a.M;
+    float* z = s_z[wave];
+    float* sd = s_sdf[wave];
+    const bool given_w = a.weights != nullptr;
+    for (int i = lane; i < M; i += 64) {
+        z[i] = a.z[(long)r * a.ld + i];
+        sd[i] = given_w ? 0.0f : a.sdf[(long)r * a.ld + i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    upsample_row(a, r, lane, M, z, sd, s_cdf[wave]);
+}
+
 // ------------------------------------------------------------------------------------------
 // merge the new samples into the sorted ray (cat + sort + permuted sdf, renderer.py:197-205)
 // also used for z_feed = sort(cat(z_vals, z_vals_outside)) (renderer.py:390-391), sdf pointers NULL
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kRayWaves * 64) void merge_kernel(MergeArgs a) {
-    __shared__ float s_a[kRayWaves][kMaxT], s_b[kRayWaves][kMaxT];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int r = blockIdx.x * kRayWaves + wave;
-    if (r >= a.B) return;
+// za / zb: this wave's LDS scratch for the old and the new row; lz / ls (optional): LDS copies of the merged z / sdf rows
+VDN_DEV void merge_row(const MergeArgs& a, int r, int lane, float* za, float* zb, float* lz, float* ls) {
     const int M = a.M, K = a.K;
-    float* za = s_a[wave];
-    float* zb = s_b[wave];
     for (int i = lane; i < M; i += 64) za[i] = a.z[(long)r * a.ld + i];
     for (int j = lane; j < K; j += 64) zb[j] = a.new_z[(long)r * a.K + j];
     __builtin_amdgcn_wave_barrier();
@@ -251,12 +251,34 @@ __global__ __launch_bounds__(kRayWaves * 64) void merge_kernel(MergeArgs a) {
         if (opos[e] >= 0) {
             a.z_out[(long)r * a.ld_out + opos[e]] = oz[e];
             if (has_sdf) a.sdf_out[(long)r * a.ld_out + opos[e]] = os[e];
+            if (lz != nullptr) { lz[opos[e]] = oz[e]; ls[opos[e]] = os[e]; }
         }
     }
     if (npos >= 0) {
         a.z_out[(long)r * a.ld_out + npos] = nz;
         if (has_sdf) a.sdf_out[(long)r * a.ld_out + npos] = ns;
+        if (lz != nullptr) { lz[npos] = nz; ls[npos] = ns; }
     }
+}
+
+__global__ __launch_bounds__(kRayWaves * 64) void merge_kernel(MergeArgs a) {
+    __shared__ float s_a[kRayWaves][kMaxT], s_b[kRayWaves][kMaxT];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * kRayWaves + wave;
+    if (r >= a.B) return;
+    merge_row(a, r, lane, s_a[wave], s_b[wave], nullptr, nullptr);
+}
+
+// merge of round i followed by the up-sampling of round i+1 on the merged row, which never leaves LDS in between
+// (renderer.py:372-386: cat_z_vals, then up_sample of the next iteration): one launch instead of two
+__global__ __launch_bounds__(kRayWaves * 64) void merge_upsample_kernel(MergeArgs m, UpsampleArgs u) {
+    __shared__ float s_a[kRayWaves][kMaxT], s_b[kRayWaves][kMaxT], s_z[kRayWaves][kMaxT], s_sdf[kRayWaves][kMaxT];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * kRayWaves + wave;
+    if (r >= m.B) return;
+    merge_row(m, r, lane, s_a[wave], s_b[wave], s_z[wave], s_sdf[wave]);
+    __builtin_amdgcn_wave_barrier();
+    upsample_row(u, r, lane, m.M + m.K, s_z[wave], s_sdf[wave], s_a[wave]);     // the old row's scratch serves as the cdf row
 }
 
 // ------------------------------------------------------------------------------------------
@@ -657,6 +679,15 @@ extern "C" int vdn_train_prep(const VdnTrainPrepArgs* a, void* stream) {
     const int nb = (a->B + kRayWaves - 1) / kRayWaves;
     hipLaunchKernelGGL(train_prep_kernel<0>, dim3(nb), dim3(kRayWaves * 64), 0, (hipStream_t)stream, *a);
     hipLaunchKernelGGL(train_prep_kernel<1>, dim3(2 * nb), dim3(kRayWaves * 64), 0, (hipStream_t)stream, *a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int vdn_merge_upsample(const VdnMergeArgs* m, const VdnUpsampleArgs* u, void* stream) {
+    if (!m || !u || m->B <= 0 || !m->z || !m->new_z || !m->z_out || !m->sdf || !m->new_sdf || !m->sdf_out) return -1;
+    if (m->M < 1 || m->K < 1 || m->K > 64 || m->M + m->K > kMaxT || m->ld < m->M || m->ld_out < m->M + m->K) return -2;
+    if (u->B != m->B || u->M != m->M + m->K || u->weights || !u->rays_o || !u->rays_d || !u->u || !u->new_z ||
+        u->n_imp < 1 || u->n_imp > 64) return -3;
+    hipLaunchKernelGGL(merge_upsample_kernel, dim3((m->B + kRayWaves - 1) / kRayWaves), dim3(kRayWaves * 64), 0, (hipStream_t)stream, *m, *u);
     return (int)hipGetLastError();
 }
 

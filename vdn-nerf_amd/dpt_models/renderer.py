@@ -194,11 +194,14 @@ class NeuSRenderer:
                 new_z = torch.empty(B, n_imp, dtype=torch.float32, device=dev)
                 new_sdf = torch.empty(B, n_imp, dtype=torch.float32, device=dev)
                 M = S
-                for i in range(self.up_sample_steps):
+
+                def upsample_args(i, M):
                     u = lib.VdnUpsampleArgs()
                     u.rays_o, u.rays_d, u.z, u.sdf, u.u = (t.data_ptr() for t in (rays_o, rays_d, z, sdf, c["u"]))
                     u.new_z, u.inv_s, u.B, u.M, u.ld, u.n_imp = new_z.data_ptr(), float(64 * 2 ** i), B, M, N, n_imp
-                    lib.call("vdn_upsample_round", u, st)
+                    return u
+                lib.call("vdn_upsample_round", upsample_args(0, M), st)
+                for i in range(self.up_sample_steps):
                     last = (i + 1 == self.up_sample_steps)
                     m = lib.VdnMergeArgs()
                     m.z, m.new_z, m.z_out = z.data_ptr(), new_z.data_ptr(), z.data_ptr()
@@ -206,7 +209,11 @@ class NeuSRenderer:
                     if not last:
                         self.sdf_network._run(0, rays=(rays_o, rays_d, new_z), sdf_out=new_sdf)         # renderer.py:201
                         m.sdf, m.new_sdf, m.sdf_out = sdf.data_ptr(), new_sdf.data_ptr(), sdf.data_ptr()
-                    lib.call("vdn_merge_sorted", m, st)
+                        # cat_z_vals of this round + up_sample of the next one (renderer.py:372-386) in one launch: the new
+                        # samples of round i are read before those of round i+1 are written over them
+                        lib.call("vdn_merge_upsample", m, upsample_args(i + 1, M + n_imp), st)
+                    else:
+                        lib.call("vdn_merge_sorted", m, st)
                     M += n_imp
         else:
             z = z[:, :S] if N == S else z
