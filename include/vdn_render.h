@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VDN_ABI_VERSION 13
+#define VDN_ABI_VERSION 14
 
 int vdn_abi_version(void);
 
@@ -423,6 +423,12 @@ typedef struct {
     int32_t splits, M, N;                  /* M = m_tiles*32, N = n_tiles*32 */
     int32_t accumulate;                    /* 0: '=' (phase 0), 1: '+=' (phase 1) */
     float scale, bscale;
+    /* optional second source for ONE target row: target[xrow, cmap[j]] gets  + xscale * sum_s xsum[s, cmap[j]]  on top of the slab
+     * sums (the sdf row of the last SDF layer also collects colsum(ub_8), k_sdf_bwd.h) - instead of a '+=' descriptor and
+     * a second launch */
+    const float* xsum;                     /* [xsplits, xM] or NULL */
+    int32_t xsplits, xM, xrow;
+    float xscale;
 } VdnDwFinalizeDesc;
 int vdn_dw_finalize(const VdnDwFinalizeDesc* descs_dev, int n_desc, int max_M, int phase, void* stream);
 

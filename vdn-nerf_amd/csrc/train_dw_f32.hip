@@ -153,8 +153,14 @@ __global__ __launch_bounds__(256) void dw_finalize_kernel(const DwFinalizeDesc* 
             for (int e = 0; e < 4; ++e) {
                 const int cc = d.cmap[j + e];
                 if (cc < 0) continue;
+                float val = d.scale * t4[e];
+                if (d.xsum != nullptr && r == d.xrow) {
+                    float x = 0.0f;
+                    for (int s2 = 0; s2 < d.xsplits; ++s2) x += d.xsum[(long)s2 * d.xM + cc];
+                    val += d.xscale * x;
+                }
                 float* t = d.target + (long)r * d.t_stride + cc;
-                *t = d.accumulate ? *t + d.scale * t4[e] : d.scale * t4[e];
+                *t = d.accumulate ? *t + val : val;
             }
         }
     }

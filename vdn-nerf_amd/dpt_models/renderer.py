@@ -56,6 +56,9 @@ def extract_geometry(bound_min, bound_max, resolution, threshold, query_func):
     return vertices, triangles.cpu().numpy()
 
 
+_FUSE_ROUNDS = __import__("os").environ.get("VDN_FUSE_ROUNDS", "1") != "0"      # A/B switch: vdn_merge_upsample vs the two launches
+
+
 def bg_compaction():
     """VDN_BG_COMPACT=0 evaluates every background sample as the reference does (A/B switch for the parity tests)."""
     import os
@@ -211,7 +214,11 @@ class NeuSRenderer:
                         m.sdf, m.new_sdf, m.sdf_out = sdf.data_ptr(), new_sdf.data_ptr(), sdf.data_ptr()
                         # cat_z_vals of this round + up_sample of the next one (renderer.py:372-386) in one launch: the new
                         # samples of round i are read before those of round i+1 are written over them
-                        lib.call("vdn_merge_upsample", m, upsample_args(i + 1, M + n_imp), st)
+                        if _FUSE_ROUNDS:
+                            lib.call("vdn_merge_upsample", m, upsample_args(i + 1, M + n_imp), st)
+                        else:
+                            lib.call("vdn_merge_sorted", m, st)
+                            lib.call("vdn_upsample_round", upsample_args(i + 1, M + n_imp), st)
                     else:
                         lib.call("vdn_merge_sorted", m, st)
                     M += n_imp

@@ -274,8 +274,13 @@ class TrainEngine:
             fd["splits"], fd["M"], fd["N"] = splits, mt * 32, nt * 32
             fd["scale"] = e["scale"]
             if e.get("extra_row0"):
-                tgt = net.dw_target(e["name"])
-                fd["btarget"], fd["bscale"], fd["accumulate"] = tgt.data_ptr(), 1.0 / float(self.r.sdf_network.scale), 1
+                # colsum(ub_8) / scale joins row 0 of d W8 inside the lin8 entry's own finalize (VdnDwFinalizeDesc.xsum): no
+                # '+=' descriptor, no second finalize launch. (The sums are indexed by the image row = the target column.)
+                main = next(k for k, x in enumerate(ent) if x["net"] == e["net"] and x["name"] == e["name"] and not x.get("extra_row0"))
+                fm = fin[main]
+                fm["xsum"], fm["xsplits"], fm["xM"], fm["xrow"] = d["colsum"], splits, mt * 32, 0
+                fm["xscale"] = 1.0 / float(self.r.sdf_network.scale)
+                fd["slab"], fd["colsum"] = 0, 0
             else:
                 tgt = net.dw_target(e["name"])
                 fd["target"], fd["t_stride"] = tgt.data_ptr(), tgt.shape[1]
@@ -284,6 +289,7 @@ class TrainEngine:
                     fd["btarget"], fd["bscale"] = bt.data_ptr(), 1.0
         self.dw_table = torch.from_numpy(dw.view(np.uint8)).to(dev)
         self.fin_table = torch.from_numpy(fin.view(np.uint8)).to(dev)
+        self.fin_has_phase1 = bool((fin["accumulate"] != 0).any())
         self.n_dw = len(ent)
         self.fin_max_M = int(max(len(e["rmap"]) for e in ent))
         # weight-norm backward table
@@ -607,7 +613,8 @@ class TrainEngine:
         self._join()
         self._launch_dw()
         lib.call("vdn_dw_finalize", lib.ptr(self.fin_table), self.n_dw, self.fin_max_M, 0, st)
-        lib.call("vdn_dw_finalize", lib.ptr(self.fin_table), self.n_dw, self.fin_max_M, 1, st)
+        if self.fin_has_phase1:
+            lib.call("vdn_dw_finalize", lib.ptr(self.fin_table), self.n_dw, self.fin_max_M, 1, st)
         if self.n_wn:
             lib.call("vdn_weightnorm_bwd", lib.ptr(self.wn_table), self.n_wn, self.wn_max_rows, st)
         if rg:
