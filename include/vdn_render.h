@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VDN_ABI_VERSION 14
+#define VDN_ABI_VERSION 15
 
 int vdn_abi_version(void);
 
@@ -586,14 +586,16 @@ typedef struct {
     int32_t* ray_counts;       /* [B] scratch */
 } VdnForegroundActiveArgs;
 
-/* The per-ray preparation of a training step in two launches instead of six: the sections of the inside depths and of
- * z_feed (vdn_sections twice), and both work lists (vdn_foreground_active, vdn_background_active: count pass + fill pass
- * each). Same results element for element. fg_active_idx == NULL skips the foreground list (every inside sample is
- * evaluated: the caller then sets its own row count). */
+/* The per-ray preparation of a training step in two launches instead of seven: z_feed = sort(cat(z, z_out))
+ * (vdn_merge_sorted, renderer.py:390-391), the sections of the inside depths and of z_feed (vdn_sections twice), and both
+ * work lists (vdn_foreground_active, vdn_background_active: count pass + fill pass each). Same results element for
+ * element. fg_active_idx == NULL skips the foreground list (every inside sample is evaluated: the caller then sets its
+ * own row count). */
 typedef struct {
     const float* rays_o; const float* rays_d;
     const float* z;            /* [B,z_ld] sorted inside depths */
-    const float* z_feed;       /* [B,T] sorted [inside | outside] depths (vdn_merge_sorted) */
+    const float* z_out;        /* [B,T-N] outside depths */
+    float* z_feed;             /* [B,T] out: sorted [inside | outside] depths */
     int32_t B, N, T, z_ld;
     float sample_dist, fg_radius;
     float* dists; float* mid_z;            /* [B,N] out */

@@ -656,13 +656,15 @@ def test_train_prep_equals_the_separate_launches(dev):
     for with_fg in (True, False):
         got = dict(dists=f(B, N), mid=f(B, N), bdists=f(B, T), bmid=f(B, T), fg=(i32(B * N), i32(1), i32(B)), bg=(i32(B * T), i32(1), i32(B)))
         tp = lib.VdnTrainPrepArgs()
-        tp.rays_o, tp.rays_d, tp.z, tp.z_feed = ro.data_ptr(), rd.data_ptr(), zt.data_ptr(), zf.data_ptr()
+        zo_t, zfeed = g(z_out, dev), f(B, T)
+        tp.rays_o, tp.rays_d, tp.z, tp.z_out, tp.z_feed = ro.data_ptr(), rd.data_ptr(), zt.data_ptr(), zo_t.data_ptr(), zfeed.data_ptr()
         tp.B, tp.N, tp.T, tp.z_ld, tp.sample_dist, tp.fg_radius = B, N, T, N, 2.0 / 64, 1.2
         tp.dists, tp.mid_z, tp.bg_dists, tp.bg_mid = (got[k].data_ptr() for k in ("dists", "mid", "bdists", "bmid"))
         if with_fg:
             tp.fg_active_idx, tp.fg_n_active, tp.fg_ray_counts = (t.data_ptr() for t in got["fg"])
         tp.bg_active_idx, tp.bg_n_active, tp.bg_ray_counts = (t.data_ptr() for t in got["bg"])
         lib.call("vdn_train_prep", tp, st)
+        assert torch.equal(zfeed, zf)
         for k in ("dists", "mid", "bdists", "bmid"):
             assert torch.equal(got[k], ref[k]), k
         for k in ("fg", "bg") if with_fg else ("bg",):

@@ -626,15 +626,24 @@ __global__ __launch_bounds__(kRayWaves * 64) void train_prep_kernel(TrainPrepArg
         d[k] = a.rays_d[r * 3 + k];
     }
     if (PASS == 0) {
+        // z_feed = stable merge of the inside and the outside depths; both rows and the merged one stay in LDS for the sections
+        __shared__ float s_a[kRayWaves][kMaxT], s_b[kRayWaves][kMaxT], s_f[kRayWaves][kMaxT], s_x[kRayWaves][kMaxT];
+        MergeArgs m = {};
+        m.z = a.z; m.new_z = a.z_out; m.z_out = a.z_feed;
+        m.B = a.B; m.M = a.N; m.K = a.T - a.N; m.ld = a.z_ld; m.ld_out = a.T;
+        merge_row(m, r, lane, s_a[wave], s_b[wave], s_f[wave], s_x[wave]);
+        __builtin_amdgcn_wave_barrier();
+        const float* zi = s_a[wave];
+        const float* zf = s_f[wave];
         for (int i = lane; i < a.N; i += 64) {
-            const float z0 = a.z[(long)r * a.z_ld + i];
-            const float dist = (i + 1 < a.N) ? a.z[(long)r * a.z_ld + i + 1] - z0 : a.sample_dist;
+            const float z0 = zi[i];
+            const float dist = (i + 1 < a.N) ? zi[i + 1] - z0 : a.sample_dist;
             a.dists[(long)r * a.N + i] = dist;
             a.mid_z[(long)r * a.N + i] = z0 + dist * 0.5f;
         }
         for (int i = lane; i < a.T; i += 64) {
-            const float z0 = a.z_feed[(long)r * a.T + i];
-            const float dist = (i + 1 < a.T) ? a.z_feed[(long)r * a.T + i + 1] - z0 : a.sample_dist;
+            const float z0 = zf[i];
+            const float dist = (i + 1 < a.T) ? zf[i + 1] - z0 : a.sample_dist;
             a.bg_dists[(long)r * a.T + i] = dist;
             a.bg_mid[(long)r * a.T + i] = z0 + dist * 0.5f;
         }
@@ -673,7 +682,8 @@ __global__ __launch_bounds__(kRayWaves * 64) void train_prep_kernel(TrainPrepArg
 
 extern "C" int vdn_train_prep(const VdnTrainPrepArgs* a, void* stream) {
     if (!a || a->B <= 0 || a->N <= 0 || a->T <= a->N || a->T > kMaxT || a->z_ld < a->N) return -1;
-    if (!a->rays_o || !a->rays_d || !a->z || !a->z_feed || !a->dists || !a->mid_z || !a->bg_dists || !a->bg_mid) return -2;
+    if (!a->rays_o || !a->rays_d || !a->z || !a->z_out || !a->z_feed || !a->dists || !a->mid_z || !a->bg_dists || !a->bg_mid) return -2;
+    if (a->T - a->N > 64) return -2;
     if (!a->bg_active_idx || !a->bg_n_active || !a->bg_ray_counts) return -3;
     if (a->fg_active_idx && (!a->fg_n_active || !a->fg_ray_counts || !(a->fg_radius > 0.0f))) return -4;
     const int nb = (a->B + kRayWaves - 1) / kRayWaves;

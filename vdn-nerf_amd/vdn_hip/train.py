@@ -348,15 +348,15 @@ class TrainEngine:
         from dpt_models.renderer import background_active, bg_compaction
         self._bg_compact = O > 0 and bg_compaction()
         fused_prep = self._bg_compact and os.environ.get("VDN_FUSED_PREP", "1") != "0"
-        if O > 0:
+        if O > 0 and not fused_prep:
             m = lib.VdnMergeArgs()
             m.z, m.new_z, m.z_out = z.data_ptr(), z_out.data_ptr(), w["z_feed"].data_ptr()
             m.B, m.M, m.K, m.ld, m.ld_out = B, N, O, z.stride(0), T
             lib.call("vdn_merge_sorted", m, st)
         if fused_prep:
-            # sections of both depth sets + both work lists in two launches (vdn_train_prep) instead of six
+            # z_feed, the sections of both depth sets and both work lists in two launches (vdn_train_prep) instead of seven
             tp = lib.VdnTrainPrepArgs()
-            tp.rays_o, tp.rays_d, tp.z, tp.z_feed = rays_o.data_ptr(), rays_d.data_ptr(), z.data_ptr(), w["z_feed"].data_ptr()
+            tp.rays_o, tp.rays_d, tp.z, tp.z_out, tp.z_feed = (t.data_ptr() for t in (rays_o, rays_d, z, z_out, w["z_feed"]))
             tp.B, tp.N, tp.T, tp.z_ld, tp.sample_dist, tp.fg_radius = B, N, T, z.stride(0), sample_dist, 1.2
             tp.dists, tp.mid_z, tp.bg_dists, tp.bg_mid = (w[k].data_ptr() for k in ("dists", "mid_z", "bg_dists", "bg_mid"))
             if self._fg_compact:
