@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VDN_ABI_VERSION 15
+#define VDN_ABI_VERSION 16
 
 int vdn_abi_version(void);
 
@@ -469,7 +469,7 @@ typedef struct {
     float* d_bg_rgb;           /* [B*T,3] */
     float* d_bg_feat;          /* [B*T,C] or NULL */
     float* d_var_partial;      /* [B] per-ray d loss / d variance */
-    float* d_variance;         /* [1] */
+    float* d_variance;         /* [1], or NULL: the caller sums d_var_partial itself (e.g. as one more vdn_dw_finalize descriptor) */
     /* optional, for differentiable rays (all three or none): adjoints of the section lengths and of the ray direction
      * inside true_cos = rays_d . normal (renderer.py:265) */
     float* d_dists;            /* [B,N] */
@@ -593,7 +593,10 @@ typedef struct {
  * own row count). */
 typedef struct {
     const float* rays_o; const float* rays_d;
-    const float* z;            /* [B,z_ld] sorted inside depths */
+    float* z;                  /* [B,z_ld] sorted inside depths; with new_z: the first M_old of them, completed in place */
+    const float* new_z;        /* optional [B,N-M_old]: the last up-sampling round's samples, still to be merged into z
+                                * (the final cat_z_vals of renderer.py:379-385, which evaluates no sdf), or NULL */
+    int32_t M_old, _pad;
     const float* z_out;        /* [B,T-N] outside depths */
     float* z_feed;             /* [B,T] out: sorted [inside | outside] depths */
     int32_t B, N, T, z_ld;

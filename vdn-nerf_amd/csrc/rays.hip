@@ -194,9 +194,10 @@ __global__ __launch_bounds__(kRayWaves * 64) void upsample_kernel(UpsampleArgs a
 // also used for z_feed = sort(cat(z_vals, z_vals_outside)) (renderer.py:390-391), sdf pointers NULL
 // ------------------------------------------------------------------------------------------
 // za / zb: this wave's LDS scratch for the old and the new row; lz / ls (optional): LDS copies of the merged z / sdf rows
-VDN_DEV void merge_row(const MergeArgs& a, int r, int lane, float* za, float* zb, float* lz, float* ls) {
+// old_src (optional): the old row already in LDS (then a.z is not read)
+VDN_DEV void merge_row(const MergeArgs& a, int r, int lane, float* za, float* zb, float* lz, float* ls, const float* old_src = nullptr) {
     const int M = a.M, K = a.K;
-    for (int i = lane; i < M; i += 64) za[i] = a.z[(long)r * a.ld + i];
+    for (int i = lane; i < M; i += 64) za[i] = old_src != nullptr ? old_src[i] : a.z[(long)r * a.ld + i];
     for (int j = lane; j < K; j += 64) zb[j] = a.new_z[(long)r * a.K + j];
     __builtin_amdgcn_wave_barrier();
     const bool has_sdf = a.sdf != nullptr;
@@ -627,11 +628,20 @@ __global__ __launch_bounds__(kRayWaves * 64) void train_prep_kernel(TrainPrepArg
     }
     if (PASS == 0) {
         // z_feed = stable merge of the inside and the outside depths; both rows and the merged one stay in LDS for the sections
-        __shared__ float s_a[kRayWaves][kMaxT], s_b[kRayWaves][kMaxT], s_f[kRayWaves][kMaxT], s_x[kRayWaves][kMaxT];
+        __shared__ float s_a[kRayWaves][kMaxT], s_b[kRayWaves][kMaxT], s_f[kRayWaves][kMaxT], s_x[kRayWaves][kMaxT], s_z[kRayWaves][kMaxT];
+        const float* final_z = nullptr;
+        if (a.new_z != nullptr) {       // the last round's merge (no sdf), in place; the completed row stays in LDS
+            MergeArgs m1 = {};
+            m1.z = a.z; m1.new_z = a.new_z; m1.z_out = a.z;
+            m1.B = a.B; m1.M = a.M_old; m1.K = a.N - a.M_old; m1.ld = a.z_ld; m1.ld_out = a.z_ld;
+            merge_row(m1, r, lane, s_a[wave], s_b[wave], s_z[wave], s_x[wave]);
+            __builtin_amdgcn_wave_barrier();
+            final_z = s_z[wave];
+        }
         MergeArgs m = {};
         m.z = a.z; m.new_z = a.z_out; m.z_out = a.z_feed;
         m.B = a.B; m.M = a.N; m.K = a.T - a.N; m.ld = a.z_ld; m.ld_out = a.T;
-        merge_row(m, r, lane, s_a[wave], s_b[wave], s_f[wave], s_x[wave]);
+        merge_row(m, r, lane, s_a[wave], s_b[wave], s_f[wave], s_x[wave], final_z);
         __builtin_amdgcn_wave_barrier();
         const float* zi = s_a[wave];
         const float* zf = s_f[wave];
@@ -684,6 +694,7 @@ extern "C" int vdn_train_prep(const VdnTrainPrepArgs* a, void* stream) {
     if (!a || a->B <= 0 || a->N <= 0 || a->T <= a->N || a->T > kMaxT || a->z_ld < a->N) return -1;
     if (!a->rays_o || !a->rays_d || !a->z || !a->z_out || !a->z_feed || !a->dists || !a->mid_z || !a->bg_dists || !a->bg_mid) return -2;
     if (a->T - a->N > 64) return -2;
+    if (a->new_z && (a->M_old < 1 || a->M_old >= a->N || a->N - a->M_old > 64)) return -2;
     if (!a->bg_active_idx || !a->bg_n_active || !a->bg_ray_counts) return -3;
     if (a->fg_active_idx && (!a->fg_n_active || !a->fg_ray_counts || !(a->fg_radius > 0.0f))) return -4;
     const int nb = (a->B + kRayWaves - 1) / kRayWaves;

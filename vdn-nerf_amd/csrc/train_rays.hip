@@ -287,12 +287,13 @@ extern "C" int vdn_alpha_composite_bwd(const VdnCompositeBwdArgs* a, void* strea
     if (!a || a->B <= 0 || a->N <= 0 || a->T < a->N || a->T > kMaxTB) return -1;
     if (!a->rays_o || !a->rays_d || !a->sdf || !a->normals || !a->dists || !a->mid_z || !a->color || !a->variance ||
         !a->alpha || !a->weights || !a->eik) return -2;
-    if (!a->d_sdf || !a->d_normals || !a->d_color || !a->d_var_partial || !a->d_variance) return -3;
+    if (!a->d_sdf || !a->d_normals || !a->d_color || !a->d_var_partial) return -3;
     if (a->T > a->N && (!a->bg_density || !a->bg_rgb || !a->bg_dists || !a->d_bg_density || !a->d_bg_rgb)) return -4;
     if (a->d_feat && (!a->feat || a->feat_ch <= 0)) return -5;
     if ((a->d_dists != nullptr) != (a->d_dir_cos != nullptr) || (a->d_bg_dists && !a->d_dists)) return -6;
     hipLaunchKernelGGL(composite_bwd_kernel, dim3((a->B + kRW - 1) / kRW), dim3(kRW * 64), 0, (hipStream_t)stream, *a);
-    hipLaunchKernelGGL(variance_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a->d_var_partial, a->B, a->d_variance);
+    if (a->d_variance != nullptr)
+        hipLaunchKernelGGL(variance_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a->d_var_partial, a->B, a->d_variance);
     return (int)hipGetLastError();
 }
 

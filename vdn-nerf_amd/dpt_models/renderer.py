@@ -163,8 +163,12 @@ class NeuSRenderer:
         return c
 
     # -------------------------------------------------------------------------------------
-    def _sample(self, rays_o, rays_d, near, far, perturb, t_rand, t_rand_out, z_vals_inject):
-        """renderer.py:334-386 -> z [B,N] (sorted inside samples), z_out [B,O] or None."""
+    def _sample(self, rays_o, rays_d, near, far, perturb, t_rand, t_rand_out, z_vals_inject, defer_last_merge=False):
+        """renderer.py:334-386 -> z [B,N] (sorted inside samples), z_out [B,O] or None.
+        defer_last_merge (the training engine's fused preparation, vdn_train_prep): the final cat_z_vals - which evaluates
+        no sdf (renderer.py:379-385) - is left to the caller: self._pending_merge = (new_z [B,n_imp], M_old) and the first
+        M_old columns of z are the sorted row so far."""
+        self._pending_merge = None
         B, dev = rays_o.shape[0], rays_o.device
         S, I, O = self.n_samples, self.n_importance, self.n_outside
         N = S + I
@@ -219,6 +223,8 @@ class NeuSRenderer:
                         else:
                             lib.call("vdn_merge_sorted", m, st)
                             lib.call("vdn_upsample_round", upsample_args(i + 1, M + n_imp), st)
+                    elif defer_last_merge:
+                        self._pending_merge = (new_z, M)
                     else:
                         lib.call("vdn_merge_sorted", m, st)
                     M += n_imp

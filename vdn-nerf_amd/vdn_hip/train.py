@@ -288,8 +288,17 @@ class TrainEngine:
                     bt = net.bias_target(e["name"])
                     fd["btarget"], fd["bscale"] = bt.data_ptr(), 1.0
         self.dw_table = torch.from_numpy(dw.view(np.uint8)).to(dev)
+        # one more finalize descriptor: d loss / d variance = sum over rays of the compositor's per-ray partials (a [B,1] "column
+        # sum" with one row): the reduction rides in the finalize launch instead of a launch of its own
+        vfin = np.zeros(1, dtype=fin.dtype)
+        self._var_map = torch.zeros(1, dtype=torch.int32, device=dev)
+        vfin[0]["colsum"], vfin[0]["rmap"] = w["d_var_partial"].data_ptr(), self._var_map.data_ptr()
+        vfin[0]["btarget"], vfin[0]["bscale"] = self.grad_views[id(self.r.deviation_network.variance)].data_ptr(), 1.0
+        vfin[0]["splits"], vfin[0]["M"], vfin[0]["N"] = self.B, 1, 0
+        fin = np.concatenate([fin, vfin])
         self.fin_table = torch.from_numpy(fin.view(np.uint8)).to(dev)
         self.fin_has_phase1 = bool((fin["accumulate"] != 0).any())
+        self.n_fin = len(fin)
         self.n_dw = len(ent)
         self.fin_max_M = int(max(len(e["rmap"]) for e in ent))
         # weight-norm backward table
@@ -323,7 +332,7 @@ class TrainEngine:
                 w["d_bg_pts"], w["d_bg_dirs"], w["d_bg_dists"], w["d_z_out"] = f(Q, 3), f(Q, 3), f(B, T), f(B, T - N)
         return w
 
-    def forward(self, rays_o, rays_d, z, z_out, background_rgb, cos_anneal_ratio, skip_far=False, ray_grads=False):
+    def forward(self, rays_o, rays_d, z, z_out, background_rgb, cos_anneal_ratio, skip_far=False, ray_grads=False, pending_merge=None):
         """Differentiable part of render() at detached z [B,N] (+ z_out [B,O]); returns the output tensors.
         skip_far (the Trainer's hot loop): inside samples beyond the relaxed sphere (|p| >= 1.2: inside_sphere = 0 and
         relax_inside_sphere = 0, renderer.py:284-286) enter the loss only through exact zeros, so the SDF / colour / VDN
@@ -348,6 +357,14 @@ class TrainEngine:
         from dpt_models.renderer import background_active, bg_compaction
         self._bg_compact = O > 0 and bg_compaction()
         fused_prep = self._bg_compact and os.environ.get("VDN_FUSED_PREP", "1") != "0"
+        if pending_merge is not None and not fused_prep:
+            # NeuSRenderer._sample(defer_last_merge=True) left the last round's samples unmerged: complete z here
+            new_z, M_old = pending_merge
+            m = lib.VdnMergeArgs()
+            m.z, m.new_z, m.z_out = z.data_ptr(), new_z.data_ptr(), z.data_ptr()
+            m.B, m.M, m.K, m.ld, m.ld_out = B, M_old, N - M_old, z.stride(0), z.stride(0)
+            lib.call("vdn_merge_sorted", m, st)
+            pending_merge = None
         if O > 0 and not fused_prep:
             m = lib.VdnMergeArgs()
             m.z, m.new_z, m.z_out = z.data_ptr(), z_out.data_ptr(), w["z_feed"].data_ptr()
@@ -358,6 +375,8 @@ class TrainEngine:
             tp = lib.VdnTrainPrepArgs()
             tp.rays_o, tp.rays_d, tp.z, tp.z_out, tp.z_feed = (t.data_ptr() for t in (rays_o, rays_d, z, z_out, w["z_feed"]))
             tp.B, tp.N, tp.T, tp.z_ld, tp.sample_dist, tp.fg_radius = B, N, T, z.stride(0), sample_dist, 1.2
+            if pending_merge is not None:
+                tp.new_z, tp.M_old = pending_merge[0].data_ptr(), pending_merge[1]
             tp.dists, tp.mid_z, tp.bg_dists, tp.bg_mid = (w[k].data_ptr() for k in ("dists", "mid_z", "bg_dists", "bg_mid"))
             if self._fg_compact:
                 tp.fg_active_idx, tp.fg_n_active, tp.fg_ray_counts = (t.data_ptr() for t in w["fg_active"])
@@ -538,8 +557,7 @@ class TrainEngine:
                 c.d_bg_feat = w["d_bg_feat"].data_ptr()
                 if g_feat is None:
                     w["d_bg_feat"].zero_()
-        c.d_var_partial = w["d_var_partial"].data_ptr()
-        c.d_variance = self.grad_views[id(r.deviation_network.variance)].data_ptr()
+        c.d_var_partial = w["d_var_partial"].data_ptr()       # summed into the variance's gradient by the finalize launch (_build_dw_plan)
         rg = getattr(self, "_ray_grads", False)
         if rg:
             c.d_dists, c.d_dir_cos = w["d_dists"].data_ptr(), w["d_dir_cos"].data_ptr()
@@ -612,9 +630,9 @@ class TrainEngine:
 
         self._join()
         self._launch_dw()
-        lib.call("vdn_dw_finalize", lib.ptr(self.fin_table), self.n_dw, self.fin_max_M, 0, st)
+        lib.call("vdn_dw_finalize", lib.ptr(self.fin_table), self.n_fin, self.fin_max_M, 0, st)
         if self.fin_has_phase1:
-            lib.call("vdn_dw_finalize", lib.ptr(self.fin_table), self.n_dw, self.fin_max_M, 1, st)
+            lib.call("vdn_dw_finalize", lib.ptr(self.fin_table), self.n_fin, self.fin_max_M, 1, st)
         if self.n_wn:
             lib.call("vdn_weightnorm_bwd", lib.ptr(self.wn_table), self.n_wn, self.wn_max_rows, st)
         if rg:

@@ -114,8 +114,10 @@ class Trainer:
         true_rgb = packed(true_rgb, (B, 3), "true_rgb")
         gt_feats, mask = packed(gt_feats, (B, 96), "gt_feats"), packed(mask, (B, 1), "mask")
         with torch.no_grad():
-            z, z_out = r._sample(rays_o, rays_d, near.reshape(B), far.reshape(B), r.perturb, t_rand, t_rand_out, z_vals_inject)
-        w = eng.forward(rays_o, rays_d, z.contiguous(), z_out, self.bg, self.cos_anneal_ratio(), skip_far=True)
+            z, z_out = r._sample(rays_o, rays_d, near.reshape(B), far.reshape(B), r.perturb, t_rand, t_rand_out, z_vals_inject,
+                                 defer_last_merge=True)
+        w = eng.forward(rays_o, rays_d, z.contiguous(), z_out, self.bg, self.cos_anneal_ratio(), skip_far=True,
+                        pending_merge=r._pending_merge)
         if self.world > 1:
             # the eikonal term is a ratio of sums over the GLOBAL batch (renderer.py:313-315)
             w["eik"][0:1].copy_(dp.global_eikonal(w["eik"][1:3]).reshape(1))
