@@ -164,11 +164,17 @@ __global__ __launch_bounds__(256) void dw_finalize_kernel(const DwFinalizeDesc* 
             }
         }
     }
-    if (d.btarget != nullptr && lane == 0) {
+    if (d.btarget != nullptr) {
+        // the row's wave sums the splits (lanes strided over s, then a fixed shuffle tree: deterministic); the variance gradient
+        // arrives here as a 512-"split" column sum, which one lane alone would stretch the whole launch by
         float v = 0.0f;
-        for (int s = 0; s < d.splits; ++s) v += d.colsum[(long)s * d.M + i];
-        float* t = d.btarget + r;
-        *t = d.accumulate ? *t + d.bscale * v : d.bscale * v;
+        for (int s = lane; s < d.splits; s += 64) v += d.colsum[(long)s * d.M + i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) {
+            float* t = d.btarget + r;
+            *t = d.accumulate ? *t + d.bscale * v : d.bscale * v;
+        }
     }
 }
 
