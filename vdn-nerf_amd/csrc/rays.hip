@@ -414,22 +414,47 @@ __global__ __launch_bounds__(kRayWaves * 64) void composite_kernel(CompositeArgs
     if (a.feat_out != nullptr) {
         __builtin_amdgcn_wave_barrier();
         const int C = a.feat_ch;
-        for (int ch = lane; ch < C; ch += 64) {
-            double acc = 0.0;
-            for (int i = 0; i < T; ++i) {
-                float fv;
-                if (i < N) {
-                    fv = a.feat[((long)r * N + i) * C + ch];
-                    if (has_bg) {
-                        const float inside = s_in[wave][i];
-                        fv = fv * inside + a.bg_feat[((long)r * T + i) * C + ch] * (1.0f - inside);   // renderer.py:297-298
-                    }
-                } else {
-                    fv = a.bg_feat[((long)r * T + i) * C + ch];
+        // lanes over channels (this lane: ch0 = lane, ch1 = lane + 64; up to 128 channels per pass), samples in groups of 8 with
+        // all 32 loads of a group issued before the first use - the plain loop waited out one memory round trip per sample and
+        // channel pass (160 us for 160 samples x 96 channels). Each channel's sum keeps the samples' order.
+        for (int c0 = 0; c0 < C; c0 += 128) {
+            const int ch0 = c0 + lane, ch1 = c0 + lane + 64;
+            const bool v0 = ch0 < C, v1 = ch1 < C;
+            double acc0 = 0.0, acc1 = 0.0;
+            for (int i0 = 0; i0 < T; i0 += 8) {
+                float fa[8][2], fb[8][2];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int i = i0 + k;
+                    const bool fg = i < N, bg = i < T && (has_bg || i >= N) && a.bg_feat != nullptr;
+                    const long qf = ((long)r * N + i) * C, qb = ((long)r * T + i) * C;
+                    fa[k][0] = (fg && v0) ? a.feat[qf + ch0] : 0.0f;
+                    fa[k][1] = (fg && v1) ? a.feat[qf + ch1] : 0.0f;
+                    fb[k][0] = (bg && v0) ? a.bg_feat[qb + ch0] : 0.0f;
+                    fb[k][1] = (bg && v1) ? a.bg_feat[qb + ch1] : 0.0f;
                 }
-                acc += (double)(fv * s_w[wave][i]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int i = i0 + k;
+                    if (i >= T) break;
+                    float f0, f1;
+                    if (i < N) {
+                        f0 = fa[k][0]; f1 = fa[k][1];
+                        if (has_bg) {
+                            const float inside = s_in[wave][i];
+                            f0 = f0 * inside + fb[k][0] * (1.0f - inside);   // renderer.py:297-298
+                            f1 = f1 * inside + fb[k][1] * (1.0f - inside);
+                        }
+                    } else {
+                        f0 = fb[k][0]; f1 = fb[k][1];
+                    }
+                    const float wi = s_w[wave][i];
+                    acc0 += (double)(f0 * wi);
+                    acc1 += (double)(f1 * wi);
+                }
             }
-            a.feat_out[(long)r * C + ch] = (float)acc;
+            if (v0) a.feat_out[(long)r * C + ch0] = (float)acc0;
+            if (v1) a.feat_out[(long)r * C + ch1] = (float)acc1;
         }
     }
 }

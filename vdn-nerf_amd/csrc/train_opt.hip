@@ -17,8 +17,8 @@ __device__ double block_sum(double v, double* sh) {
 }
 
 // one block; rays strided over threads
-__global__ __launch_bounds__(512) void loss_kernel(LossArgs a) {
-    __shared__ double sh[8];
+__global__ __launch_bounds__(1024) void loss_kernel(LossArgs a) {
+    __shared__ double sh[16];
     double msum = 0.0;
     for (int r = threadIdx.x; r < a.B; r += blockDim.x) msum += a.mask ? (double)a.mask[r] : 1.0;
     const float mask_sum = (float)block_sum(msum, sh) + 1e-5f;                 // dpt_runner.py:213
@@ -34,14 +34,6 @@ __global__ __launch_bounds__(512) void loss_kernel(LossArgs a) {
             const float sgn = e > 0.0f ? 1.0f : (e < 0.0f ? -1.0f : 0.0f);
             a.g_color[r * 3 + k] = sgn * m / mask_sum * a.grad_scale;
         }
-        if (a.feats != nullptr && a.g_feats != nullptr) {
-            for (int ch = 0; ch < a.C; ++ch) {
-                const float e = (a.feats[(long)r * a.C + ch] - a.gt_feats[(long)r * a.C + ch]) * m;
-                dl1 += (double)fabsf(e);
-                const float sgn = e > 0.0f ? 1.0f : (e < 0.0f ? -1.0f : 0.0f);
-                a.g_feats[(long)r * a.C + ch] = sgn * m / mask_sum * a.depth_weight * a.grad_scale;
-            }
-        }
         if (a.mask_weight != 0.0f && a.g_weights != nullptr) {
             float ws = 0.0f;
             for (int i = 0; i < a.T; ++i) ws += a.weights[(long)r * a.T + i];
@@ -50,6 +42,31 @@ __global__ __launch_bounds__(512) void loss_kernel(LossArgs a) {
             const bool inside = ws >= 1e-3f && ws <= 1.0f - 1e-3f;
             const float gws = inside ? (-m / wc + (1.0f - m) / (1.0f - wc)) / (float)a.B * a.mask_weight * a.grad_scale : 0.0f;
             for (int i = 0; i < a.T; ++i) a.g_weights[(long)r * a.T + i] = gws;
+        }
+    }
+    if (a.feats != nullptr && a.g_feats != nullptr) {
+        // the depth-feature term (dpt_runner.py:239-243) over the flat [B * C] index: consecutive threads read consecutive
+        // addresses (a thread per ray walked its own 384-byte row: 123 us for 512 x 96 values)
+        const long n = (long)a.B * a.C;
+        for (long base = threadIdx.x; base < n; base += 4L * blockDim.x) {
+            float fv[4], gv[4], mv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {           // four independent load pairs in flight
+                const long idx = base + (long)k * blockDim.x;
+                const bool in = idx < n;
+                fv[k] = in ? a.feats[idx] : 0.0f;
+                gv[k] = in ? a.gt_feats[idx] : 0.0f;
+                mv[k] = in ? (a.mask ? a.mask[(int)(idx / a.C)] : 1.0f) : 0.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const long idx = base + (long)k * blockDim.x;
+                if (idx >= n) break;
+                const float e = (fv[k] - gv[k]) * mv[k];
+                dl1 += (double)fabsf(e);
+                const float sgn = e > 0.0f ? 1.0f : (e < 0.0f ? -1.0f : 0.0f);
+                a.g_feats[idx] = sgn * mv[k] / mask_sum * a.depth_weight * a.grad_scale;
+            }
         }
     }
     l1 = block_sum(l1, sh);
@@ -94,7 +111,7 @@ extern "C" int vdn_loss_fwd_bwd(const VdnLossArgs* a, void* stream) {
     if (!a || a->B <= 0 || !a->color || !a->true_rgb || !a->eik || !a->g_color || !a->g_eik || !a->out_scalars) return -1;
     if (a->feats && (!a->gt_feats || a->C <= 0)) return -2;
     if (a->mask_weight != 0.0f && (!a->weights || !a->g_weights || a->T <= 0)) return -3;
-    hipLaunchKernelGGL(vdn::loss_kernel, dim3(1), dim3(512), 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(vdn::loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, *a);
     return (int)hipGetLastError();
 }
 
