@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VDN_ABI_VERSION 16
+#define VDN_ABI_VERSION 17
 
 int vdn_abi_version(void);
 
@@ -475,6 +475,9 @@ typedef struct {
     float* d_dists;            /* [B,N] */
     float* d_bg_dists;         /* [B,T] (NULL without a background) */
     float* d_dir_cos;          /* [B,3] */
+    /* optional scratch for the feature channels, [B*(2T+N)] floats: with it the per-sample feature dot products and the outer
+     * products d_feat / d_bg_feat run as two streaming launches around the per-ray kernel (which has only 2 waves per CU) */
+    float* feat_scratch;
 } VdnCompositeBwdArgs;
 int vdn_alpha_composite_bwd(const VdnCompositeBwdArgs* args_host, void* stream);
 

@@ -18,6 +18,68 @@ VDN_DEV double wsum_d(double v) {
     return v;
 }
 
+// The 96 feature channels outside the per-ray kernel (CompositeBwdArgs.feat_scratch = [fd (B*T) | cf (B*N) | cb (B*T)]):
+// one wave per sample row, lanes over channels, many waves per CU - plain streaming kernels.
+//   feat_dot:   fd[r,i] = sum_ch g_feat[r,ch] * blended feature(r,i,ch)       (the features' share of dL/dw_i)
+//   feat_outer: d_feat[r,i,:] = cf[r,i] * g_feat[r,:],  d_bg_feat[r,i,:] = cb[r,i] * g_feat[r,:]
+__global__ __launch_bounds__(256) void feat_dot_kernel(CompositeBwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int N = a.N, T = a.T, C = a.feat_ch;
+    if (row >= (long)a.B * T) return;
+    const int r = (int)(row / T), i = (int)(row - (long)r * T);
+    const bool has_bg = a.bg_density != nullptr;
+    float v0 = 0.0f, v1 = 0.0f;
+    float b0 = 0.0f, b1 = 0.0f;
+    if (has_bg && a.bg_feat != nullptr) {
+        if (lane < C) b0 = a.bg_feat[row * C + lane];
+        if (lane + 64 < C) b1 = a.bg_feat[row * C + lane + 64];
+    }
+    if (i < N) {
+        const long q = (long)r * N + i;
+        if (lane < C) v0 = a.feat[q * C + lane];
+        if (lane + 64 < C) v1 = a.feat[q * C + lane + 64];
+        if (has_bg) {
+            const float mz = a.mid_z[q];
+            const float x = a.rays_o[r * 3] + a.rays_d[r * 3] * mz, y = a.rays_o[r * 3 + 1] + a.rays_d[r * 3 + 1] * mz,
+                        zz = a.rays_o[r * 3 + 2] + a.rays_d[r * 3 + 2] * mz;
+            const float inside = sqrtf(x * x + y * y + zz * zz) < 1.0f ? 1.0f : 0.0f;
+            v0 = v0 * inside + b0 * (1.0f - inside);
+            v1 = v1 * inside + b1 * (1.0f - inside);
+        }
+    } else {
+        v0 = b0; v1 = b1;
+    }
+    float part = 0.0f;
+    if (lane < C) part += a.g_feat[(long)r * C + lane] * v0;
+    if (lane + 64 < C) part += a.g_feat[(long)r * C + lane + 64] * v1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    if (lane == 0) a.feat_scratch[row] = part;
+}
+
+__global__ __launch_bounds__(256) void feat_outer_kernel(CompositeBwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int N = a.N, T = a.T, C = a.feat_ch;
+    if (row >= (long)a.B * T) return;
+    const int r = (int)(row / T), i = (int)(row - (long)r * T);
+    const float* cf = a.feat_scratch + (long)a.B * T;
+    const float* cb = cf + (long)a.B * N;
+    const float g0 = lane < C ? a.g_feat[(long)r * C + lane] : 0.0f, g1 = lane + 64 < C ? a.g_feat[(long)r * C + lane + 64] : 0.0f;
+    if (i < N) {
+        const long q = (long)r * N + i;
+        const float c = cf[q];
+        if (lane < C) a.d_feat[q * C + lane] = c * g0;
+        if (lane + 64 < C) a.d_feat[q * C + lane + 64] = c * g1;
+    }
+    if (a.bg_density != nullptr && a.d_bg_feat != nullptr) {
+        const float c = cb[row];
+        if (lane < C) a.d_bg_feat[row * C + lane] = c * g0;
+        if (lane + 64 < C) a.d_bg_feat[row * C + lane + 64] = c * g1;
+    }
+}
+
 __global__ __launch_bounds__(kRW * 64) void composite_bwd_kernel(CompositeBwdArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = blockIdx.x * kRW + wave;
@@ -50,7 +112,11 @@ __global__ __launch_bounds__(kRW * 64) void composite_bwd_kernel(CompositeBwdArg
     // g_feat in d_feat[i, :] / d_bg_feat[i, :], filled by the owner lanes below.
     __shared__ float s_fd[kRW][kMaxTB], s_cf[kRW][kMaxTB], s_cb[kRW][kMaxTB];
     float gfa = 0.0f, gfb = 0.0f;               // this lane's channels of g_feat: lane, lane + 64
-    if (has_feat) {
+    const bool ext_feat = has_feat && a.feat_scratch != nullptr;       // feat_dot_kernel ran before, feat_outer_kernel runs after
+    if (ext_feat) {
+        for (int i = lane; i < T; i += 64) s_fd[wave][i] = a.feat_scratch[(long)r * T + i];
+        __builtin_amdgcn_wave_barrier();
+    } else if (has_feat) {
         if (lane < C) gfa = a.g_feat[(long)r * C + lane];
         if (lane + 64 < C) gfb = a.g_feat[(long)r * C + lane + 64];
         for (int i0 = 0; i0 < T; i0 += 8) {
@@ -241,7 +307,15 @@ __global__ __launch_bounds__(kRW * 64) void composite_bwd_kernel(CompositeBwdArg
             if (a.d_bg_dists != nullptr) a.d_bg_dists[qt] = da_bg * expf(-sp * dist) * sp;
         }
     }
-    if (has_feat) {
+    if (ext_feat) {
+        __builtin_amdgcn_wave_barrier();
+        float* cf = a.feat_scratch + (long)a.B * T;
+        float* cb = cf + (long)a.B * N;
+        for (int i = lane; i < T; i += 64) {
+            if (i < N) cf[(long)r * N + i] = s_cf[wave][i];
+            if (has_bg && a.d_bg_feat != nullptr) cb[(long)r * T + i] = s_cb[wave][i];
+        }
+    } else if (has_feat) {
         __builtin_amdgcn_wave_barrier();
         for (int i = 0; i < T; ++i) {
             if (i < N) {
@@ -346,7 +420,11 @@ extern "C" int vdn_alpha_composite_bwd(const VdnCompositeBwdArgs* a, void* strea
     if (a->T > a->N && (!a->bg_density || !a->bg_rgb || !a->bg_dists || !a->d_bg_density || !a->d_bg_rgb)) return -4;
     if (a->d_feat && (!a->feat || a->feat_ch <= 0 || a->feat_ch > 128)) return -5;
     if ((a->d_dists != nullptr) != (a->d_dir_cos != nullptr) || (a->d_bg_dists && !a->d_dists)) return -6;
+    const bool ext_feat = a->d_feat && a->g_feat && a->feat_scratch;
+    const int row_blocks = (int)(((long)a->B * a->T + 3) / 4);
+    if (ext_feat) hipLaunchKernelGGL(feat_dot_kernel, dim3(row_blocks), dim3(256), 0, (hipStream_t)stream, *a);
     hipLaunchKernelGGL(composite_bwd_kernel, dim3((a->B + kRW - 1) / kRW), dim3(kRW * 64), 0, (hipStream_t)stream, *a);
+    if (ext_feat) hipLaunchKernelGGL(feat_outer_kernel, dim3(row_blocks), dim3(256), 0, (hipStream_t)stream, *a);
     if (a->d_variance != nullptr)
         hipLaunchKernelGGL(variance_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a->d_var_partial, a->B, a->d_variance);
     return (int)hipGetLastError();

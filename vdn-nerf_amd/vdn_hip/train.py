@@ -119,6 +119,7 @@ class TrainEngine:
         # ---- backward intermediates
         w["d_sdf"], w["d_normals"], w["d_color"], w["d_featvec"] = f(P), f(P, 3), f(P, 3), fs(Pp, 256)
         w["d_vdn"] = f(P, 96) if self.wdepth else None
+        w["feat_scratch"] = f(B * (2 * T + N)) if self.wdepth else None        # VdnCompositeBwdArgs.feat_scratch
         w["d_var_partial"], w["d_variance"] = f(B), f(1)
         w["col_dout"], w["col_dh"] = fs(Pp, 32), fs(4, Pp, 256)
         if self.wdepth:
@@ -549,6 +550,7 @@ class TrainEngine:
         use_vdn = self.wdepth and g_feat is not None
         if self.wdepth:
             c.d_feat = w["d_vdn"].data_ptr()
+            c.feat_scratch = w["feat_scratch"].data_ptr()
             if g_feat is None:
                 w["d_vdn"].zero_()
         if r.n_outside > 0:
