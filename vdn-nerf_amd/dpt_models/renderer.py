@@ -276,18 +276,31 @@ class NeuSRenderer:
             if attached is not None:
                 rays_o, rays_d, z, z_out = self._attach_rays(attached, near, far, z, z_out)
             return self._render_train(rays_o, rays_d, z, z_out, background_rgb, cos_anneal_ratio, params)
-        dists, mid_z = self._sections(z, N, sample_dist)
-
         bg_density = bg_rgb = bg_feat = bg_dists = bg_mid = None
-        if O > 0:                                                                # renderer.py:389-397
-            z_feed = torch.empty(B, T, dtype=torch.float32, device=dev)
-            m = lib.VdnMergeArgs()
-            m.z, m.new_z, m.z_out = z.data_ptr(), z_out.data_ptr(), z_feed.data_ptr()
-            m.B, m.M, m.K, m.ld, m.ld_out = B, N, O, z.stride(0), T
-            lib.call("vdn_merge_sorted", m, st)
-            bg_dists, bg_mid = self._sections(z_feed, T, sample_dist)
-            active = background_active(rays_o, rays_d, mid_z, T) if bg_compaction() else None
-            bg_density, bg_rgb, bg_feat = self.nerf._run(rays=(rays_o, rays_d, bg_mid), active=active)
+        if O > 0 and bg_compaction():
+            # z_feed (renderer.py:390-391), both section sets and the background work list in two launches (vdn_train_prep)
+            f32 = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+            z = z.contiguous()
+            z_feed, dists, mid_z, bg_dists, bg_mid = f32(B, T), f32(B, N), f32(B, N), f32(B, T), f32(B, T)
+            active3 = (torch.empty(B * T, dtype=torch.int32, device=dev), torch.empty(1, dtype=torch.int32, device=dev),
+                       torch.empty(B, dtype=torch.int32, device=dev))
+            tp = lib.VdnTrainPrepArgs()
+            tp.rays_o, tp.rays_d, tp.z, tp.z_out, tp.z_feed = (t.data_ptr() for t in (rays_o, rays_d, z, z_out, z_feed))
+            tp.B, tp.N, tp.T, tp.z_ld, tp.sample_dist, tp.fg_radius = B, N, T, z.stride(0), sample_dist, 1.2
+            tp.dists, tp.mid_z, tp.bg_dists, tp.bg_mid = (t.data_ptr() for t in (dists, mid_z, bg_dists, bg_mid))
+            tp.bg_active_idx, tp.bg_n_active, tp.bg_ray_counts = (t.data_ptr() for t in active3)
+            lib.call("vdn_train_prep", tp, st)
+            bg_density, bg_rgb, bg_feat = self.nerf._run(rays=(rays_o, rays_d, bg_mid), active=active3[:2])
+        else:
+            dists, mid_z = self._sections(z, N, sample_dist)
+            if O > 0:                                                            # renderer.py:389-397
+                z_feed = torch.empty(B, T, dtype=torch.float32, device=dev)
+                m = lib.VdnMergeArgs()
+                m.z, m.new_z, m.z_out = z.data_ptr(), z_out.data_ptr(), z_feed.data_ptr()
+                m.B, m.M, m.K, m.ld, m.ld_out = B, N, O, z.stride(0), T
+                lib.call("vdn_merge_sorted", m, st)
+                bg_dists, bg_mid = self._sections(z_feed, T, sample_dist)
+                bg_density, bg_rgb, bg_feat = self.nerf._run(rays=(rays_o, rays_d, bg_mid), active=None)
 
         ws = {}
         sdf, feat, normals = self.sdf_network._run(1, rays=(rays_o, rays_d, mid_z), workspace=ws)   # renderer.py:239-243
