@@ -367,6 +367,23 @@ def test_on_device_ray_generator(dev):
     # a render fed by the generator runs end to end
     rend_rays = gen.gen_random_rays_at(0, 8)
     assert torch.isfinite(rend_rays).all()
+    # poses.py:214-252: interpolated camera; the end points are the two cameras themselves, in between the centre moves on the
+    # world-to-camera-side interpolation the reference uses and the directions stay unit vectors of a proper rotation
+    for ratio, idx in ((0.0, 0), (1.0, 2)):
+        ob, vb = gen.gen_rays_between(ratio, 0, 2, resolution_level=2)
+        oa, va = gen.gen_rays_at(idx, resolution_level=2)
+        assert (ob - oa).abs().max().item() < 2e-5 and (vb - va).abs().max().item() < 2e-5
+    ob, vb = gen.gen_rays_between(0.3, 0, 2, resolution_level=2)
+    assert ob.shape == (H // 2, W // 2, 3) and float(vb.norm(dim=-1).sub(1).abs().max()) < 1e-5
+    w0, w1 = np.linalg.inv(cams[0]), np.linalg.inv(cams[2])
+    from scipy.spatial.transform import Rotation as Rot, Slerp
+    w = np.eye(4)
+    w[:3, :3] = Slerp([0, 1], Rot.from_matrix(np.stack([w0[:3, :3], w1[:3, :3]])))(0.3).as_matrix()
+    w[:3, 3] = (0.7 * w0 + 0.3 * w1)[:3, 3]
+    c2w = np.linalg.inv(w)
+    assert np.abs(ob[0, 0].cpu().numpy() - c2w[:3, 3]).max() < 2e-5
+    pp = np.array([tx[5], ty[7], 1.0]) @ np.linalg.inv(K[:3, :3]).T
+    assert np.abs(vb[7, 5].cpu().numpy() - (pp / np.linalg.norm(pp)) @ c2w[:3, :3].T).max() < 2e-5
 
 
 def test_val_img_over_a_scene_directory(tmp_path):

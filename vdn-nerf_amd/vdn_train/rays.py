@@ -73,6 +73,40 @@ class RaysGenerator:
         v = out[:, 3:6].reshape(self.W // l, self.H // l, 3).transpose(0, 1)
         return o, v
 
+    def gen_rays_between(self, ratio, idx_0, idx_1, resolution_level=1):
+        """poses.py:214-252: rays of a camera interpolated between two views - translation linearly, rotation by Slerp, both
+        on the world-to-camera side as the reference does - with the first camera's intrinsics. -> rays_o, rays_v [H/l, W/l, 3].
+        (The pose algebra is a 4x4 on the host, as in the reference; the rays come from vdn_gen_rays.)"""
+        from scipy.spatial.transform import Rotation as Rot, Slerp
+        l = resolution_level
+        pose_0 = self.pose_all[int(idx_0)].detach().cpu().numpy().astype(np.float64)
+        pose_1 = self.pose_all[int(idx_1)].detach().cpu().numpy().astype(np.float64)
+        pose_0, pose_1 = np.linalg.inv(pose_0), np.linalg.inv(pose_1)
+        rot = Slerp([0, 1], Rot.from_matrix(np.stack([pose_0[:3, :3], pose_1[:3, :3]])))(ratio)
+        pose = np.diag([1.0, 1.0, 1.0, 1.0]).astype(np.float32)
+        pose[:3, :3] = rot.as_matrix()
+        pose[:3, 3] = ((1.0 - ratio) * pose_0 + ratio * pose_1)[:3, 3]
+        pose = np.linalg.inv(pose)
+        tx = torch.linspace(0, self.W - 1, self.W // l)
+        ty = torch.linspace(0, self.H - 1, self.H // l)
+        pixels_x, pixels_y = torch.meshgrid(tx, ty, indexing="ij")
+        px = pixels_x.reshape(-1).to(self.device).contiguous()
+        py = pixels_y.reshape(-1).to(self.device).contiguous()
+        B = px.numel()
+        out = torch.zeros(B, 6, dtype=torch.float32, device=self.device)
+        near = torch.empty(B, 1, dtype=torch.float32, device=self.device)
+        far = torch.empty(B, 1, dtype=torch.float32, device=self.device)
+        pose_t = torch.tensor(pose, dtype=torch.float32, device=self.device).contiguous()
+        a = lib.VdnGenRaysArgs()
+        a.pixels_x, a.pixels_y = px.data_ptr(), py.data_ptr()
+        a.intrinsic_inv, a.pose = self.intrin_inv[0].data_ptr(), pose_t.data_ptr()          # poses.py:229: intrin_inv[0]
+        a.out, a.near, a.far = out.data_ptr(), near.data_ptr(), far.data_ptr()
+        a.B, a.H, a.W, a.out_ld = B, self.H, self.W, 6
+        lib.call("vdn_gen_rays", a, _stream())
+        o = out[:, 0:3].reshape(self.W // l, self.H // l, 3).transpose(0, 1)
+        v = out[:, 3:6].reshape(self.W // l, self.H // l, 3).transpose(0, 1)
+        return o, v
+
     @staticmethod
     def near_far_from_sphere(rays_o, rays_d):
         """dataset.py:111-118 (torch ops on device tensors; the kernel also returns them fused)."""
