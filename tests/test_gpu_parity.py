@@ -427,6 +427,23 @@ def test_val_img_over_a_scene_directory(tmp_path):
             w = out["weights"][:, :128] * out["inside_sphere"]
             zd = out["z_vals"].gather(1, w.argmax(-1, keepdim=True)).cpu().numpy()
             assert np.array_equal(zd, depth.reshape(-1, 1)[s:s + 512])
+    # Runner.validate_image (dpt_runner.py:520-587): colour + normal image, written as the runner names them
+    torch.manual_seed(7)
+    img255, nimg = validate.validate_image(rend, gen, 1, resolution_level=1, batch_size=512, cos_anneal_ratio=0.8, out_dir=root, iter_step=12)
+    assert np.allclose(img255, (img * 255).clip(0, 255)) and nimg.shape == (H, W, 3) and nimg.min() >= 0 and nimg.max() <= 255
+    torch.manual_seed(7)
+    with torch.no_grad():
+        near, far = gen.near_far_from_sphere(o[:512], d[:512])
+        out = rend.render(o[:512], d[:512], near, far, cos_anneal_ratio=0.8, background_rgb=torch.ones(1, 3, device=dev))
+        nv = (out["gradients"] * out["weights"][:, :128, None] * out["inside_sphere"][..., None]).sum(1).cpu().numpy()
+    want = (nv @ np.linalg.inv(cams[1][:3, :3]).T * 128 + 128).clip(0, 255)
+    assert np.abs(nimg.reshape(-1, 3)[:512] - want).max() < 1e-3
+    assert os.path.exists(os.path.join(root, "validations_fine", "00000012_0_1.png")) and os.path.exists(os.path.join(root, "normals", "00000012_0_1.png"))
+    # Runner.render_novel_image (589-616): at ratio 0 the interpolated view is camera idx_0 itself
+    torch.manual_seed(7)
+    nov = validate.render_novel_image(rend, gen, 1, 0, 0.0, resolution_level=1, cos_anneal_ratio=0.8)
+    assert nov.dtype == np.uint8 and nov.shape == (H, W, 3)
+    assert np.abs(nov.astype(np.float64) - (img * 256).clip(0, 255).astype(np.uint8)).max() <= 1
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])

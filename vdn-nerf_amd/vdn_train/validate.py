@@ -1,4 +1,5 @@
-"""Whole-image rendering through the HIP renderer: the arithmetic of Runner.val_img (dpt_runner.py:417-491) - rays of
+"""Whole-image rendering through the HIP renderer: Runner.validate_image (dpt_runner.py:520-587: colour + normal image),
+Runner.render_novel_image (589-616: interpolated view) and the arithmetic of Runner.val_img (dpt_runner.py:417-491) - rays of
 one camera in batches, colour image, L1 / PSNR against the ground truth, and the weight-argmax depth written back as
 `depth_from_sdf/sdf_<name>.npy` for the wavelet fine-tuning loop (dpt_runner.py:449-453). Everything stays on the device
 until the final image copy (the reference copies every batch to the host)."""
@@ -33,6 +34,60 @@ def render_image(renderer, rays_gen, idx, resolution_level=1, batch_size=512, co
         del out
     return {"img_fine": rgb.reshape(H, W, 3).cpu().numpy(), "gradient_error": torch.stack(eik).cpu().numpy(),
             "weight_depth": depth.reshape(H, W, 1).cpu().numpy() if gen_depth_for_finetune else None}
+
+
+@torch.no_grad()
+def validate_image(renderer, rays_gen, idx, resolution_level=1, batch_size=512, cos_anneal_ratio=1.0, white_bkgd=True,
+                   depth_before_color=False, out_dir=None, iter_step=0):
+    """Runner.validate_image (dpt_runner.py:520-587): the colour image and the normal image of one camera.
+    -> (img_fine [H,W,3] in 0..255, normal_img [H,W,3] in 0..255): normals = sum_i gradients_i * weights_i * inside_sphere_i
+    per ray (553-557), rotated into the camera frame by inv(pose[:3,:3]) and mapped by * 128 + 128 (570-573). With `out_dir`
+    the two PNGs are written as the runner names them (validations_fine/, normals/; RGB order on disk, where the runner's
+    cv.imwrite stores its array as BGR)."""
+    rays_o, rays_d = rays_gen.gen_rays_at(idx, resolution_level=resolution_level)
+    H, W, _ = rays_o.shape
+    rays_o, rays_d = rays_o.reshape(-1, 3).contiguous(), rays_d.reshape(-1, 3).contiguous()
+    dev = rays_o.device
+    bg = torch.ones(1, 3, device=dev) if white_bkgd else None
+    rgb = torch.empty(H * W, 3, device=dev)
+    nrm = torch.empty(H * W, 3, device=dev)
+    n_in = renderer.n_samples + renderer.n_importance
+    for s in range(0, H * W, batch_size):
+        o, d = rays_o[s:s + batch_size], rays_d[s:s + batch_size]
+        near, far = rays_gen.near_far_from_sphere(o, d)
+        out = renderer.render(o, d, near, far, cos_anneal_ratio=cos_anneal_ratio, background_rgb=bg, depth_before_color=depth_before_color)
+        rgb[s:s + o.shape[0]] = out["color_fine"]
+        nrm[s:s + o.shape[0]] = (out["gradients"] * out["weights"][:, :n_in, None] * out["inside_sphere"][..., None]).sum(dim=1)
+        del out
+    img_fine = (rgb.reshape(H, W, 3).cpu().numpy() * 255).clip(0, 255)
+    rot = np.linalg.inv(rays_gen.pose_all[idx, :3, :3].detach().cpu().numpy())
+    normal_img = (np.matmul(rot[None, :, :], nrm.cpu().numpy()[:, :, None]).reshape(H, W, 3) * 128 + 128).clip(0, 255)
+    if out_dir is not None:
+        from PIL import Image
+        for sub, arr in (("validations_fine", img_fine), ("normals", normal_img)):
+            os.makedirs(os.path.join(out_dir, sub), exist_ok=True)
+            Image.fromarray(arr.astype(np.uint8)).save(os.path.join(out_dir, sub, "{:0>8d}_{}_{}.png".format(iter_step, 0, idx)))
+    return img_fine, normal_img
+
+
+@torch.no_grad()
+def render_novel_image(renderer, rays_gen, idx_0, idx_1, ratio, resolution_level=1, batch_size=512, cos_anneal_ratio=1.0,
+                       white_bkgd=True, depth_before_color=False):
+    """Runner.render_novel_image (dpt_runner.py:589-616): the view interpolated between two cameras -> uint8 [H,W,3]
+    (the runner's `* 256` clip). Argument order as RaysGenerator.gen_rays_between defines it (ratio first, poses.py:214);
+    the runner itself calls it with (idx_0, idx_1, ratio), SURVEY.md Appendix A."""
+    rays_o, rays_d = rays_gen.gen_rays_between(ratio, idx_0, idx_1, resolution_level=resolution_level)
+    H, W, _ = rays_o.shape
+    rays_o, rays_d = rays_o.reshape(-1, 3).contiguous(), rays_d.reshape(-1, 3).contiguous()
+    dev = rays_o.device
+    bg = torch.ones(1, 3, device=dev) if white_bkgd else None
+    rgb = torch.empty(H * W, 3, device=dev)
+    for s in range(0, H * W, batch_size):
+        o, d = rays_o[s:s + batch_size], rays_d[s:s + batch_size]
+        near, far = rays_gen.near_far_from_sphere(o, d)
+        rgb[s:s + o.shape[0]] = renderer.render(o, d, near, far, cos_anneal_ratio=cos_anneal_ratio, background_rgb=bg,
+                                                depth_before_color=depth_before_color)["color_fine"]
+    return (rgb.reshape(H, W, 3).cpu().numpy() * 256).clip(0, 255).astype(np.uint8)
 
 
 def image_metrics(img_fine, gt, mask=None):
