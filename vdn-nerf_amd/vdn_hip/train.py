@@ -72,6 +72,11 @@ class TrainEngine:
         self._side = torch.cuda.Stream(device=dev) if use_side else None
         self._ev_fork = torch.cuda.Event() if use_side else None
         self._ev_join = torch.cuda.Event() if use_side else None
+        # a second side stream for the VDN head's forward: it and the colour head read the same inputs and each fills only
+        # ~55 % of the workgroup slots (285 tiles on 512), so side by side they take little more than one of them alone
+        self._side2 = torch.cuda.Stream(device=dev) if (use_side and renderer.depth_network is not None) else None
+        self._ev_fork2 = torch.cuda.Event() if self._side2 is not None else None
+        self._ev_join2 = torch.cuda.Event() if self._side2 is not None else None
         self._pending = False
         self._fg_compact = self._bg_compact = False
         precs = {m.precision for m in (renderer.nerf, renderer.sdf_network, renderer.color_network, renderer.depth_network) if m is not None}
@@ -419,7 +424,7 @@ class TrainEngine:
             self._side_done()
         self._sdf_forward(rays_o, rays_d)
 
-        def rnet(net, out, save_h, small, d_out, module):
+        def rnet(net, out, save_h, small, d_out, module, stream=None):
             c = lib.VdnRenderNetArgs()
             c.blob = self.nets[net].img.blobs["fwd"].data_ptr()
             c.rays_o, c.rays_d, c.z, c.n_per_ray = rays_o.data_ptr(), rays_d.data_ptr(), w["mid_z"].data_ptr(), N
@@ -428,10 +433,19 @@ class TrainEngine:
             c.P, c.d_out, c.squeeze_out = self.P, d_out, int(module.squeeze_out)
             if net == "color" and self.dbc:          # renderer.py:247-248
                 c.extra, c.save_extra = w["vdn_out"].data_ptr(), w["col_extra"].data_ptr()
-            lib.call("vdn_rendernet_fwd" + self.sfx, self._fg(c), st)
+            lib.call("vdn_rendernet_fwd" + self.sfx, self._fg(c), st if stream is None else stream)
+        vdn_beside = self.wdepth and self._side2 is not None and not self.dbc     # (depth_before_color: the colour head reads the VDN output)
         if self.wdepth:
-            rnet("vdn", w["vdn_out"], w["vdn_h"], w["vdn_small"], 96, r.depth_network)
+            if vdn_beside:
+                self._ev_fork2.record(torch.cuda.current_stream())
+                self._side2.wait_event(self._ev_fork2)
+                rnet("vdn", w["vdn_out"], w["vdn_h"], w["vdn_small"], 96, r.depth_network, stream=self._side2.cuda_stream)
+                self._ev_join2.record(self._side2)
+            else:
+                rnet("vdn", w["vdn_out"], w["vdn_h"], w["vdn_small"], 96, r.depth_network)
         rnet("color", w["col_out"], w["col_h"], w["col_small"], 3, r.color_network)
+        if vdn_beside:
+            torch.cuda.current_stream().wait_event(self._ev_join2)
 
         c = self._composite_common(lib.VdnCompositeArgs(), rays_o, rays_d, background_rgb, cos_anneal_ratio)
         c.weights, c.alpha_out, c.cdf, c.inside_sphere = w["weights"].data_ptr(), w["alpha"].data_ptr(), w["cdf"].data_ptr(), w["inside"].data_ptr()
