@@ -438,7 +438,13 @@ def test_val_img_over_a_scene_directory(tmp_path):
         nv = (out["gradients"] * out["weights"][:, :128, None] * out["inside_sphere"][..., None]).sum(1).cpu().numpy()
     want = (nv @ np.linalg.inv(cams[1][:3, :3]).T * 128 + 128).clip(0, 255)
     assert np.abs(nimg.reshape(-1, 3)[:512] - want).max() < 1e-3
-    assert os.path.exists(os.path.join(root, "validations_fine", "00000012_0_1.png")) and os.path.exists(os.path.join(root, "normals", "00000012_0_1.png"))
+    assert os.path.exists(os.path.join(root, "normals", "00000012_0_1.png"))
+    # the colour file as cv.imwrite leaves it (dpt_runner.py:575-581): render stacked over the ground truth, the BGR arrays
+    # stored so that the file shows true colours - its lower half is the input PNG itself
+    disk = np.asarray(Image.open(os.path.join(root, "validations_fine", "00000012_0_1.png")))
+    assert disk.shape == (2 * H, W, 3)
+    assert np.array_equal(disk[H:], np.asarray(Image.open(os.path.join(root, "image", "001.png")).convert("RGB")))
+    assert np.array_equal(disk[:H], np.rint(img255).astype(np.uint8)[..., ::-1])
     # Runner.render_novel_image (589-616): at ratio 0 the interpolated view is camera idx_0 itself
     torch.manual_seed(7)
     nov = validate.render_novel_image(rend, gen, 1, 0, 0.0, resolution_level=1, cos_anneal_ratio=0.8)

@@ -110,7 +110,7 @@ def test_adam_step_groups_match_torch_adam_across_depth_start():
         for gq in opt.param_groups:
             gq["lr"] = lr
         for i, (sp, gr) in enumerate(zip(shadow, grads)):
-            sp.grad = None if (i in tr._depth_idx and not depth_on and tr._depth_adam_steps == 0) else gr.view_as(sp).clone()
+            sp.grad = None if (i in tr._depth_idx and not depth_on) else gr.view_as(sp).clone()
         opt.step()
         for i, (sp, p) in enumerate(zip(shadow, tr.params)):
             err = (sp.detach() - p.detach()).abs().max().item()
@@ -123,3 +123,50 @@ def test_adam_step_groups_match_torch_adam_across_depth_start():
     tr2.load_checkpoint(ck)
     assert tr2._depth_adam_steps == 3 and tr2.iter_step - tr2._step0() == 6
     assert torch.equal(tr2.exp_avg, tr.exp_avg) and torch.equal(tr2.param_flat, tr.param_flat)
+
+
+def test_adam_groups_with_depth_before_color_and_a_step_without_depth_targets():
+    """render(depth_before_color=True) feeds the VDN head's output to the colour network (renderer.py:247-248), so in the reference
+    the head has a colour-loss gradient - and Adam steps - from iteration 0; only the background network's dpt_linear waits for
+    the depth-feature loss (dpt_runner.py:239-243). And a step whose loss has no depth term (here: no gt_feats) leaves those
+    parameters' .grad None, which torch.optim.Adam skips - no step on zero gradients, no step-count advance. Compared with
+    torch.optim.Adam fed the Trainer's own gradients."""
+    from vdn_train import synth, factory
+    from vdn_train.trainer import Trainer
+    dev = torch.device("cuda:0")
+    B, seed = 64, 13
+    st = synth.make_all_states(seed, wdepth=True, depth_before_color=True)
+    rend = factory.build_renderer(wdepth=True, device=dev, states=st, depth_before_color=True)
+    tr = Trainer(rend, B, dev, conf=dict(extract_depth=True, depth_start_iter=1, warm_up_end=10))
+    dpt_ids = {id(p) for p in rend.nerf.dpt_linear.parameters()}
+    assert {id(tr.params[i]) for i in tr._depth_idx} == dpt_ids            # the VDN head is NOT in the late group
+    vdn_ids = {id(p) for p in rend.depth_network.parameters()}
+    shadow = [torch.nn.Parameter(p.detach().clone()) for p in tr.params]
+    start = [p.detach().clone() for p in tr.params]
+    opt = torch.optim.Adam(shadow, lr=1.0)
+    cams = synth.make_cameras(seed)
+    g = lambda x: torch.tensor(x).to(dev)
+    feats = g(synth.uniform(seed, "adam/feats", (B, 96)).astype(np.float32))
+    for it in range(6):
+        o, d = synth.random_pixel_batch(seed, it, 0, B, cams=cams)
+        near, far = synth.near_far_from_sphere(o, d)
+        t1, t2 = synth.jitter(seed, it, B)
+        lr = tr.learning_rate()
+        gt = None if it == 4 else feats                       # one step of the depth phase without depth targets
+        depth_on = tr.iter_step > 1 and gt is not None
+        tr.train_step(g(o), g(d), g(near), g(far), g(synth.target_colors(o, d)), gt_feats=gt, t_rand=g(t1), t_rand_out=g(t2))
+        grads = tr.engine.param_grads(clone=True)
+        for gq in opt.param_groups:
+            gq["lr"] = lr
+        for i, (sp, gr) in enumerate(zip(shadow, grads)):
+            sp.grad = None if (i in tr._depth_idx and not depth_on) else gr.view_as(sp).clone()
+        opt.step()
+        for i, (sp, p) in enumerate(zip(shadow, tr.params)):
+            err = (sp.detach() - p.detach()).abs().max().item()
+            assert err < 2e-6, (it, i, err)
+        if it == 0:      # the head moved in the very first step (its gradient comes through the colour network)
+            moved = [(p.detach() - s0).abs().max().item() for p, s0 in zip(tr.params, start) if id(p) in vdn_ids]
+            assert min(moved) > 0.0
+    assert tr._depth_adam_steps == 3          # iterations 2, 3, 5
+    steps = {int(v["step"]) for v in tr.state_dict()["optimizer"]["state"].values()}
+    assert steps == {6, 3}

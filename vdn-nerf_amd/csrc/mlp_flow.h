@@ -34,7 +34,7 @@ VDN_DEV void wait_vmcnt() {
 // through M0 (used by nothing else in these kernels). See vdn_common.h: glds16 for why this is not the builtin.
 VDN_DEV void glds16_saddr(const char* base_uniform, unsigned lane_off, char* lds_wave_base) {
     const unsigned lds = (unsigned)(size_t)lds_wave_base;
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" ::"v"(lane_off), "s"(lds), "s"(base_uniform) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" ::"v"(lane_off), "s"(lds), "s"(base_uniform) : "memory", "m0");
 }
 
 // A program: struct with

@@ -44,10 +44,10 @@ VDN_DEV int rho(int t, int h) { return (t & 3) + 8 * (t >> 2) + 4 * h; }
 // and from then on emits s_waitcnt lgkmcnt(0) in front of every LDS consumer - a full LDS round trip before each MFMA
 // group instead of a counted wait (measured on the SDF forward kernel, profiles/README.md round 2). The kernels count
 // these loads themselves (WStream::acquire's vmcnt); the compiler does not see them. M0 (the LDS destination base) is
-// used by nothing else in these kernels.
+// declared clobbered.
 VDN_DEV void glds16(const void* gsrc_lane, void* lds_wave_base) {
     const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc_lane), "s"(lds) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc_lane), "s"(lds) : "memory", "m0");
 }
 
 // Hardware transcendental forms (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp each): what the MLP

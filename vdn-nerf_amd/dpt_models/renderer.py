@@ -382,7 +382,10 @@ class NeuSRenderer:
             z_att = z + (zc - zc.detach())
         z_out_att = z_out
         if z_out is not None:
-            c = (z_out - 1.0 / S) / far_d.reshape(B, 1)                            # z_out = far * c + 1 / n_samples (renderer.py:359)
+            fd = far_d.reshape(B, 1)
+            # z_out = far * c + 1 / n_samples (renderer.py:359); a ray with far == 0 has z_out = 1 / n_samples for every c: its
+            # (zero-valued) graph term gets c = 0 instead of 0 / 0
+            c = torch.where(fd != 0, (z_out - 1.0 / S) / torch.where(fd != 0, fd, torch.ones_like(fd)), torch.zeros_like(z_out))
             z_out_att = z_out + (far - far.detach()) * c
         return rays_o.contiguous(), rays_d.contiguous(), z_att, z_out_att
 

@@ -73,6 +73,16 @@ class RaysGenerator:
         v = out[:, 3:6].reshape(self.W // l, self.H // l, 3).transpose(0, 1)
         return o, v
 
+    def image_at(self, idx, resolution_level=1):
+        """poses.py:254-256: image `idx` in 0..255 at 1/resolution_level size, channel order as loaded (BGR). cv.resize's default
+        INTER_LINEAR = bilinear taps at half-pixel centres, edges clamped, no anti-aliasing (F.interpolate, align_corners=False)."""
+        img = self.images[int(idx)]
+        l = int(resolution_level)
+        if l != 1:
+            img = torch.nn.functional.interpolate(img.permute(2, 0, 1)[None], size=(self.H // l, self.W // l), mode="bilinear",
+                                                  align_corners=False, antialias=False)[0].permute(1, 2, 0)
+        return (img.cpu().numpy() * 255).clip(0, 255)
+
     def gen_rays_between(self, ratio, idx_0, idx_1, resolution_level=1):
         """poses.py:214-252: rays of a camera interpolated between two views - translation linearly, rotation by Slerp, both
         on the world-to-camera side as the reference does - with the first camera's intrinsics. -> rays_o, rays_v [H/l, W/l, 3].

@@ -50,7 +50,10 @@ class Trainer:
         self._depth_idx = set()
         ranges, off = [], 0
         dn = renderer.depth_network
-        depth_ids = set(id(p) for p in dn.parameters()) if dn is not None else set()
+        # render(depth_before_color=True) feeds the VDN head's output to the colour network (renderer.py:247-248): the head then
+        # has a colour-loss gradient from iteration 0 and steps with everything else; only dpt_linear waits for the depth loss
+        dbc = dn is not None and renderer.color_network.conf["d_feature"] == 352
+        depth_ids = set(id(p) for p in dn.parameters()) if (dn is not None and not dbc) else set()
         dpt = getattr(renderer.nerf, "dpt_linear", None) if renderer.nerf is not None else None
         if dpt is not None:
             depth_ids |= set(id(p) for p in dpt.parameters())
@@ -150,7 +153,9 @@ class Trainer:
             lib.call("vdn_adam_step_ranges", lib.ptr(self.param_flat), lib.ptr(grad), lib.ptr(self.exp_avg), lib.ptr(self.exp_avg_sq),
                      b0, e0, b1, e1, self.learning_rate(), 0.9, 0.999, 1e-8, step, st)
         adam(self._main_ranges, self.iter_step + 1 - self._step0())
-        if self._depth_ranges and (depth_on or self._depth_adam_steps > 0):
+        if self._depth_ranges and depth_on:
+            # only when the depth loss is in this step's loss: torch.optim.Adam skips parameters whose .grad is None (the
+            # runner's zero_grad() resets them every iteration), it does not step them on zero gradients
             self._depth_adam_steps += 1
             adam(self._depth_ranges, self._depth_adam_steps)
         # weights changed behind torch's version counters: rebuild every network's images now, in two launches

@@ -42,8 +42,9 @@ def validate_image(renderer, rays_gen, idx, resolution_level=1, batch_size=512, 
     """Runner.validate_image (dpt_runner.py:520-587): the colour image and the normal image of one camera.
     -> (img_fine [H,W,3] in 0..255, normal_img [H,W,3] in 0..255): normals = sum_i gradients_i * weights_i * inside_sphere_i
     per ray (553-557), rotated into the camera frame by inv(pose[:3,:3]) and mapped by * 128 + 128 (570-573). With `out_dir`
-    the two PNGs are written as the runner names them (validations_fine/, normals/; RGB order on disk, where the runner's
-    cv.imwrite stores its array as BGR)."""
+    the two PNGs are written as the runner writes them (575-587): validations_fine/ holds the render stacked over the
+    ground-truth image (`image_at`), normals/ the normal image. The pipeline's channel order is cv.imread's BGR
+    (dataset._read_png) and cv.imwrite takes its array as BGR, so the files show true colours: PIL gets the array reversed."""
     rays_o, rays_d = rays_gen.gen_rays_at(idx, resolution_level=resolution_level)
     H, W, _ = rays_o.shape
     rays_o, rays_d = rays_o.reshape(-1, 3).contiguous(), rays_d.reshape(-1, 3).contiguous()
@@ -64,9 +65,13 @@ def validate_image(renderer, rays_gen, idx, resolution_level=1, batch_size=512, 
     normal_img = (np.matmul(rot[None, :, :], nrm.cpu().numpy()[:, :, None]).reshape(H, W, 3) * 128 + 128).clip(0, 255)
     if out_dir is not None:
         from PIL import Image
-        for sub, arr in (("validations_fine", img_fine), ("normals", normal_img)):
+        val_im = np.concatenate([img_fine, rays_gen.image_at(idx, resolution_level=resolution_level)])      # dpt_runner.py:577-578
+        for sub, arr in (("validations_fine", val_im), ("normals", normal_img)):
             os.makedirs(os.path.join(out_dir, sub), exist_ok=True)
-            Image.fromarray(arr.astype(np.uint8)).save(os.path.join(out_dir, sub, "{:0>8d}_{}_{}.png".format(iter_step, 0, idx)))
+            # cv.imwrite(path, float array) = the array read as BGR, converted with saturate_cast<uchar> (round to nearest):
+            # hand PIL the RGB view of that
+            Image.fromarray(np.ascontiguousarray(np.rint(arr).clip(0, 255).astype(np.uint8)[..., ::-1])).save(
+                os.path.join(out_dir, sub, "{:0>8d}_{}_{}.png".format(iter_step, 0, idx)))
     return img_fine, normal_img
 
 
