@@ -32,7 +32,7 @@ import torch
 # algorithmic FLOPs (2 per MAC, GEMM work only) - SURVEY.md 8d
 F_SDF, F_SDF1, F_GRAD, F_COL, F_VDN, F_NERF, F_NERF_DPT = 1049088, 918016, 918016, 542720, 590336, 1208320, 1232896
 PEAK = {"f32": 157.3e12, "bf16": 2.5e15}     # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r02"      # profiles/<round>_traffic_*.json: the PMC traffic figures quoted in `roofline.traffic`
 
 
 def flop_per_ray(wdepth, fg_frac=1.0, bg_frac=1.0):
@@ -117,7 +117,7 @@ def spawn_ranks(n):
 class Leg:
     """One configuration of the training step (precision x config) with its own renderer, trainer and resident batches."""
 
-    def __init__(self, args, dev, world, rank, precision, wdepth, n_batches):
+    def __init__(self, args, dev, world, rank, precision, wdepth, n_batches, crop=None):
         from vdn_train import synth, factory
         from vdn_train.trainer import Trainer
         self.world, self.rank, self.dev, self.B, self.wdepth, self.precision = world, rank, dev, args.batch, wdepth, precision
@@ -133,7 +133,7 @@ class Leg:
         self.gt_feats = g(synth.uniform(seed, "bench/feats/%d" % rank, (self.B, 96)).astype(np.float32)) if wdepth else None
 
         def batch(step):
-            o, d = synth.random_pixel_batch(seed, step, int(perm[step % len(perm)]), self.B, rank=rank, cams=cams)
+            o, d = synth.random_pixel_batch(seed, step, int(perm[step % len(perm)]), self.B, rank=rank, cams=cams, crop=crop)
             near, far = synth.near_far_from_sphere(o, d)
             return g(o), g(d), g(near), g(far), g(synth.target_colors(o, d))
         self.batches = [batch(s) for s in range(n_batches)]     # resident in HBM before any timed region
@@ -212,6 +212,12 @@ class Leg:
         o, d = self.batches[0][0], self.batches[0][1]
         with torch.no_grad():
             tk_inf = time_kernel(lambda: rend.sdf_network._run(1, rays=(o, d, eng.w["mid_z"])))
+        # the training-mode launch over ALL rows (what the step launches on a scene whose samples all lie inside the relaxed
+        # sphere, and in the all-samples leg): no work list
+        fgc, eng._fg_compact = eng._fg_compact, False
+        tk_full = time_kernel(lambda: eng._sdf_forward(o, d), iters=4)
+        eng._fg_compact = fgc
+        eng._sdf_forward(o, d)                    # leave the workspace as the step left it
 
         def traffic_of(tag):
             tf = os.path.join(ROOT, "profiles", "%s_traffic_sdf_fwd_%s%s.json" % (PROFILE_ROUND, self.precision, tag))
@@ -231,7 +237,10 @@ class Leg:
                 "achieved": fl_train / tk / 1e12, "peak": PEAK[dtype] / 1e12, "unit": "TFLOP/s", "frac": fl_train / tk / PEAK[dtype],
                 "traffic": tr_train, "traffic_source": src_train, "kernel_ms": tk * 1e3, "points": rows_mean, "per_list": per_list,
                 "inference_launch": {"kernel_ms": tk_inf * 1e3, "points": eng.P, "achieved": fl_inf / tk_inf / 1e12,
-                                     "frac": fl_inf / tk_inf / PEAK[dtype], "traffic": tr_inf, "traffic_source": src_inf}}
+                                     "frac": fl_inf / tk_inf / PEAK[dtype], "traffic": tr_inf, "traffic_source": src_inf},
+                "training_launch_full_rows": {"kernel_ms": tk_full * 1e3, "points": eng.P, "achieved": fl_inf / tk_full / 1e12,
+                                              "frac": fl_inf / tk_full / PEAK[dtype],
+                                              "traffic": None if tr_train is None else tr_train * float(eng.P) / rows_mean}}
 
     def dw_roofline(self):
         eng = self.trainer.engine
@@ -255,6 +264,10 @@ def main():
     ap.add_argument("--headline-only", action="store_true", help="only the headline leg: keeps a rocprof trace of this command to one "
                     "population of launches per kernel (no all-samples / fp32 / wdepth legs, no forward-only renders)")
     ap.add_argument("--no-all-samples", action="store_true", help="skip the leg with the zero-weight work lists off")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the single-kernel timing launches (with --headline-only a rocprof "
+                    "trace of this command then holds nothing but the timed step's own launches)")
+    ap.add_argument("--crop", type=int, default=None, help="draw pixels from a centred crop x crop window (object-centric capture) "
+                    "instead of the full 800 x 800 frame")
     ap.add_argument("--config", choices=["womsk_white", "womsk_white_wdepth"], default="womsk_white",
                     help="womsk_white = BASELINE.json configs[1] (the headline); womsk_white_wdepth = configs[4] (VDN head + depth-feature loss)")
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16",
@@ -288,7 +301,7 @@ def main():
     wdepth = args.config == "womsk_white_wdepth"
     K, W = args.steps, args.warmup
     nb = W + K                                          # distinct resident batches; regions cycle through them
-    head = Leg(args, dev, world, rank, args.precision, wdepth, nb)
+    head = Leg(args, dev, world, rank, args.precision, wdepth, nb, crop=args.crop)
     res = head.measure(W, K)
     extras = {}
     if not args.headline_only:
@@ -312,13 +325,16 @@ def main():
                 head.rend.render(*head.batches[i % nb][:4], background_rgb=bg, cos_anneal_ratio=0.5)
             head.fence()
             extras["forward_only_rays_per_s"] = world * args.batch * nf / (time.time() - t1)
-    roof = head.sdf_kernel_roofline()           # every rank takes part (steps hold collectives); rank 0 gets the numbers
-    roof_dw = head.dw_roofline() if rank == 0 else None
+    roof = roof_dw = None
+    if not args.no_roofline:
+        roof = head.sdf_kernel_roofline()           # every rank takes part (steps hold collectives); rank 0 gets the numbers
+        roof_dw = head.dw_roofline() if rank == 0 else None
 
-    def other_leg(precision, wd):
-        leg = Leg(args, dev, world, rank, precision, wd, nb)
+    def other_leg(precision, wd, crop=None, roofline=True):
+        leg = Leg(args, dev, world, rank, precision, wd, nb, crop=crop)
         r = leg.measure(W, K)
-        r["roofline"] = leg.sdf_kernel_roofline(n_lists=3)
+        if roofline:
+            r["roofline"] = leg.sdf_kernel_roofline(n_lists=3)
         if world > 1:
             leg.fence()
         del leg
@@ -331,6 +347,13 @@ def main():
                                          note="same step on the exact-fp32 MFMA kernels (v_mfma_f32_32x32x2_f32): the path the 1e-4 parity tests hold on")
         if not wdepth:
             extras["wdepth"] = dict(other_leg(args.precision, True), config="womsk_white_wdepth (VDN head 4x256->96 + depth-feature loss, BASELINE.json configs[4])")
+        if args.crop is None:
+            # the same step on an object-centric capture (pixels from the central 420-px window: the object fills the frame, as in
+            # the DTU scenes the shipped configs train on): nearly every foreground sample lies inside the relaxed sphere, so the
+            # SDF-side kernels get no relief from the work lists, while more background samples drop out
+            oc = other_leg(args.precision, wdepth, crop=420)
+            oc["note"] = "pixels drawn from the central 420 x 420 window of the 800 x 800 frames"
+            extras["object_centric"] = oc
 
     if rank == 0:
         dtype = "f32" if args.precision == "fp32" else "bf16"
@@ -340,7 +363,16 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "training step of %s (hierarchical sampling + render forward + backward + gradient "
                                    "all-reduce + Adam): SDF 8x256 + colour 4x256 %s+ NeRF 8x256, 512 rays x (64 coarse + 64 importance "
-                                   "+ 32 outside) per GPU per step" % (args.config, "+ VDN head 4x256->96 " if wdepth else ""),
+                                   "+ 32 outside) per GPU per step; pixels uniform over %s; samples that enter the loss through exact "
+                                   "zeros are skipped: %.0f %% of the foreground and %.0f %% of the background points evaluated%s"
+                                   % (args.config, "+ VDN head 4x256->96 " if wdepth else "",
+                                      "the full 800 x 800 frame" if args.crop is None else "the central %d-px window" % args.crop,
+                                      100.0 * res["foreground_points_evaluated_last_step"] / res["foreground_points_total"],
+                                      100.0 * res["background_points_evaluated_last_step"] / max(res["background_points_total"], 1),
+                                      (" (object_centric leg: %.0f %% / %.0f %%)" % (
+                                          100.0 * extras["object_centric"]["foreground_points_evaluated_last_step"] / extras["object_centric"]["foreground_points_total"],
+                                          100.0 * extras["object_centric"]["background_points_evaluated_last_step"] / max(extras["object_centric"]["background_points_total"], 1)))
+                                      if "object_centric" in extras else ""),
                        "rays_per_gpu": args.batch, "samples_per_ray": 128, "outside_samples": 32, "parallelism": "dp%d" % world,
                        "flop_per_ray": flop_per_ray(wdepth), "allreduce_bytes": head.trainer.param_flat.numel() * 4,
                        # flop_per_ray is SURVEY.md 8d's algorithmic count (every sample evaluated); samples that render_core

@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VDN_ABI_VERSION 17
+#define VDN_ABI_VERSION 18
 
 int vdn_abi_version(void);
 
@@ -262,6 +262,22 @@ typedef struct {
     float* eik_out;            /* [3]: gradient_error, numerator, denominator */
 } VdnCompositeArgs;
 int vdn_alpha_composite_fwd(const VdnCompositeArgs* args_host, void* stream);
+
+/* The eikonal sums of renderer.py:313-315 alone - relax_inside_sphere * (|gradient| - 1)^2 and relax_inside_sphere, summed
+ * per ray and over the batch, with the compositor's own expressions (same translation unit, bit-identical to the values
+ * vdn_alpha_composite_fwd leaves in eik_out) - available as soon as the SDF normals exist: the data-parallel Trainer
+ * launches it right behind the fused SDF kernel and all-reduces (numerator, denominator) over the ranks while the colour
+ * head, the background network and the compositor still run. */
+typedef struct {
+    const float* rays_o;       /* [B,3] */
+    const float* rays_d;       /* [B,3] */
+    const float* mid_z;        /* [B,N] section mid-points */
+    const float* normals;      /* [B*N,3] */
+    int32_t B, N;
+    float* eik_partial;        /* [B,2] workspace */
+    float* eik_out;            /* [3]: gradient_error, numerator, denominator */
+} VdnEikonalArgs;
+int vdn_eikonal_terms(const VdnEikonalArgs* args_host, void* stream);
 
 /* ======================= training step: backward of the render path ============================
  * The reference back-propagates with autograd (dpt_runner.py:253) through renderer.py:209-330 and,

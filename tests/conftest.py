@@ -29,6 +29,15 @@ def relmax(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
+def relelem(a, b, rtol=1e-4, floor=1e-6):
+    """Element-wise form of "within 1e-4 rel": worst |a-b| / (rtol |b| + floor max|b|) over the tensor; <= 1 passes.
+    Unlike relmax, an entry much smaller than the tensor's largest one is still held to rtol of ITS size (down to the
+    floor, 1e-6 of the largest entry - fp32 round-off of the sums that produce it)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float((np.abs(a - b) / (rtol * np.abs(b) + floor * np.abs(b).max() + 1e-300)).max())
+
+
 @pytest.fixture(scope="session")
 def golden():
     cache = {}

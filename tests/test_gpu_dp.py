@@ -104,6 +104,65 @@ def test_two_rank_gradient_over_rccl():
     _two_rank_vs_single(True, "nccl")
 
 
+def _one_rank_worker(port, q, backend):
+    """Fresh process, process group first (before anything touches the GPU), then two Trainers in lockstep: one without
+    collectives, one with the collective path forced on in the one-rank group."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "vdn-nerf_amd"))
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda", 0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    torch.cuda.set_device(dev)
+    from vdn_train import synth, factory
+    from vdn_train.trainer import Trainer
+    conf = dict(WDEPTH_CONF, warm_up_end=10)
+    trs = [Trainer(factory.build_renderer(wdepth=True, device=dev, states=synth.make_all_states(SEED, wdepth=True)), B, dev, conf=conf,
+                   collectives=c) for c in (None, True)]
+    assert not trs[0].coll.enabled and trs[1].coll.enabled
+    g = lambda x: torch.tensor(x).to(dev)
+    cams = synth.make_cameras(SEED)
+    same = True
+    for it in range(4):
+        o, d = synth.random_pixel_batch(SEED, it, it, B, cams=cams)
+        near, far = synth.near_far_from_sphere(o, d)
+        t1, t2 = synth.jitter(SEED, it, B)
+        args = [g(o), g(d), g(near), g(far), g(synth.target_colors(o, d))]
+        sc = [tr.train_step(*args, gt_feats=g(_gt_feats(0)), t_rand=g(t1), t_rand_out=g(t2)).clone() for tr in trs]
+        same = same and torch.equal(sc[0], sc[1]) and torch.equal(trs[0].engine.grad_flat, trs[1].engine.grad_flat)
+        same = same and torch.equal(trs[0].param_flat, trs[1].param_flat)
+    torch.cuda.synchronize()
+    q.put((bool(same), float(sc[1][0].item()), float(trs[1].engine.grad_flat.abs().max().item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("backend", ["nccl", "gloo"])
+def test_one_rank_group_runs_the_collective_path_bit_for_bit(backend):
+    """RCCL on the one GPU of the test box: a ONE-rank "nccl" process group, the Trainer's collective path forced on
+    (Trainer(collectives=True): the early eikonal-sum all-reduce beside the colour head / compositor, the SDF gradient slice on
+    the main stream, the other slices on the side stream beside the next sampler, the parameter broadcast). A one-rank
+    all-reduce is the identity, so every step must equal the step without collectives bit for bit - losses, gradients,
+    parameters - which also exercises the ordering of both streams against RCCL's own stream."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_worker, args=(port, q, backend))
+    p.start()
+    same, loss, gmax = q.get(timeout=600)
+    p.join(timeout=600)
+    assert p.exitcode == 0
+    assert same and np.isfinite(loss) and gmax > 0
+
+
 def _bench(cmd, env=None):
     import json
     import subprocess

@@ -257,6 +257,7 @@ def test_trainer_three_adam_steps_match_reference(golden):
         t1, t2 = synth.jitter(seed, it, B)
         sc = tr.train_step(o, d, near, far, rgb, t_rand=g(t1, dev), t_rand_out=g(t2, dev))
         assert abs(sc[0].item() - fx["losses"][it]) < 5e-5 * abs(fx["losses"][it]), (it, sc[0].item(), fx["losses"][it])
+    tr.join()          # the background / colour networks' half of the last step runs on the side stream (Trainer docstring)
     named = [("nerf." + n, p) for n, p in rend.nerf.named_parameters()] + [("sdf." + n, p) for n, p in rend.sdf_network.named_parameters()] + \
             [("variance", rend.deviation_network.variance)] + [("color." + n, p) for n, p in rend.color_network.named_parameters()]
     for n, p in named:

@@ -164,7 +164,8 @@ def test_adam_groups_with_depth_before_color_and_a_step_without_depth_targets():
         for i, (sp, p) in enumerate(zip(shadow, tr.params)):
             err = (sp.detach() - p.detach()).abs().max().item()
             assert err < 2e-6, (it, i, err)
-        if it == 0:      # the head moved in the very first step (its gradient comes through the colour network)
+        if it == 1:      # the head moves from the first step with a non-zero learning rate (warm-up: lr = 0 at iteration 0), long
+            # before the depth loss: its gradient comes through the colour network
             moved = [(p.detach() - s0).abs().max().item() for p, s0 in zip(tr.params, start) if id(p) in vdn_ids]
             assert min(moved) > 0.0
     assert tr._depth_adam_steps == 3          # iterations 2, 3, 5

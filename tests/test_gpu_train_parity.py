@@ -49,3 +49,36 @@ def test_training_is_bitwise_reproducible():
                 tr.train_step(*args, gt_feats=feats, t_rand=gg(t1), t_rand_out=gg(t2))
             assert torch.equal(trs[0].engine.grad_flat, trs[1].engine.grad_flat), (wdepth, it)
         assert torch.equal(trs[0].param_flat, trs[1].param_flat)
+
+
+def test_overlapped_schedule_is_bit_identical_to_the_in_order_one():
+    """Trainer(overlap=True) - the default: the colour / VDN / background networks' weight-gradient GEMM, their Adam step and
+    their weight images on the side stream, beside the next step's sampler - launches the same kernels on the same data as the
+    in-order schedule: losses, gradients, parameters and Adam moments must be identical bit for bit at every step (a missing
+    stream dependency shows up here as a difference)."""
+    import torch
+    from vdn_train import synth, factory
+    from vdn_train.trainer import Trainer
+    dev = torch.device("cuda:0")
+    B, seed = 512, 3
+    cams = synth.make_cameras(seed)
+    gg = lambda x: torch.tensor(x).to(dev)
+    conf = dict(warm_up_end=20, end_iter=300, anneal_end=40, extract_depth=True, depth_start_iter=5)
+    trs = []
+    for ov in (True, False):
+        torch.manual_seed(0)
+        trs.append(Trainer(factory.build_renderer(wdepth=True, device=dev, precision="bf16"), B, dev, conf=conf, overlap=ov))
+    assert trs[0].overlap and not trs[1].overlap
+    feats = gg(synth.uniform(seed, "ovl/feats", (B, 96)).astype(np.float32))
+    for it in range(24):
+        o, d = synth.random_pixel_batch(seed, it, it % 40, B, cams=cams, crop=420)
+        near, far = synth.near_far_from_sphere(o, d)
+        t1, t2 = synth.jitter(seed, it, B)
+        args = [gg(o), gg(d), gg(near), gg(far), gg(synth.target_colors(o, d, 0.5))]
+        sc = [tr.train_step(*args, gt_feats=feats, t_rand=gg(t1), t_rand_out=gg(t2)).clone() for tr in trs]
+        assert torch.equal(sc[0], sc[1]), it
+        if it % 4 == 3:       # (reading the buffers joins the streams: not at every step, so that steps do overlap)
+            assert torch.equal(trs[0].engine.grad_flat, trs[1].engine.grad_flat), it
+    assert torch.equal(trs[0].param_flat, trs[1].param_flat)
+    assert torch.equal(trs[0].exp_avg, trs[1].exp_avg) and torch.equal(trs[0].exp_avg_sq, trs[1].exp_avg_sq)
+    assert trs[0]._depth_adam_steps == trs[1]._depth_adam_steps > 0

@@ -533,6 +533,43 @@ __global__ void eikonal_reduce_kernel(const float* partial, int B, float* out3) 
     }
 }
 
+// The eikonal sums of composite_kernel on their own (same element -> lane mapping, same expressions, same double-precision
+// wave sums: bit-identical partials), for the data-parallel step, which reduces them over the ranks early (vdn_eikonal_terms).
+__global__ __launch_bounds__(kRayWaves * 64) void eikonal_terms_kernel(VdnEikonalArgs a) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * kRayWaves + wave;
+    if (r >= a.B) return;
+    const int N = a.N;
+    float o[3], d[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        o[k] = a.rays_o[r * 3 + k];
+        d[k] = a.rays_d[r * 3 + k];
+    }
+    double eik_num = 0.0, eik_den = 0.0;
+#pragma unroll
+    for (int e = 0; e < kEPL; ++e) {
+        const int i = kEPL * lane + e;
+        if (i < N) {
+            const long q = (long)r * N + i;
+            const float g0 = a.normals[q * 3], g1 = a.normals[q * 3 + 1], g2 = a.normals[q * 3 + 2];
+            const float mz = a.mid_z[q];
+            const float x = o[0] + d[0] * mz, y = o[1] + d[1] * mz, w = o[2] + d[2] * mz;
+            const float pn = sqrtf(x * x + y * y + w * w);
+            const float relax = pn < 1.2f ? 1.0f : 0.0f;
+            const float gn = sqrtf(g0 * g0 + g1 * g1 + g2 * g2) - 1.0f;
+            eik_num += (double)(relax * (gn * gn));
+            eik_den += (double)relax;
+        }
+    }
+    eik_num = wave_sum(eik_num);
+    eik_den = wave_sum(eik_den);
+    if (lane == 0) {
+        a.eik_partial[r * 2] = (float)eik_num;
+        a.eik_partial[r * 2 + 1] = (float)eik_den;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // ray generation (poses.py:168-212, dataset.py:111-118): one thread per ray, images resident in HBM
 // ------------------------------------------------------------------------------------------
@@ -798,6 +835,14 @@ extern "C" int vdn_sections(const VdnSectionArgs* a, void* stream) {
     if (!a || a->B <= 0 || a->n <= 0 || !a->z || !a->dists || !a->mid_z || a->ld < a->n) return -1;
     const int n = a->B * a->n;
     hipLaunchKernelGGL(sections_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int vdn_eikonal_terms(const VdnEikonalArgs* a, void* stream) {
+    if (!a || a->B <= 0 || a->N <= 0 || a->N > kMaxT) return -1;
+    if (!a->rays_o || !a->rays_d || !a->mid_z || !a->normals || !a->eik_partial || !a->eik_out) return -2;
+    hipLaunchKernelGGL(eikonal_terms_kernel, dim3((a->B + kRayWaves - 1) / kRayWaves), dim3(kRayWaves * 64), 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(eikonal_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a->eik_partial, a->B, a->eik_out);
     return (int)hipGetLastError();
 }
 

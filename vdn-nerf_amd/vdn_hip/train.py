@@ -77,6 +77,7 @@ class TrainEngine:
         self._side2 = torch.cuda.Stream(device=dev) if (use_side and renderer.depth_network is not None) else None
         self._ev_fork2 = torch.cuda.Event() if self._side2 is not None else None
         self._ev_join2 = torch.cuda.Event() if self._side2 is not None else None
+        self._ev_heads = torch.cuda.Event() if use_side else None
         self._pending = False
         self._fg_compact = self._bg_compact = False
         precs = {m.precision for m in (renderer.nerf, renderer.sdf_network, renderer.color_network, renderer.depth_network) if m is not None}
@@ -138,10 +139,10 @@ class TrainEngine:
         # colour, vdn): the single message of the data-parallel all-reduce
         self.params = renderer._all_parameters()
         total = sum(p.numel() for p in self.params)
-        self.grad_flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._grad_flat = torch.zeros(total, dtype=torch.float32, device=dev)
         views, off = {}, 0
         for p in self.params:
-            views[id(p)] = self.grad_flat[off:off + p.numel()].view(p.shape)
+            views[id(p)] = self._grad_flat[off:off + p.numel()].view(p.shape)
             off += p.numel()
         self.grad_views = views
         self.nets = {"sdf": _Net(renderer.sdf_network, dev, views), "color": _Net(renderer.color_network, dev, views)}
@@ -229,6 +230,11 @@ class TrainEngine:
         fin = np.zeros(len(ent), dtype=lib.struct_dtype("VdnDwFinalizeDesc"))
         slab_elems, cs_elems, wg = 0, 0, 0
         lay = []
+        # Two launch groups: the SDF network's entries (the critical path into the next step: its sampler only needs the SDF
+        # weights) and the rest (colour / VDN heads, background network). `ent` lists the SDF entries first, so the group
+        # tables are a prefix and a suffix of the full table; the suffix copy numbers its workgroups from its own zero.
+        n_sdf = sum(1 for e in ent if e["net"] == "sdf")
+        assert all(e["net"] == "sdf" for e in ent[:n_sdf]) and all(e["net"] != "sdf" for e in ent[n_sdf:])
         for i, e in enumerate(ent):
             mt = len(e["rmap"]) // 32
             nt = 0 if e["cmap"] is None else len(e["cmap"]) // 32
@@ -294,6 +300,12 @@ class TrainEngine:
                     bt = net.bias_target(e["name"])
                     fd["btarget"], fd["bscale"] = bt.data_ptr(), 1.0
         self.dw_table = torch.from_numpy(dw.view(np.uint8)).to(dev)
+        wg_sdf = int(dw[n_sdf]["wg_begin"]) if n_sdf < len(ent) else wg
+        rest = dw[n_sdf:].copy()
+        rest["wg_begin"] -= wg_sdf
+        self.dw_groups = {"sdf": (self.dw_table, n_sdf, wg_sdf)}
+        if len(rest):
+            self.dw_groups["rest"] = (torch.from_numpy(rest.view(np.uint8)).to(dev), len(rest), wg - wg_sdf)
         # one more finalize descriptor: d loss / d variance = sum over rays of the compositor's per-ray partials (a [B,1] "column
         # sum" with one row): the reduction rides in the finalize launch instead of a launch of its own
         vfin = np.zeros(1, dtype=fin.dtype)
@@ -301,18 +313,24 @@ class TrainEngine:
         vfin[0]["colsum"], vfin[0]["rmap"] = w["d_var_partial"].data_ptr(), self._var_map.data_ptr()
         vfin[0]["btarget"], vfin[0]["bscale"] = self.grad_views[id(self.r.deviation_network.variance)].data_ptr(), 1.0
         vfin[0]["splits"], vfin[0]["M"], vfin[0]["N"] = self.B, 1, 0
-        fin = np.concatenate([fin, vfin])
-        self.fin_table = torch.from_numpy(fin.view(np.uint8)).to(dev)
-        self.fin_has_phase1 = bool((fin["accumulate"] != 0).any())
-        self.n_fin = len(fin)
+        fin_all = np.concatenate([fin, vfin])
+        self.fin_table = torch.from_numpy(fin_all.view(np.uint8)).to(dev)
+        self.fin_has_phase1 = bool((fin_all["accumulate"] != 0).any())
+        self.n_fin = len(fin_all)
         self.n_dw = len(ent)
         self.fin_max_M = int(max(len(e["rmap"]) for e in ent))
+        # per-group finalize tables (the variance's reduction rides with the SDF group)
+        fg = {"sdf": np.concatenate([fin[:n_sdf], vfin]), "rest": fin[n_sdf:]}
+        mm = {"sdf": ent[:n_sdf], "rest": ent[n_sdf:]}
+        self.fin_groups = {k: (torch.from_numpy(v.view(np.uint8).copy()).to(dev), len(v), int(max(len(e["rmap"]) for e in mm[k])),
+                               bool((v["accumulate"] != 0).any())) for k, v in fg.items() if len(v) and len(mm[k])}
         # weight-norm backward table
-        rows = []
-        for net in self.nets.values():
+        rows, row_group = [], []
+        for key, net in self.nets.items():          # "sdf" first (dict order of self.nets)
             for name, (g, v, b) in net.img.matrices.items():
                 if g is not None:
                     rows.append((g, v, net.img.inv_norm[net.img.r_off[name]:], net.dweff_view(name), net.grads[id(g)], net.grads[id(v)]))
+                    row_group.append("sdf" if key == "sdf" else "rest")
         wn = np.zeros(len(rows), dtype=lib.struct_dtype("VdnWeightNormBwdDesc"))
         for i, (g, v, inv, dwe, dg, dv) in enumerate(rows):
             wn[i]["g"], wn[i]["v"], wn[i]["inv_norm"], wn[i]["dw_eff"] = g.data_ptr(), v.data_ptr(), inv.data_ptr(), dwe.data_ptr()
@@ -320,7 +338,19 @@ class TrainEngine:
         self.wn_table = torch.from_numpy(wn.view(np.uint8).copy() if len(rows) else np.zeros(8, np.uint8)).to(dev)
         self.n_wn = len(rows)
         self.wn_max_rows = max([r[1].shape[0] for r in rows] + [1])
+        self.wn_groups = {}
+        for k in ("sdf", "rest"):
+            idx = [i for i, gk in enumerate(row_group) if gk == k]
+            if idx:
+                self.wn_groups[k] = (torch.from_numpy(wn[idx].view(np.uint8).copy()).to(dev), len(idx), max(rows[i][1].shape[0] for i in idx))
         self._param_ptrs = self._ptr_key()
+
+    @property
+    def grad_flat(self):
+        """The flat gradient buffer (dpt_runner.py:121-130 parameter order), complete on torch's current stream."""
+        if getattr(self, "join_hook", None) is not None:     # the Trainer's deferred half of the backward (side stream)
+            self.join_hook()
+        return self._grad_flat
 
     def _ptr_key(self):
         return tuple(p.data_ptr() for net in self.nets.values() for p in net.module.parameters())
@@ -338,7 +368,8 @@ class TrainEngine:
                 w["d_bg_pts"], w["d_bg_dirs"], w["d_bg_dists"], w["d_z_out"] = f(Q, 3), f(Q, 3), f(B, T), f(B, T - N)
         return w
 
-    def forward(self, rays_o, rays_d, z, z_out, background_rgb, cos_anneal_ratio, skip_far=False, ray_grads=False, pending_merge=None):
+    def forward(self, rays_o, rays_d, z, z_out, background_rgb, cos_anneal_ratio, skip_far=False, ray_grads=False, pending_merge=None,
+                after_sdf=None):
         """Differentiable part of render() at detached z [B,N] (+ z_out [B,O]); returns the output tensors.
         skip_far (the Trainer's hot loop): inside samples beyond the relaxed sphere (|p| >= 1.2: inside_sphere = 0 and
         relax_inside_sphere = 0, renderer.py:284-286) enter the loss only through exact zeros, so the SDF / colour / VDN
@@ -349,6 +380,7 @@ class TrainEngine:
         if ray_grads and skip_far:
             raise ValueError("ray gradients need every inside sample evaluated (skip_far=False)")
         self._ray_grads = bool(ray_grads)
+        self._fwd_rays = (rays_o, rays_d)
         if ray_grads:
             self._ray_workspaces()
         for net in self.nets.values():
@@ -423,6 +455,8 @@ class TrainEngine:
             lib.call("vdn_nerf_mlp_fwd" + self.sfx, n, self._side_handle(st))
             self._side_done()
         self._sdf_forward(rays_o, rays_d)
+        if after_sdf is not None:       # (the data-parallel Trainer reduces the eikonal sums over the ranks from here on)
+            after_sdf(self)
 
         def rnet(net, out, save_h, small, d_out, module, stream=None):
             c = lib.VdnRenderNetArgs()
@@ -526,6 +560,41 @@ class TrainEngine:
     def _launch_dw(self):
         lib.call("vdn_dw_gemm" + self.sfx, lib.ptr(self.dw_table), self.n_dw, self.dw_total_wgs, _stream())
 
+    def rest_weight_grads(self, after=None):
+        """Second half of backward(defer_rest=True): the colour / VDN / background networks' weight gradients, issued on the side
+        stream behind the background network's backward (or, without a side stream, on the caller's stream). `after`: an event
+        the work should also wait for (the Trainer passes the SDF group's GEMM, so that the two HBM-bound GEMMs do not share the
+        chip and this one runs beside the next step's sampler instead). Returns the torch stream it was issued on (None = the
+        caller's): the caller orders its next use of those gradients / planes behind it."""
+        if self._side is None:
+            self.weight_grads("rest", _stream())
+            return None
+        self._side.wait_event(self._ev_heads)
+        if after is not None:
+            self._side.wait_event(after)
+        self.weight_grads("rest", self._side.cuda_stream)
+        self._pending = False            # joined by the caller's own event, not by _join()
+        return self._side
+
+    def weight_grads(self, group, stream, gemm_event=None):
+        """Weight-gradient GEMM + finalize + weight-norm backward of one launch group ("sdf": the SDF network and the variance;
+        "rest": colour / VDN heads and the background network) on `stream` (a raw handle). The two groups touch disjoint
+        slabs and disjoint ranges of the flat gradient buffer. gemm_event: recorded on torch's current stream (which must be
+        `stream`) right behind the GEMM launch."""
+        if group in self.dw_groups:
+            tab, n, wgs = self.dw_groups[group]
+            lib.call("vdn_dw_gemm" + self.sfx, lib.ptr(tab), n, wgs, stream)
+        if gemm_event is not None:
+            gemm_event.record(torch.cuda.current_stream())
+        if group in self.fin_groups:
+            tab, n, max_m, phase1 = self.fin_groups[group]
+            lib.call("vdn_dw_finalize", lib.ptr(tab), n, max_m, 0, stream)
+            if phase1:
+                lib.call("vdn_dw_finalize", lib.ptr(tab), n, max_m, 1, stream)
+        if group in self.wn_groups:
+            tab, n, max_rows = self.wn_groups[group]
+            lib.call("vdn_weightnorm_bwd", lib.ptr(tab), n, max_rows, stream)
+
     def _composite_common(self, c, rays_o, rays_d, background_rgb, cos_anneal_ratio):
         w, r = self.w, self.r
         c.rays_o, c.rays_d, c.sdf, c.normals = rays_o.data_ptr(), rays_d.data_ptr(), w["sdf"].data_ptr(), w["normals"].data_ptr()
@@ -544,9 +613,12 @@ class TrainEngine:
         return c
 
     # ------------------------------------------------------------------------------------------
-    def backward(self, g_color, g_feat, g_weights, g_eik, g_cdf=None, g_gradients=None):
+    def backward(self, g_color, g_feat, g_weights, g_eik, g_cdf=None, g_gradients=None, defer_rest=False, gemm_event=None):
         """Upstream grads (any may be None) -> list of parameter grads (clones) per network. g_cdf [B,N] / g_gradients
-        [B,N,3]: adjoints of the `cdf_fine` / `gradients` outputs (the reference returns them attached, renderer.py:426-439)."""
+        [B,N,3]: adjoints of the `cdf_fine` / `gradients` outputs (the reference returns them attached, renderer.py:426-439).
+        defer_rest (the Trainer's hot loop): only the SDF network's and the variance's gradients are complete on return (on the
+        caller's stream); the caller finishes the others with rest_weight_grads() - on the side stream, behind the background
+        network's backward - so that they overlap whatever follows on the main stream."""
         r, w, st = self.r, self.w, _stream()
         rays_o, rays_d, background_rgb, car, z = self._ctx
         c = self._composite_common(lib.VdnCompositeBwdArgs(), rays_o, rays_d, background_rgb, car)
@@ -622,6 +694,8 @@ class TrainEngine:
         # (accumulate flag covers both d_feat and d_normals; d_normals must always accumulate)
         if self.wdepth:
             rnet_bwd("vdn", w["d_vdn"], w["vdn_out"], w["vdn_h"], w["vdn_dout"], w["vdn_dh"], 96, r.depth_network, True)
+        if defer_rest and self._side is not None:
+            self._ev_heads.record(torch.cuda.current_stream())      # the heads' deltas (operands of the rest group) are complete
 
         rb = lib.VdnSdfRbarArgs()
         img = self.nets["sdf"].img
@@ -644,6 +718,11 @@ class TrainEngine:
             fb.g_normals, fb.U_pe, fb.acc_pts, fb.d_pts = w["d_normals"].data_ptr(), w["U_pe"].data_ptr(), 1, w["d_pts"].data_ptr()
         lib.call("vdn_sdf_bwd_fbar" + self.sfx, self._fg(fb), st)
 
+        if defer_rest:
+            if rg:
+                raise ValueError("defer_rest is the Trainer's path: no ray gradients there")
+            self.weight_grads("sdf", st, gemm_event)
+            return self._grad_flat
         self._join()
         self._launch_dw()
         lib.call("vdn_dw_finalize", lib.ptr(self.fin_table), self.n_fin, self.fin_max_M, 0, st)
@@ -661,9 +740,11 @@ class TrainEngine:
                 ra.d_bg_pts, ra.d_bg_dirs, ra.d_bg_dists, ra.d_z_out = (w[k].data_ptr() for k in ("d_bg_pts", "d_bg_dirs", "d_bg_dists", "d_z_out"))
             ra.d_rays_o, ra.d_rays_d, ra.d_z = w["d_rays_o"].data_ptr(), w["d_rays_d"].data_ptr(), w["d_z"].data_ptr()
             lib.call("vdn_ray_adjoint", ra, st)
-        # gradients now sit in self.grad_flat (views per parameter in self.grad_views)
-        return self.grad_flat
+        # gradients now sit in self._grad_flat (views per parameter in self.grad_views)
+        return self._grad_flat
 
     def param_grads(self, clone=True):
         """Per-parameter gradients in renderer._all_parameters() order."""
+        if getattr(self, "join_hook", None) is not None:     # the Trainer's deferred half of the backward (side stream)
+            self.join_hook()
         return [self.grad_views[id(p)].clone() if clone else self.grad_views[id(p)] for p in self.params]

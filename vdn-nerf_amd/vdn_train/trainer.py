@@ -3,9 +3,19 @@ on the MI355X engine: loss, Adam, warm-up + cosine learning rate, cos-anneal, th
 ramp, checkpoints in the reference's key schema, and ray-sharded data parallelism.
 
 The hot loop does not go through autograd: TrainEngine.forward -> fused loss kernel ->
-TrainEngine.backward -> (one all-reduce of the flat gradient) -> fused Adam on flat buffers.
+TrainEngine.backward -> (all-reduce of the gradient slices) -> fused Adam on flat buffers.
+
+Schedule of one step (overlap=True, the default): the next step begins with the sampler - four dependent SDF-only passes
+that fill a quarter of the chip - so the step ends in two halves:
+  main stream   ... SDF backward -> SDF weight-gradient GEMM -> [all-reduce SDF slice] -> Adam(SDF, variance) -> SDF images
+                -> next step's sampler ...
+  side stream   background backward -> (SDF GEMM done) -> colour / VDN / background weight-gradient GEMM ->
+                [all-reduce their slices] -> Adam(rest) -> their images            (joined before the next forward)
+The HBM-bound second GEMM and the collectives run beside the latency-bound sampler. Results are identical to the in-order
+schedule (overlap=False) bit for bit: the same launches on the same data, only on two streams.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -23,7 +33,11 @@ def _stream():
 
 
 class Trainer:
-    def __init__(self, renderer, batch_size, device, conf=None, world_size=1, rank=0):
+    def __init__(self, renderer, batch_size, device, conf=None, world_size=1, rank=0, collectives=None, overlap=None):
+        """collectives: None = on when world_size > 1; True runs the collective calls also in a one-rank group (the RCCL path
+        on a single GPU). overlap: None = on (VDN_OVERLAP=0 turns it off) - see the module docstring; after train_step the
+        colour / VDN / background parameters and gradients are then complete on the side stream: join() before touching them
+        (state_dict, load_checkpoint and TrainEngine.param_grads do)."""
         self.r, self.B, self.dev = renderer, batch_size, torch.device(device)
         self.conf = dict(DEFAULT_TRAIN_CONF)
         self.conf.update(conf or {})
@@ -32,23 +46,24 @@ class Trainer:
         self._img_cache = {}
         # flatten: every Parameter becomes a view of one buffer (names / state_dict unchanged), so Adam is one
         # launch and the gradient all-reduce one message
-        self.params = renderer._all_parameters()
-        total = sum(p.numel() for p in self.params)
-        self.param_flat = torch.empty(total, dtype=torch.float32, device=self.dev)
+        self._params = renderer._all_parameters()
+        total = sum(p.numel() for p in self._params)
+        self._param_flat = torch.empty(total, dtype=torch.float32, device=self.dev)
         off = 0
         with torch.no_grad():
-            for p in self.params:
+            for p in self._params:
                 n = p.numel()
-                self.param_flat[off:off + n].copy_(p.detach().reshape(-1))
-                p.data = self.param_flat[off:off + n].view(p.shape)
+                self._param_flat[off:off + n].copy_(p.detach().reshape(-1))
+                p.data = self._param_flat[off:off + n].view(p.shape)
                 off += n
-        self.exp_avg = torch.zeros_like(self.param_flat)
-        self.exp_avg_sq = torch.zeros_like(self.param_flat)
+        self._exp_avg = torch.zeros_like(self._param_flat)
+        self._exp_avg_sq = torch.zeros_like(self._param_flat)
         # torch.optim.Adam keeps a step count per parameter and skips parameters whose .grad is None. In the reference that
         # is the VDN head and the background network's dpt_linear until the depth-feature loss first enters the loss
         # (dpt_runner.py:239-243): their moments and bias correction start THEN. Two groups of flat-buffer ranges:
         self._depth_idx = set()
         ranges, off = [], 0
+        crit_ids = set(id(p) for m in (renderer.sdf_network, renderer.deviation_network) for p in m.parameters())
         dn = renderer.depth_network
         # render(depth_before_color=True) feeds the VDN head's output to the colour network (renderer.py:247-248): the head then
         # has a colour-loss gradient from iteration 0 and steps with everything else; only dpt_linear waits for the depth loss
@@ -57,24 +72,37 @@ class Trainer:
         dpt = getattr(renderer.nerf, "dpt_linear", None) if renderer.nerf is not None else None
         if dpt is not None:
             depth_ids |= set(id(p) for p in dpt.parameters())
-        for i, p in enumerate(self.params):
-            is_d = id(p) in depth_ids
-            if is_d:
+        for i, p in enumerate(self._params):
+            kind = "depth" if id(p) in depth_ids else ("sdf" if id(p) in crit_ids else "rest")
+            if kind == "depth":
                 self._depth_idx.add(i)
-            if ranges and ranges[-1][0] == is_d:
+            if ranges and ranges[-1][0] == kind:
                 ranges[-1][2] = off + p.numel()
             else:
-                ranges.append([is_d, off, off + p.numel()])
+                ranges.append([kind, off, off + p.numel()])
             off += p.numel()
-        self._main_ranges = [(b, e) for d, b, e in ranges if not d]
-        self._depth_ranges = [(b, e) for d, b, e in ranges if d]
-        if len(self._main_ranges) > 2 or len(self._depth_ranges) > 2:
+        # step groups of the fused Adam (two element ranges per launch): the SDF network + variance (critical path), the other
+        # parameters that step from iteration 0, and the late group
+        self._sdf_ranges = [(b, e) for k, b, e in ranges if k == "sdf"]
+        self._rest_ranges = [(b, e) for k, b, e in ranges if k == "rest"]
+        self._depth_ranges = [(b, e) for k, b, e in ranges if k == "depth"]
+        if len(self._sdf_ranges) != 1 or len(self._rest_ranges) > 2 or len(self._depth_ranges) > 2:
             raise ValueError("unexpected parameter order: the fused Adam handles two ranges per step group")
+        # all-reduce slices of the flat gradient: the SDF slice, and whatever lies before / behind it (dpt_runner.py:121-130 order)
+        (sb, se), total = self._sdf_ranges[0], off
+        self._slices_rest = [(b, e) for b, e in ((0, sb), (se, total)) if e > b]
         self._depth_adam_steps = 0          # optimizer steps the depth group has taken
-        if world_size > 1:
-            import torch.distributed as dist
-            dist.broadcast(self.param_flat, 0)     # replicas must start from rank 0's parameters (e.g. per-process random init)
+        self.coll = dp.Collectives(world_size, force=bool(collectives))
+        if self.coll.enabled:
+            self.coll.broadcast(self._param_flat, 0)     # replicas must start from rank 0's parameters (e.g. per-process random init)
         self.engine = TrainEngine(renderer, batch_size, self.dev)
+        self.overlap = (os.environ.get("VDN_OVERLAP", "1") != "0") if overlap is None else bool(overlap)
+        self._ev_gemm, self._ev_rest = torch.cuda.Event(), torch.cuda.Event()
+        self._rest_pending = False
+        self.engine.join_hook = self.join
+        self._eik_global = torch.zeros(3, dtype=torch.float32, device=self.dev)
+        self._eik_partial = torch.zeros(batch_size, 2, dtype=torch.float32, device=self.dev)
+        self._eik_handles = []
         B, T = batch_size, self.engine.T
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.dev)
         self.g_color, self.g_weights, self.g_eik, self.scalars = f(B, 3), f(B, T), f(1), f(6)
@@ -122,13 +150,19 @@ class Trainer:
             u = torch.rand(B * (1 + r.n_outside), device=self.dev)
             t_rand, t_rand_out = u[:B].view(B, 1), u[B:].view(B, r.n_outside)
         with torch.no_grad():
+            # (the sampler only reads the SDF weight images: it runs beside the previous step's side-stream half)
             z, z_out = r._sample(rays_o, rays_d, near.reshape(B), far.reshape(B), r.perturb, t_rand, t_rand_out, z_vals_inject,
                                  defer_last_merge=True)
+        self.join()
         w = eng.forward(rays_o, rays_d, z.contiguous(), z_out, self.bg, self.cos_anneal_ratio(), skip_far=True,
-                        pending_merge=r._pending_merge)
-        if self.world > 1:
-            # the eikonal term is a ratio of sums over the GLOBAL batch (renderer.py:313-315)
-            w["eik"][0:1].copy_(dp.global_eikonal(w["eik"][1:3]).reshape(1))
+                        pending_merge=r._pending_merge, after_sdf=self._eikonal_begin if self.coll.enabled else None)
+        if self.coll.enabled:
+            # the eikonal term is a ratio of sums over the GLOBAL batch (renderer.py:313-315): its two sums were
+            # on their way since the SDF kernel finished; the loss kernel and the compositor's adjoint read w["eik"]
+            self.coll.finish(self._eik_handles)
+            eg = self._eik_global
+            eg[0:1] = eg[1:2] / (eg[2:3] + 1e-5)
+            w["eik"].copy_(eg)
         depth_on = self.conf["extract_depth"] and self.iter_step > self.conf["depth_start_iter"] and gt_feats is not None
         a = lib.VdnLossArgs()
         a.color, a.true_rgb, a.weights, a.eik = w["color"].data_ptr(), true_rgb.data_ptr(), w["weights"].data_ptr(), w["eik"].data_ptr()
@@ -144,43 +178,96 @@ class Trainer:
             a.depth_weight = self.depth_iter_weight()
             self.depth_iter += 1
         lib.call("vdn_loss_fwd_bwd", a, st)
-        grad = eng.backward(self.g_color, self.g_feats if depth_on else None,
-                            self.g_weights if self.conf["mask_weight"] != 0.0 else None, self.g_eik)
-        if self.world > 1:
-            dp.allreduce_flat(grad)                # one flat message: all gradients of all networks
-        def adam(ranges, step):
+        g_feats = self.g_feats if depth_on else None
+        g_weights = self.g_weights if self.conf["mask_weight"] != 0.0 else None
+        lr, main_step = self.learning_rate(), self.iter_step + 1 - self._step0()
+
+        def adam(ranges, step, stream):
             (b0, e0), (b1, e1) = ranges[0], (ranges[1] if len(ranges) > 1 else (0, 0))
-            lib.call("vdn_adam_step_ranges", lib.ptr(self.param_flat), lib.ptr(grad), lib.ptr(self.exp_avg), lib.ptr(self.exp_avg_sq),
-                     b0, e0, b1, e1, self.learning_rate(), 0.9, 0.999, 1e-8, step, st)
-        adam(self._main_ranges, self.iter_step + 1 - self._step0())
-        if self._depth_ranges and depth_on:
+            lib.call("vdn_adam_step_ranges", lib.ptr(self._param_flat), lib.ptr(grad), lib.ptr(self._exp_avg), lib.ptr(self._exp_avg_sq),
+                     b0, e0, b1, e1, lr, 0.9, 0.999, 1e-8, step, stream)
+
+        rest_nets = [k for k in eng.nets if k != "sdf"]
+        if depth_on and self._depth_ranges:
             # only when the depth loss is in this step's loss: torch.optim.Adam skips parameters whose .grad is None (the
             # runner's zero_grad() resets them every iteration), it does not step them on zero gradients
             self._depth_adam_steps += 1
-            adam(self._depth_ranges, self._depth_adam_steps)
-        # weights changed behind torch's version counters: rebuild every network's images now, in two launches
-        images.refresh_together([net.img for net in eng.nets.values()], st, self._img_cache)
+        depth_step = self._depth_adam_steps if (depth_on and self._depth_ranges) else 0
+
+        def update_rest(stream):
+            self.coll.finish(self.coll.begin([grad[b:e] for b, e in self._slices_rest]))
+            if self._rest_ranges:
+                adam(self._rest_ranges, main_step, stream)
+            if depth_step:
+                adam(self._depth_ranges, depth_step, stream)
+            images.refresh_together([eng.nets[k].img for k in rest_nets], stream, self._img_cache.setdefault("rest", {}))
+
+        def update_sdf(stream):
+            self.coll.finish(self.coll.begin([grad[b:e] for b, e in self._sdf_ranges]))
+            adam(self._sdf_ranges, main_step, stream)
+            images.refresh_together([eng.nets["sdf"].img], stream, self._img_cache.setdefault("sdf", {}))
+
+        grad = eng._grad_flat
+        eng.backward(self.g_color, g_feats, g_weights, self.g_eik, defer_rest=True, gemm_event=self._ev_gemm if self.overlap else None)
+        update_sdf(st)
+        side = eng.rest_weight_grads(after=self._ev_gemm) if self.overlap else None
+        if side is None:
+            if not self.overlap:
+                eng._join()                     # the background network's backward (side stream) feeds the rest group
+                eng.weight_grads("rest", st)
+            update_rest(st)
+        else:
+            with torch.cuda.stream(side):
+                update_rest(side.cuda_stream)
+                self._ev_rest.record(side)
+            self._rest_pending = True
         self.iter_step += 1
         return self.scalars        # device tensor [loss, color_loss, psnr, eikonal, depth_loss, mask_loss]; no host sync here
+
+    # the flat buffers / the parameter list as seen from outside: complete on torch's current stream
+    params = property(lambda self: (self.join(), self._params)[1])
+    param_flat = property(lambda self: (self.join(), self._param_flat)[1])
+    exp_avg = property(lambda self: (self.join(), self._exp_avg)[1])
+    exp_avg_sq = property(lambda self: (self.join(), self._exp_avg_sq)[1])
+
+    def join(self):
+        """Order torch's current stream behind the side-stream half of the last step (colour / VDN / background gradients,
+        their Adam step and weight images). train_step calls it before its forward; call it before reading those parameters
+        or rendering with the renderer outside the Trainer."""
+        if self._rest_pending:
+            torch.cuda.current_stream().wait_event(self._ev_rest)
+            self._rest_pending = False
+
+    def _eikonal_begin(self, eng):
+        """Right behind the fused SDF kernel: this rank's eikonal sums (vdn_eikonal_terms: the compositor's own expressions) and
+        the start of their all-reduce, which then runs under the colour head, the background network and the compositor."""
+        rays_o, rays_d = eng._fwd_rays
+        a = lib.VdnEikonalArgs()
+        a.rays_o, a.rays_d, a.mid_z, a.normals = rays_o.data_ptr(), rays_d.data_ptr(), eng.w["mid_z"].data_ptr(), eng.w["normals"].data_ptr()
+        a.B, a.N = eng.B, eng.N
+        a.eik_partial, a.eik_out = self._eik_partial.data_ptr(), self._eik_global.data_ptr()
+        lib.call("vdn_eikonal_terms", a, _stream())
+        self._eik_handles = self.coll.begin([self._eik_global[1:3]])
 
     def _step0(self):
         return getattr(self, "_adam_step_offset", 0)
 
     # ---- checkpoints in the reference's schema (dpt_runner.py:366-381, 350-359)
     def state_dict(self):
+        self.join()
         r = self.r
         state, off = {}, 0
-        for i, p in enumerate(self.params):
+        for i, p in enumerate(self._params):
             n = p.numel()
             steps = self._depth_adam_steps if i in self._depth_idx else self.iter_step - self._step0()
             if steps > 0:          # torch.optim.Adam has no state for a parameter that never had a gradient
                 state[i] = {"step": torch.tensor(float(steps)),
-                            "exp_avg": self.exp_avg[off:off + n].view(p.shape).clone(),
-                            "exp_avg_sq": self.exp_avg_sq[off:off + n].view(p.shape).clone()}
+                            "exp_avg": self._exp_avg[off:off + n].view(p.shape).clone(),
+                            "exp_avg_sq": self._exp_avg_sq[off:off + n].view(p.shape).clone()}
             off += n
         opt = {"state": state,
                "param_groups": [{"lr": self.learning_rate(), "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0, "amsgrad": False,
-                                 "params": list(range(len(self.params)))}]}
+                                 "params": list(range(len(self._params)))}]}
         cl = lambda m: {k: v.detach().clone() for k, v in m.state_dict().items()}
         return {"nerf": cl(r.nerf), "sdf_network_fine": cl(r.sdf_network), "variance_network_fine": cl(r.deviation_network),
                 "color_network_fine": cl(r.color_network),
@@ -192,6 +279,7 @@ class Trainer:
 
     def load_checkpoint(self, path_or_dict):
         ck = torch.load(path_or_dict, map_location=self.dev) if isinstance(path_or_dict, str) else path_or_dict
+        self.join()
         r = self.r
         with torch.no_grad():
             def load(mod, sd, strict=True):
@@ -212,13 +300,13 @@ class Trainer:
             st = ck["optimizer"]["state"]
             off = 0
             steps = {False: 0, True: 0}           # per step group: (main, depth)
-            self.exp_avg.zero_()
-            self.exp_avg_sq.zero_()
-            for i, p in enumerate(self.params):
+            self._exp_avg.zero_()
+            self._exp_avg_sq.zero_()
+            for i, p in enumerate(self._params):
                 n = p.numel()
                 if i in st:
-                    self.exp_avg[off:off + n].copy_(st[i]["exp_avg"].reshape(-1).to(self.dev))
-                    self.exp_avg_sq[off:off + n].copy_(st[i]["exp_avg_sq"].reshape(-1).to(self.dev))
+                    self._exp_avg[off:off + n].copy_(st[i]["exp_avg"].reshape(-1).to(self.dev))
+                    self._exp_avg_sq[off:off + n].copy_(st[i]["exp_avg_sq"].reshape(-1).to(self.dev))
                     g = i in self._depth_idx
                     steps[g] = max(steps[g], int(st[i]["step"]))
                 off += n
