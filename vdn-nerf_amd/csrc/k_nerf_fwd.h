@@ -71,7 +71,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void nerf_fwd_ke
         };
     };
     auto sv = [&](int l) VDN_INL { return save_h ? save_h + l * PS : (ST*)nullptr; };
-    const int est = save_h != nullptr ? 4 : 0;
+    const int est = save_h != nullptr ? P::kTileOps : 0;
     ws.all_issue = __any(ok);
     put_pe(true);
     ws.start();

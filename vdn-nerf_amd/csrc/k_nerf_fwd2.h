@@ -29,10 +29,10 @@ struct NerfFwdProg {
     // conditional and uncounted, which can only make a wait longer
     static constexpr int stores(int c) {
         if (!SAVE || c < 0 || c >= total) return 0;
-        if (c < 64) return 4;                   // save_h tile
-        if (c < 72) return 4;                   // save_feature tile
+        if (c < 64) return BF16::kTileOps;      // save_h tile
+        if (c < 72) return BF16::kTileOps;      // save_feature tile
         if (c < 73) return 0;                   // alpha row
-        if (c < 77) return 4;                   // save_hv tile
+        if (c < 77) return BF16::kTileOps;      // save_hv tile
         return 0;
     }
 };

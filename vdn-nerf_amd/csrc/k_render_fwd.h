@@ -71,7 +71,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_f
             if (save_h != nullptr) P::store_tile(save_h + l * PS, p, 256, nt, h, o, ok);
         };
     };
-    const int est = save_h != nullptr ? 4 : 0;
+    const int est = save_h != nullptr ? P::kTileOps : 0;
     ws.all_issue = __any(ok);
     ws.start();
     dense<P, 10 + EX, 8, true>(ws, X, 0, NoPre{}, relu_into(Y, 0), est);

@@ -12,12 +12,14 @@
 // This is the hand-derived form of what autograd builds for reference fields.py:97-108 with
 // create_graph=True and then differentiates in dpt_runner.py:253.
 #pragma once
+#include <cstdlib>
 #include "mlp_engine.h"
 #include "vdn_kernels.h"
 
 namespace vdn {
 
-template <class P>
+// PF: chunk steps between the issue of a tile's plane loads and their use (mlp_engine.h: dense)
+template <class P, int PF>
 __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_rbar_kernel(SdfRbarArgs a) {
     using ST = typename P::store_t;
     constexpr int kSlot = P::stride(9);
@@ -112,23 +114,23 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_rbar_ke
     };
     ws.all_issue = __any(ok);
     ws.start();
-    dense<P, 2, 8, false>(ws, X, 0, ldSV(0), epi(Y, ub1, 256, 0), 8, 8);
-    dense<P, 8, 8, false>(ws, Y, 0, ldSV(1), epi(X, ub2, 256, 1), 8, 8);
-    dense<P, 8, 8, false>(ws, X, 0, ldSV(2), epi(Y, ub3, 256, 2), 8, 8);
-    dense<P, 8, 7, false>(ws, Y, 0, ldSV(3), epi(X, ub4, 288, 3), 8, 8);      // ub_4[h part]: 7 tiles
+    dense<P, 2, 8, false, PF>(ws, X, 0, ldSV(0), epi(Y, ub1, 256, 0), 2 * P::kTileOps, 2 * P::kTileOps);
+    dense<P, 8, 8, false, PF>(ws, Y, 0, ldSV(1), epi(X, ub2, 256, 1), 2 * P::kTileOps, 2 * P::kTileOps);
+    dense<P, 8, 8, false, PF>(ws, X, 0, ldSV(2), epi(Y, ub3, 256, 2), 2 * P::kTileOps, 2 * P::kTileOps);
+    dense<P, 8, 7, false, PF>(ws, Y, 0, ldSV(3), epi(X, ub4, 288, 3), 2 * P::kTileOps, 2 * P::kTileOps);      // ub_4[h part]: 7 tiles
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {                                        // ub_4[PE part] = ub_total
         const f32x16 t16 = vals_tile<39>(ub39, h, kt);
         X.set(7 + kt, t16);
         P::store_tile(ub4, p, 288, 7 + kt, h, t16, ok);
     }
-    dense<P, 9, 8, false>(ws, X, 0, ldSV(4), epi(Y, ub5, 256, 4), 8, 8);
-    dense<P, 8, 8, false>(ws, Y, 0, ldSV(5), epi(X, ub6, 256, 5), 8, 8);
-    dense<P, 8, 8, false>(ws, X, 0, ldSV(6), epi(Y, ub7, 256, 6), 8, 8);
-    dense<P, 8, 8, false>(ws, Y, 0, ldSV(7), epi(X, ub8, 256, 7), 8, 8);
+    dense<P, 9, 8, false, PF>(ws, X, 0, ldSV(4), epi(Y, ub5, 256, 4), 2 * P::kTileOps, 2 * P::kTileOps);
+    dense<P, 8, 8, false, PF>(ws, Y, 0, ldSV(5), epi(X, ub6, 256, 5), 2 * P::kTileOps, 2 * P::kTileOps);
+    dense<P, 8, 8, false, PF>(ws, X, 0, ldSV(6), epi(Y, ub7, 256, 6), 2 * P::kTileOps, 2 * P::kTileOps);
+    dense<P, 8, 8, false, PF>(ws, Y, 0, ldSV(7), epi(X, ub8, 256, 7), 2 * P::kTileOps, 2 * P::kTileOps);
 }
 
-template <class P>
+template <class P, int PF>
 __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_fbar_kernel(SdfFbarArgs a) {
     using ST = typename P::store_t;
     constexpr int kSlot = P::stride(9);
@@ -215,14 +217,14 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_fbar_ke
     };
     ws.all_issue = __any(ok);
     ws.start();
-    dense<P, 9, 8, false>(ws, X, 0, ldSE(7), epi(Y, 7), 4, 8);     // W8^T
-    dense<P, 8, 8, false>(ws, Y, 0, ldSE(6), epi(X, 6), 4, 8);     // W7^T
-    dense<P, 8, 8, false>(ws, X, 0, ldSE(5), epi(Y, 5), 4, 8);     // W6^T
-    dense<P, 8, 8, false>(ws, Y, 0, ldSE(4), epi(X, 4), 4, 8);     // W5^T
+    dense<P, 9, 8, false, PF>(ws, X, 0, ldSE(7), epi(Y, 7), P::kTileOps, 2 * P::kTileOps);     // W8^T
+    dense<P, 8, 8, false, PF>(ws, Y, 0, ldSE(6), epi(X, 6), P::kTileOps, 2 * P::kTileOps);     // W7^T
+    dense<P, 8, 8, false, PF>(ws, X, 0, ldSE(5), epi(Y, 5), P::kTileOps, 2 * P::kTileOps);     // W6^T
+    dense<P, 8, 8, false, PF>(ws, Y, 0, ldSE(4), epi(X, 4), P::kTileOps, 2 * P::kTileOps);     // W5^T
     {   // W4^T: 9 output tiles = [h4 part (7) | PE part (2: the skip input's adjoint, only wanted for differentiable rays)]
         ST* dst = ab(3);
         f32x16 PE4[2];
-        dense<P, 8, 9, false>(ws, X, 0,
+        dense<P, 8, 9, false, PF>(ws, X, 0,
             [&](int nt) VDN_INL {
                 SE r;
                 if (nt < 7) {
@@ -247,9 +249,9 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_fbar_ke
             });
         if (want_pts) pe_adjoint(PE4);
     }
-    dense<P, 7, 8, false>(ws, Y, 0, ldSE(2), epi(X, 2), 4, 8);     // W3^T
-    dense<P, 8, 8, false>(ws, X, 0, ldSE(1), epi(Y, 1), 4, 8);     // W2^T
-    dense<P, 8, 8, false>(ws, Y, 0, ldSE(0), epi(X, 0), 4, 8);      // W1^T
+    dense<P, 7, 8, false, PF>(ws, Y, 0, ldSE(2), epi(X, 2), P::kTileOps, 2 * P::kTileOps);     // W3^T
+    dense<P, 8, 8, false, PF>(ws, X, 0, ldSE(1), epi(Y, 1), P::kTileOps, 2 * P::kTileOps);     // W2^T
+    dense<P, 8, 8, false, PF>(ws, Y, 0, ldSE(0), epi(X, 0), P::kTileOps, 2 * P::kTileOps);      // W1^T
     if (want_pts) {
         // d loss / d point = scale * d loss / d xin:  J_PE^T (W0^T ab_0 + [W4^T ab_4]_PE)  through the activations, plus the
         // explicit dependence of normal = scale * J_PE(xin)^T u on xin at fixed u (the u-dependence went through rbar):
@@ -276,6 +278,12 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_fbar_ke
     }
 }
 
+// VDN_PLANE_PREFETCH = 1 | 2 (default 2): read once per process
+inline int plane_prefetch_depth() {
+    static const int d = [] { const char* e = getenv("VDN_PLANE_PREFETCH"); return (e != nullptr && e[0] == '1') ? 1 : 2; }();
+    return d;
+}
+
 template <class P>
 int launch_sdf_rbar(const VdnSdfRbarArgs* args, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -283,9 +291,12 @@ int launch_sdf_rbar(const VdnSdfRbarArgs* args, void* stream_) {
     if (!args->pts && (!args->rays_o || !args->rays_d || !args->z || args->n_per_ray <= 0 || args->z_ld < args->n_per_ray)) return -2;
     const int ppw = P::kWaves * 32;
     const size_t lds = 3 * P::stride(9);
-    static bool once = (allow_big_lds(sdf_rbar_kernel<P>, lds), true);
+    static bool once = (allow_big_lds(sdf_rbar_kernel<P, 1>, lds), allow_big_lds(sdf_rbar_kernel<P, 2>, lds), true);
     (void)once;
-    hipLaunchKernelGGL((sdf_rbar_kernel<P>), dim3((args->P + ppw - 1) / ppw), dim3(P::kWaves * 64), lds, stream, *args);
+    if (plane_prefetch_depth() == 2)
+        hipLaunchKernelGGL((sdf_rbar_kernel<P, 2>), dim3((args->P + ppw - 1) / ppw), dim3(P::kWaves * 64), lds, stream, *args);
+    else
+        hipLaunchKernelGGL((sdf_rbar_kernel<P, 1>), dim3((args->P + ppw - 1) / ppw), dim3(P::kWaves * 64), lds, stream, *args);
     return (int)hipGetLastError();
 }
 
@@ -297,9 +308,12 @@ int launch_sdf_fbar(const VdnSdfFbarArgs* args, void* stream_) {
                         (!args->pts && (!args->rays_o || !args->rays_d || !args->z || args->n_per_ray <= 0 || args->z_ld < args->n_per_ray)))) return -2;
     const int ppw = P::kWaves * 32;
     const size_t lds = 3 * P::stride(9);
-    static bool once = (allow_big_lds(sdf_fbar_kernel<P>, lds), true);
+    static bool once = (allow_big_lds(sdf_fbar_kernel<P, 1>, lds), allow_big_lds(sdf_fbar_kernel<P, 2>, lds), true);
     (void)once;
-    hipLaunchKernelGGL((sdf_fbar_kernel<P>), dim3((args->P + ppw - 1) / ppw), dim3(P::kWaves * 64), lds, stream, *args);
+    if (plane_prefetch_depth() == 2)
+        hipLaunchKernelGGL((sdf_fbar_kernel<P, 2>), dim3((args->P + ppw - 1) / ppw), dim3(P::kWaves * 64), lds, stream, *args);
+    else
+        hipLaunchKernelGGL((sdf_fbar_kernel<P, 1>), dim3((args->P + ppw - 1) / ppw), dim3(P::kWaves * 64), lds, stream, *args);
     return (int)hipGetLastError();
 }
 

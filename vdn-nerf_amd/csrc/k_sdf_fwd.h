@@ -91,8 +91,8 @@ __global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(Sdf
                 }
             });
     };
-    const int est_h = SV ? (Hs != nullptr && !derive ? 8 : 4) : 0;     // stores per hidden-layer tile (S and / or H)
-    const int est_v = Vs != nullptr ? 4 : 0;                // stores per sweep tile (V when training)
+    const int est_h = SV ? (Hs != nullptr && !derive ? 2 * P::kTileOps : P::kTileOps) : 0;     // stores per hidden-layer tile (S and / or H)
+    const int est_v = Vs != nullptr ? P::kTileOps : 0;                // stores per sweep tile (V when training)
     put_pe(0);
     ws.start();
     dense<P, 2, 8, true>(ws, X, 0, NoPre{}, hidden(Y, 0), est_h);
@@ -168,9 +168,9 @@ __global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(Sdf
                 }
             }
         };
-        dense<P, 8, 8, false>(ws, Y, 0, loadS(6), mulInto(X, 6), est_v, 4);   // through W7^T
-        dense<P, 8, 8, false>(ws, X, 0, loadS(5), mulInto(Y, 5), est_v, 4);   // W6^T
-        dense<P, 8, 8, false>(ws, Y, 0, loadS(4), mulInto(X, 4), est_v, 4);   // W5^T
+        dense<P, 8, 8, false>(ws, Y, 0, loadS(6), mulInto(X, 6), est_v, P::kTileOps);   // through W7^T
+        dense<P, 8, 8, false>(ws, X, 0, loadS(5), mulInto(Y, 5), est_v, P::kTileOps);   // W6^T
+        dense<P, 8, 8, false>(ws, Y, 0, loadS(4), mulInto(X, 4), est_v, P::kTileOps);   // W5^T
         {   // W4^T: 9 output tiles = [h4 part (7 tiles) | PE part (2 tiles)]
             f32x16 UPE[2];
             dense<P, 8, 9, false>(ws, X, 0,
@@ -188,9 +188,9 @@ __global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(Sdf
                 });
             pe_backward(UPE, true);
         }
-        dense<P, 7, 8, false>(ws, Y, 0, loadS(2), mulInto(X, 2), est_v, 4);   // W3^T
-        dense<P, 8, 8, false>(ws, X, 0, loadS(1), mulInto(Y, 1), est_v, 4);   // W2^T
-        dense<P, 8, 8, false>(ws, Y, 0, loadS(0), mulInto(X, 0), est_v, 4);   // W1^T
+        dense<P, 7, 8, false>(ws, Y, 0, loadS(2), mulInto(X, 2), est_v, P::kTileOps);   // W3^T
+        dense<P, 8, 8, false>(ws, X, 0, loadS(1), mulInto(Y, 1), est_v, P::kTileOps);   // W2^T
+        dense<P, 8, 8, false>(ws, Y, 0, loadS(0), mulInto(X, 0), est_v, P::kTileOps);   // W1^T
         f32x16 U0[2];
         dense<P, 8, 2, false>(ws, X, 0, NoPre{}, [&](int nt, const f32x16& acc, int) VDN_INL { U0[nt] = acc; });   // W0^T
         pe_backward(U0, false);

@@ -90,11 +90,11 @@ constexpr int tile_stores(int c) {
     if (c < 0 || c >= PG::total) return 0;
     const LayerDesc d = PG::layer(PG::layer_of(c));
     const int t = PG::tile_of(c);
-    switch (d.kind) {
-        case HID: return SAVE ? 4 : 0;                                           // H plane tile
-        case LAST: return (MODE == 1 && t < 8) ? (SAVE ? 8 : 4) : 0;             // feature tile (+ V[7] tile)
-        case SWEEP: return SAVE ? 4 : 0;                                         // V[l]
-        case SWEEP_SKIP: return (SAVE && t < 7) ? 4 : 0;
+    switch (d.kind) {      // (two 16-byte stores per plane tile: BF16::kTileOps)
+        case HID: return SAVE ? 2 : 0;                                           // H plane tile
+        case LAST: return (MODE == 1 && t < 8) ? (SAVE ? 4 : 2) : 0;             // feature tile (+ V[7] tile)
+        case SWEEP: return SAVE ? 2 : 0;                                         // V[l]
+        case SWEEP_SKIP: return (SAVE && t < 7) ? 2 : 0;
         default: return 0;
     }
 }
@@ -261,20 +261,31 @@ VDN_DEV f32x16 chunk_step(Pipe<NSLOT>& pp, const ActT& X, Group&& group) {
     return acc;
 }
 
-// softplus in scaled units:  t -> g = max(t,0) + log2(1 + 2^-|t|)
-VDN_DEV float softplus_t(float t) {
-#if VDN_SDF2_ABL & 1
-    return t;
+#ifndef VDN_SDF2_SP
+#define VDN_SDF2_SP 1   // softplus form: 0 = max(t,0) + log2(1 + 2^-|t|), sigma from 2^-g;  1 = med3(log2(1 + 2^t), t, 25), sigma from 1 / (1 + 2^t)
 #endif
+// softplus in scaled units, t -> g = log2(1 + 2^t), and E = 2^-g = 1 - sigma(100 a) = 1 / (1 + 2^t).
+// Form 1 (one VALU instruction fewer per value, and E no longer waits for g): w = 1 + 2^t overflows to +inf from t = 128 on
+// (log2 -> +inf) and for t >= 25 the f32 value of log2(w) is t itself, so g = median(log2(w), t, 25) - one v_med3_f32 - is exact
+// on both sides: below 25 the logarithm lies between t and 25, from 25 on t lies between 25 and the (possibly infinite)
+// logarithm. For t <= -25 w rounds to 1 and g to 0 (true value < 2^-25 units = 2e-10 in h). E = 1/w: 0 at +inf, 1 at w = 1.
+struct SpE { float g, e; };
+VDN_DEV SpE softplus_sigma(float t) {
+    SpE r;
+#if VDN_SDF2_ABL & 1
+    r.g = t; r.e = t;
+    return r;
+#endif
+#if VDN_SDF2_SP == 1
+    const float w = 1.0f + __builtin_amdgcn_exp2f(t);
+    r.g = __builtin_amdgcn_fmed3f(__builtin_amdgcn_logf(w), t, 25.0f);
+    r.e = __builtin_amdgcn_rcpf(w);
+#else
     const float e = __builtin_amdgcn_exp2f(-fabsf(t));
-    return relu0(t) + __builtin_amdgcn_logf(1.0f + e);
-}
-// 2^-g = 1 - sigma(100 a)
-VDN_DEV float one_minus_sigma(float g) {
-#if VDN_SDF2_ABL & 1
-    return g;
+    r.g = relu0(t) + __builtin_amdgcn_logf(1.0f + e);
+    r.e = __builtin_amdgcn_exp2f(-r.g);
 #endif
-    return __builtin_amdgcn_exp2f(-g);
+    return r;
 }
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -356,7 +367,7 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
     ST* Vs = reinterpret_cast<ST*>(a.V);
     ST* feat = reinterpret_cast<ST*>(a.feat);
     const long PS = P::plane(a.P, 256);
-    const long prow = (p >> 5) * (32L * 256) + h * 128 + (p & 31) * 4;       // PT32 offset of this lane's pieces (mlp_engine.h)
+    const long prow = (p >> 5) * (32L * 256) + h * 256 + (p & 31) * 8;       // PT32 offset of this lane's 16-byte pieces (mlp_engine.h)
     const float inv_scale = 1.0f / a.scale;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ordinary loads above: nothing but DMA and stores from here on
 
@@ -402,7 +413,8 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
     f32x16 acc_prev;            // accumulator of the previous chunk's tile (its epilogue runs under this chunk's MFMAs)
     u32x4 sq_prev;              // 255 sigma of the previous chunk's tile: read by the sweep's epilogue, built by a hidden layer's
     u32x4 sq_v7;                // 255 sigma_7 tile while v7 is formed
-    unsigned hold0 = 0, hold1 = 0;  // a pair's values waiting for their partners (one 4-value pack / one 8-byte store)
+    unsigned hold0 = 0, hold1 = 0;  // a pair's values waiting for their partners (one 4-value pack / one 16-byte store)
+    unsigned fhold0 = 0, fhold1 = 0, vhold0 = 0, vhold1 = 0;    // first halves of 16-byte plane pieces (feature / V)
     f32x4 w8hold;               // W8 row 0 at the features of the pair being worked on
     float sdf_dot = 0.0f;       // this lane's half of  W8[0,:] . g8  (f32)
     f32x16 UPE[2];              // d sdf / d(PE) tiles (W4^T rows 7,8 and W0^T)
@@ -440,8 +452,8 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
             if constexpr (L.kind == HID) {
                 static_for<PE_ - PB>([&](auto i_c) VDN_INL {
                     constexpr int pr = PB + decltype(i_c)::value;       // elements 2pr, 2pr+1
-                    const float g0 = softplus_t(acc_prev[2 * pr]);
-                    const float g1 = softplus_t(acc_prev[2 * pr + 1]);
+                    const SpE sp0 = softplus_sigma(acc_prev[2 * pr]), sp1 = softplus_sigma(acc_prev[2 * pr + 1]);
+                    const float g0 = sp0.g, g1 = sp1.g;
                     if constexpr (L.l == 7) {
                         // the sdf row of the last layer in f32 on the VALU, from the unrounded activations: 2 FMAs per pair on
                         // one layer's epilogue, and the output that the alpha multiplies by inv_s loses no bits to bf16
@@ -455,20 +467,15 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
                     D.r[T * 2 + (pr >> 2)] = __builtin_bit_cast(bf16x8, cur);
                     if constexpr (MODE == 1) {
                         if constexpr ((pr & 1) == 0) {
-                            hold0 = __builtin_bit_cast(unsigned, one_minus_sigma(g0));
-                            hold1 = __builtin_bit_cast(unsigned, one_minus_sigma(g1));
+                            hold0 = __builtin_bit_cast(unsigned, sp0.e);
+                            hold1 = __builtin_bit_cast(unsigned, sp1.e);
                             asm volatile("" : "+v"(hold0), "+v"(hold1));
                         } else {
-                            unsigned w = sigma255_pack(__builtin_bit_cast(float, hold0), __builtin_bit_cast(float, hold1),
-                                                       one_minus_sigma(g0), one_minus_sigma(g1));
+                            unsigned w = sigma255_pack(__builtin_bit_cast(float, hold0), __builtin_bit_cast(float, hold1), sp0.e, sp1.e);
                             asm volatile("" : "+v"(w));      // materialise here: otherwise the chain sinks to the tile's end
                             sq_prev[pr >> 1] = w;
-                            if constexpr (SAVE) {       // H plane piece q = pr >> 1: elements 4q .. 4q+3
-                                uint2 o;
-                                o.x = cur[(pr & 3) - 1];
-                                o.y = cur[pr & 3];
-                                *reinterpret_cast<uint2*>(Hs + L.l * PS + prow + T * 1024 + 256 * (pr >> 1)) = o;
-                            }
+                            if constexpr (SAVE && (pr & 3) == 3)        // H plane piece k = pr >> 2 = this k-step's whole B fragment
+                                *reinterpret_cast<u32x4*>(Hs + L.l * PS + prow + T * 1024 + 512 * (pr >> 2)) = cur;
                             if constexpr (pr == 7) SS.template put<PG::s_tile0(L.l) + T>(sq_prev);
                         }
                     }
@@ -480,10 +487,18 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
                         constexpr int pr = PB + decltype(i_c)::value;
                         if constexpr ((pr & 1) == 1) {
                             constexpr int q = pr >> 1;
-                            uint2 o;
-                            o.x = pack_bf16x2(acc_prev[4 * q], acc_prev[4 * q + 1]);
-                            o.y = pack_bf16x2(acc_prev[4 * q + 2], acc_prev[4 * q + 3]);
-                            *reinterpret_cast<uint2*>(feat + prow + T * 1024 + 256 * q) = o;
+                            if constexpr ((q & 1) == 0) {       // first half of the 16-byte piece k = q >> 1 waits for the second
+                                fhold0 = pack_bf16x2(acc_prev[4 * q], acc_prev[4 * q + 1]);
+                                fhold1 = pack_bf16x2(acc_prev[4 * q + 2], acc_prev[4 * q + 3]);
+                                asm volatile("" : "+v"(fhold0), "+v"(fhold1));
+                            } else {
+                                u32x4 o;
+                                o[0] = fhold0;
+                                o[1] = fhold1;
+                                o[2] = pack_bf16x2(acc_prev[4 * q], acc_prev[4 * q + 1]);
+                                o[3] = pack_bf16x2(acc_prev[4 * q + 2], acc_prev[4 * q + 3]);
+                                *reinterpret_cast<u32x4*>(feat + prow + T * 1024 + 512 * (q >> 1)) = o;
+                            }
                             const f32x4 w = *(reinterpret_cast<const f32x4*>(pp.template slot<CP + 1>() + kTail) + (8 * T + 2 * q + h));
                             if constexpr (q == 0) sq_v7 = SS.template get<PG::s_tile0(7) + T>();
                             const unsigned sw = sq_v7[q];
@@ -496,10 +511,18 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
                             cur[2 * (q & 1) + 1] = k1;
                             Y.r[T * 2 + (q >> 1)] = __builtin_bit_cast(bf16x8, cur);
                             if constexpr (SAVE) {
-                                uint2 ov;
-                                ov.x = pack_bf16x2(v0 * kVSave, v1 * kVSave);
-                                ov.y = pack_bf16x2(v2 * kVSave, v3 * kVSave);
-                                *reinterpret_cast<uint2*>(Vs + 7 * PS + prow + T * 1024 + 256 * q) = ov;
+                                if constexpr ((q & 1) == 0) {
+                                    vhold0 = pack_bf16x2(v0 * kVSave, v1 * kVSave);
+                                    vhold1 = pack_bf16x2(v2 * kVSave, v3 * kVSave);
+                                    asm volatile("" : "+v"(vhold0), "+v"(vhold1));
+                                } else {
+                                    u32x4 ov;
+                                    ov[0] = vhold0;
+                                    ov[1] = vhold1;
+                                    ov[2] = pack_bf16x2(v0 * kVSave, v1 * kVSave);
+                                    ov[3] = pack_bf16x2(v2 * kVSave, v3 * kVSave);
+                                    *reinterpret_cast<u32x4*>(Vs + 7 * PS + prow + T * 1024 + 512 * (q >> 1)) = ov;
+                                }
                             }
                         }
                     });
@@ -518,14 +541,22 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
                     if constexpr (SAVE) {
                         // the V plane holds 100 log2(e) v, v = u (.) sigma: the units of H and PE
                         unsigned pv = pack_bf16x2(v0 * kVSave, v1 * kVSave);
-                        if constexpr ((pr & 1) == 0) {
+                        if constexpr ((pr & 3) == 0) {
+                            vhold0 = pv;
+                            asm volatile("" : "+v"(vhold0));
+                        } else if constexpr ((pr & 3) == 1) {
+                            vhold1 = pv;
+                            asm volatile("" : "+v"(vhold1));
+                        } else if constexpr ((pr & 3) == 2) {
                             hold0 = pv;
                             asm volatile("" : "+v"(hold0));
-                        } else {
-                            uint2 o;
-                            o.x = hold0;
-                            o.y = pv;
-                            *reinterpret_cast<uint2*>(Vs + L.l * PS + prow + T * 1024 + 256 * (pr >> 1)) = o;
+                        } else {        // 16-byte piece k = pr >> 2
+                            u32x4 o;
+                            o[0] = vhold0;
+                            o[1] = vhold1;
+                            o[2] = hold0;
+                            o[3] = pv;
+                            *reinterpret_cast<u32x4*>(Vs + L.l * PS + prow + T * 1024 + 512 * (pr >> 2)) = o;
                         }
                     }
                 });

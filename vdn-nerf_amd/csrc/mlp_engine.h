@@ -142,6 +142,7 @@ struct F32 {
     static constexpr bool kDeriveS = false;         // the parity path keeps softplus' exactly as the forward computed it
     static constexpr int chunk_bytes(int KT) { return KT * 4096 + 1024; }
     static constexpr int stride(int KTMAX) { return (chunk_bytes(KTMAX) + 4095) / 4096 * 4096; }   // uniform chunk stride
+    static constexpr int kTileOps = 4;      // vector-memory instructions per store_tile / load_tile (the kernels' vmcnt accounting)
     using store_t = float;
 
     template <int NT>
@@ -347,30 +348,38 @@ struct BF16 {
         return acc;
     }
 
-    // bf16 activation planes use the tile-blocked "PT32" layout: points in blocks of 32 (= one wave's tile),
-    //   element (p, f) at  (p>>5)*(32*ld) + (f>>5)*1024 + ((f&31)>>3)*256 + ((f&7)>>2)*128 + (p&31)*4 + (f&3)
-    // so that a wave's store/load of (tile, q) is ONE contiguous 512-byte run (64 lanes x 8 B) instead of 64
-    // 8-byte pieces in 32 different rows, and the weight-gradient GEMM reads 1 KiB runs. P is padded to 32.
+    // bf16 activation planes use the tile-blocked "PT32" layout: points in blocks of 32 (= one wave's tile); inside a
+    // block, per 32-feature tile (2 KiB):  [k (2)][h (2)][point (32)][8 features = 16 bytes], where the 16-byte unit (k, h, point)
+    // holds accumulator registers 8k .. 8k+7 of lane (point, h) - features 16k + 4h + {0..3} and 16k + 8 + 4h + {0..3}, i.e. exactly
+    // the MFMA B-operand fragment of k-step k:
+    //   element (p, f) at  (p>>5)*(32*ld) + (f>>5)*1024 + ((f>>4)&1)*512 + ((f>>2)&1)*256 + (p&31)*8 + ((f>>3)&1)*4 + (f&3)
+    // A wave's store / load of (tile, k) is ONE contiguous 1-KiB run of 16-byte pieces (two vector-memory instructions per tile;
+    // the first layout of this path used four 8-byte ones - the training-mode kernels are bound by the ISSUE of those
+    // instructions, ~50 cycles each beside the MFMA stream), and the weight-gradient GEMM reads 1-KiB runs. P is padded to 32.
+    static constexpr int kTileOps = 2;      // vector-memory instructions per store_tile / load_tile (the kernels' vmcnt accounting)
     static VDN_DEV long rows(long P) { return (P + 31) & ~31L; }
     static VDN_DEV long plane(long P, int ld) { return rows(P) * ld; }
     static VDN_DEV void store_tile(unsigned short* base, long row, int ld, int tile, int h, const f32x16& v, bool ok) {
         if (!ok) return;
-        unsigned short* p = base + (row >> 5) * (32L * ld) + tile * 1024 + h * 128 + (row & 31) * 4;
+        unsigned short* p = base + (row >> 5) * (32L * ld) + tile * 1024 + h * 256 + (row & 31) * 8;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            uint2 o;
-            o.x = pack_bf16x2(v[4 * q], v[4 * q + 1]);
-            o.y = pack_bf16x2(v[4 * q + 2], v[4 * q + 3]);
-            *reinterpret_cast<uint2*>(p + 256 * q) = o;
+        for (int k = 0; k < 2; ++k) {
+            uint4 o;
+            o.x = pack_bf16x2(v[8 * k], v[8 * k + 1]);
+            o.y = pack_bf16x2(v[8 * k + 2], v[8 * k + 3]);
+            o.z = pack_bf16x2(v[8 * k + 4], v[8 * k + 5]);
+            o.w = pack_bf16x2(v[8 * k + 6], v[8 * k + 7]);
+            *reinterpret_cast<uint4*>(p + 512 * k) = o;
         }
     }
     static VDN_DEV f32x16 load_tile(const unsigned short* base, long row, int ld, int tile, int h) {
-        const unsigned short* p = base + (row >> 5) * (32L * ld) + tile * 1024 + h * 128 + (row & 31) * 4;
+        const unsigned short* p = base + (row >> 5) * (32L * ld) + tile * 1024 + h * 256 + (row & 31) * 8;
         f32x16 r;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint2 o = *reinterpret_cast<const uint2*>(p + 256 * q);
-            r[4 * q] = bf16_lo(o.x); r[4 * q + 1] = bf16_hi(o.x); r[4 * q + 2] = bf16_lo(o.y); r[4 * q + 3] = bf16_hi(o.y);
+        for (int k = 0; k < 2; ++k) {
+            const uint4 o = *reinterpret_cast<const uint4*>(p + 512 * k);
+            r[8 * k] = bf16_lo(o.x); r[8 * k + 1] = bf16_hi(o.x); r[8 * k + 2] = bf16_lo(o.y); r[8 * k + 3] = bf16_hi(o.y);
+            r[8 * k + 4] = bf16_lo(o.z); r[8 * k + 5] = bf16_hi(o.z); r[8 * k + 6] = bf16_lo(o.w); r[8 * k + 7] = bf16_hi(o.w);
         }
         return r;
     }
@@ -380,7 +389,7 @@ struct BF16 {
 // then epi(nt, acc, aux) with aux = pre(nt) evaluated right after the chunk is acquired (so its
 // loads overlap the MFMA loop).
 // epi_stores = vector-memory store instructions every in-range wave issues in epi() per tile, pre_loads = load
-// instructions in pre() per tile (their sum must be 0, 4, 8, 12 or 16; a lower bound is safe, 0 drains the queue
+// instructions in pre() per tile (P::kTileOps per store_tile / load_tile; a lower bound is safe, 0 drains the queue
 // at every step). Both are younger than the glds of the chunk being acquired, so they may stay in flight across
 // the barrier: the prefetched loads then have two chunk steps to land.
 // An epilogue split into a per-register part and a per-tile part:
@@ -405,7 +414,9 @@ VDN_DEV ElemEpi<ScratchT, Elem, Finish> elem_epi(Elem e, Finish f) { return {e, 
 template <class T> struct is_elem_epi : std::false_type {};
 template <class S, class E, class F> struct is_elem_epi<ElemEpi<S, E, F>> : std::true_type {};
 
-template <class P, int KT, int NT, bool BIAS, class WS, class ActT, class Pre, class Epi>
+// PF = how many chunk steps ahead of its use pre(nt) is issued (plain epilogues only): the HBM-bound backward chains run at
+// half their wave slots on the training step's work lists, so each wave keeps two steps of plane loads in flight.
+template <class P, int KT, int NT, bool BIAS, int PF = 1, class WS, class ActT, class Pre, class Epi>
 VDN_DEV void dense(WS& ws, const ActT& X, int x0, Pre&& pre, Epi&& epi, int epi_stores = 0, int pre_loads = 0) {
     const int lane = ws.lane;
     using EpiT = std::remove_cv_t<std::remove_reference_t<Epi>>;
@@ -447,20 +458,28 @@ VDN_DEV void dense(WS& ws, const ActT& X, int x0, Pre&& pre, Epi&& epi, int epi_
         });
         return;
     }
-    // pre(nt) (HBM loads feeding tile nt's epilogue) is issued one chunk step ahead of its use, so a full
-    // step of MFMA + epilogue work hides its latency; tile 0's is issued before the layer's first barrier.
-    auto aux = pre(0);
+    // pre(nt) (HBM loads feeding tile nt's epilogue) is issued PF chunk steps ahead of its use, so PF full steps of
+    // MFMA + epilogue work hide its latency; the first PF tiles' are issued before the layer's first barrier.
+    using Aux = decltype(pre(0));
+    Aux ring[PF];
+    static_for<PF>([&](auto i_c) VDN_INL {
+        constexpr int i = decltype(i_c)::value;
+        if constexpr (i < NT) ring[i] = pre(i);
+    });
     static_for<NT>([&](auto nt_c) VDN_INL {
         constexpr int nt = decltype(nt_c)::value;
         // tile 0 follows another layer's epilogue (unknown store count): only the chunks ahead stay in flight
         constexpr int n_steps = nt < WS::DEPTH ? nt : WS::DEPTH;     // steps of this layer since chunk nt's DMA was issued
-        const int yg = n_steps * (epi_stores + pre_loads);
+        // younger than that DMA: the stores of those steps' epilogues and the loads they issued (step j issues pre(j + PF),
+        // if that tile exists) - counted exactly: a count that is too large would release the wait early
+        constexpr int n_pre = [] { int n = 0; for (int j = nt - n_steps; j < nt; ++j) n += (j + PF < NT) ? 1 : 0; return n; }();
+        const int yg = n_steps * epi_stores + n_pre * pre_loads;
         const char* w = ws.acquire(yg);
-        auto aux_next = aux;
-        if constexpr (nt + 1 < NT) aux_next = pre(nt + 1);
+        Aux nxt{};
+        if constexpr (nt + PF < NT) nxt = pre(nt + PF);
         const f32x16 acc = P::template mma<KT, BIAS>(w, X, x0, lane);
-        epi(nt, acc, aux);
-        aux = aux_next;
+        epi(nt, acc, ring[nt % PF]);
+        if constexpr (nt + PF < NT) ring[nt % PF] = nxt;
         // keep each tile's epilogue inside its own chunk step: without this the scheduler sinks the
         // register-only epilogues of several tiles past the barriers and runs out of registers
         __builtin_amdgcn_sched_barrier(0);

@@ -1,7 +1,8 @@
 // Weight-gradient GEMM on gfx950 with bf16 MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulate):
 // dW[m,n] = sum over points of A[p,m] * B[p,n], A/B = bf16 activation planes in the tile-blocked PT32 layout
 // written by the forward / backward chains (mlp_engine.h: points in blocks of 32; within a (block, 32-feature tile):
-// [fq(8)][point(32)][e(4)], feature = 32*tile + 4*fq + e - an 8-byte unit holds 4 consecutive features of one point).
+// [k(2)][h(2)][point(32)][16 B], the 16-byte unit (k, h, point) = two 8-byte granules of 4 consecutive features of that
+// point: feature quads fq = 4k + h and fq = 4k + h + 2, feature = 32*tile + 4*fq + e).
 //
 // The op is HBM-bound: 2*256*256 flop per 1 KiB of operand rows = 128 flop/B, i.e. ~0.8 PFLOP/s at the achievable
 // 6.3 TB/s - a third of the MFMA peak. So the kernel is built around reading every operand byte exactly once and doing
@@ -12,10 +13,10 @@
 //    points x up to 16 feature tiles (32 KiB), NBUF stages form a ring with ONE barrier per stage;
 //  * the contraction index (points) is the slow index of both operands while an MFMA lane wants 8 k-values of one
 //    feature: ds_read_b64_tr_b16 does that transpose inside the LDS read. A DMA lane writes LDS at base + 16*lane but
-//    chooses its own global address, so the LDS image of a tile is re-ordered to [point pair(16)][fq(8)][2 points x 4
-//    features]: the 4 points x 32 features a half-wave's transposing read touches are then 256 contiguous bytes
-//    (conflict-free), and a lane's 16-byte global piece (one fq, two consecutive points) is still contiguous in PT32.
-//    The k order inside a fragment is the same for A and B, so the contraction is unchanged;
+//    chooses its own global address, so the LDS image of a tile is re-ordered to [point quad(8)][k(2)][h(2)][point in quad(4)]
+//    [16 B]: the 4 points x 32 features a half-wave's transposing read touches are then 256 contiguous bytes
+//    (conflict-free), while a lane's 16-byte global piece is one unit of the plane layout (4 lanes = 4 consecutive
+//    points = 64 contiguous bytes). The k order inside a fragment is the same for A and B, so the contraction is unchanged;
 //  * bias gradients (column sums of A) come from the matrix core too: one extra MFMA per m-tile against a fragment of
 //    ones instead of unpacking bf16 pairs on the VALU.
 // K splits are reduced by vdn_dw_finalize (train_dw_f32.hip), deterministically.
@@ -109,7 +110,8 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_bf16_kernel(const DwDesc* desc
     // ---- DMA: piece u = (tile u>>1, half u&1) of the stage, 1 KiB each; wave w moves pieces w, w+8, w+16, w+24
     const int n_pieces = 2 * (nA + nB);
     const int npw = (n_pieces - wave + kDwWaves - 1) / kDwWaves;             // pieces of this wave per stage (wave-uniform)
-    const unsigned lane_off = (lane & 7) * 256 + (lane >> 3) * 16;           // fq = lane&7, point pair = lane>>3
+    // lane -> unit of the plane tile: point quad (lane >> 4) of this half tile, k = bit 3, h = bit 2, point in quad = bits 1:0
+    const unsigned lane_off = ((lane >> 3) & 1) * 1024 + ((lane >> 2) & 1) * 512 + ((lane >> 4) * 4 + (lane & 3)) * 16;
     const unsigned lds0 = (unsigned)(size_t)(lds_char*)smem;
     auto issue_stage = [&](int s) VDN_INL {
         const long blk32 = (k_begin >> 5) + s;
@@ -123,14 +125,16 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_bf16_kernel(const DwDesc* desc
                 const char* src = isA ? A + blk32 * (64 * lda) + (long)(a_t0 + t) * 2048
                                       : Bm + blk32 * (64 * ldb) + (long)(b_t0 + t - nA) * 2048;
                 const int slot = isA ? t : 8 + (t - nA);
-                dw_glds16(src + half * 128, lane_off, buf + slot * kDwTileBytes + half * 1024);
+                dw_glds16(src + half * 256, lane_off, buf + slot * kDwTileBytes + half * 1024);      // half = points 16 half ..
             }
         }
     };
 
     // ---- fragment addressing: group g = lane>>4 (j = g&1: feature half, h = g>>1: k half), i = lane&15 = 4q'+p
     const int gi = lane & 15, qp = gi >> 2, pp = gi & 3, jj = (lane >> 4) & 1;
-    const unsigned frag_off = (4 * jj + pp) * 16 + (qp & 1) * 8 + (4 * h + (qp >> 1)) * 128;
+    // granule (point 8h + qp, feature quad fq = 4jj + pp) of a 16-point k-step: point quad 2h (the second read: 2h + 1), unit
+    // (k = jj, h' = pp & 1, point in quad = qp), half of the unit pp >> 1
+    const unsigned frag_off = (2 * h) * 256 + (jj * 8 + (pp & 1) * 4 + qp) * 16 + (pp >> 1) * 8;
     const lds_char* lbase = (lds_char*)smem + frag_off;
 
     f32x16 acc[2][4];
@@ -163,8 +167,8 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_bf16_kernel(const DwDesc* desc
                 // the last block is partial: rows from k_end on hold whatever the producers' padding left there
                 const int valid = k_end & 31;
                 char* buf = smem + (s % kDwBuf) * kDwStageBytes;
-                for (int u = threadIdx.x; u < 16 * 256; u += 512) {          // 8-byte units: [tile][pair][fq][pt&1]
-                    const int pt = ((u >> 4) & 15) * 2 + (u & 1);
+                for (int u = threadIdx.x; u < 16 * 256; u += 512) {          // 8-byte granules: [tile][point quad(8)][unit(16)][2]
+                    const int pt = ((u >> 5) & 7) * 4 + ((u >> 1) & 3);
                     if (pt >= valid) *reinterpret_cast<unsigned long long*>(buf + u * 8) = 0ull;
                 }
                 __syncthreads();

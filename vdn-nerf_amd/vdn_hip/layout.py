@@ -1,7 +1,9 @@
 """Activation-plane layouts (see csrc/mlp_engine.h).
 
-fp32 path: row-major [P, ld].  bf16 path: tile-blocked "PT32": points padded to a multiple of 32;
-element (p, f) at (p>>5)*(32*ld) + (f>>5)*1024 + ((f&31)>>3)*256 + ((f&7)>>2)*128 + (p&31)*4 + (f&3).
+fp32 path: row-major [P, ld].  bf16 path: tile-blocked "PT32": points padded to a multiple of 32; per block and 32-feature
+tile [k(2)][h(2)][point(32)][8 features], the 16-byte unit (k, h, point) holding features 16k + 4h + {0..3} and
+16k + 8 + 4h + {0..3}: element (p, f) at
+(p>>5)*(32*ld) + (f>>5)*1024 + ((f>>4)&1)*512 + ((f>>2)&1)*256 + (p&31)*8 + ((f>>3)&1)*4 + (f&3).
 These converters serve the stand-alone module API (SDFNetwork.forward / RenderingNetwork.forward), where
 the caller hands over / expects row-major tensors; the render path never converts."""
 import torch
@@ -21,14 +23,15 @@ def to_pt32(x):
     Pp = pad32(P)
     buf = torch.zeros(Pp, ld, dtype=torch.bfloat16, device=x.device)
     buf[:P] = x.to(torch.bfloat16)
-    # [blk, c, nt, q, hh, e] -> [blk, nt, q, hh, c, e]
-    return buf.view(Pp // 32, 32, ld // 32, 4, 2, 4).permute(0, 2, 3, 4, 1, 5).contiguous().view(-1)
+    # feature within a tile = 16 k + 8 j + 4 hh + e:  [blk, c, nt, k, j, hh, e] -> [blk, nt, k, hh, c, j, e]
+    return buf.view(Pp // 32, 32, ld // 32, 2, 2, 2, 4).permute(0, 2, 3, 5, 1, 4, 6).contiguous().view(-1)
 
 
 def from_pt32(buf, P, ld):
     """bf16 PT32 buffer -> [P, ld] float32."""
     Pp = pad32(P)
-    x = buf.view(-1)[:Pp * ld].view(Pp // 32, ld // 32, 4, 2, 32, 4).permute(0, 4, 1, 2, 3, 5).contiguous().view(Pp, ld)
+    # [blk, nt, k, hh, c, j, e] -> [blk, c, nt, k, j, hh, e]
+    x = buf.view(-1)[:Pp * ld].view(Pp // 32, ld // 32, 2, 2, 32, 2, 4).permute(0, 4, 1, 2, 5, 3, 6).contiguous().view(Pp, ld)
     return x[:P].float()
 
 

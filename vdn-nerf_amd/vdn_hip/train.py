@@ -18,6 +18,18 @@ from . import images, layout, lib
 PTS_PER_SPLIT = int(os.environ.get("VDN_DW_SPLIT_PTS", "4096"))        # rows one workgroup of the weight-gradient GEMM contracts
 
 
+def _pts_per_split(net):
+    """Rows per K split of the weight-gradient GEMM, per launch group (SDF network / the rest): read when an engine is built.
+    Measured at the bench's steady-state lists (tools/dev/dw_split_sweep.py, all settings interleaved in one process): the SDF
+    group at 6144 rows per split is 231 workgroups - ONE round of the 256 CUs (this kernel runs one 128-KiB-LDS workgroup per
+    CU) - and the step is 3.1 % shorter than at 4096 (336 workgroups = 1.3 rounds); 8192 (168 workgroups) gives part of that
+    back, 3072 (462) is in between. The rest group is best at 4096 (376 workgroups; 6144: +1.4 %, 3072 = 510 workgroups,
+    two full rounds: +17 %)."""
+    if net == "sdf":
+        return int(os.environ.get("VDN_DW_SPLIT_PTS_SDF", os.environ.get("VDN_DW_SPLIT_PTS", "6144")))
+    return int(os.environ.get("VDN_DW_SPLIT_PTS_REST", str(PTS_PER_SPLIT)))
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -244,7 +256,8 @@ class TrainEngine:
             # bandwidth-bound - and 2048 / 8192 rows per split are 10 % slower (more slab traffic / a coarser tail).
             segs = 2 if e.get("A2") is not None else 1
             K = e["Pn"] * segs
-            splits = max(1, (K + PTS_PER_SPLIT - 1) // PTS_PER_SPLIT)
+            pps = _pts_per_split(e["net"])
+            splits = max(1, (K + pps - 1) // pps)
             if segs == 2:
                 splits += splits % 2          # first half of the splits = segment 1, second half = segment 2
             lay.append((mt, nt, splits, slab_elems, cs_elems, moff, wg))
