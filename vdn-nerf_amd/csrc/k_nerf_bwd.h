@@ -97,9 +97,9 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void nerf_bwd_ke
         X.set(8, t16);
         P::store_tile(delta_head, p, 288, 8, h, t16, ok);
     }
-    dense<P, 9, 8, false>(ws, X, 0, ldH(7), mask_store(Y, delta_h + 7 * PS, 256), P::kTileOps, P::kTileOps);     // Whead^T
-    dense<P, 8, 8, false>(ws, Y, 0, ldH(6), mask_store(X, delta_h + 6 * PS, 256), P::kTileOps, P::kTileOps);     // W7^T
-    dense<P, 8, 8, false>(ws, X, 0, ldH(5), mask_store(Y, delta_h + 5 * PS, 256), P::kTileOps, P::kTileOps);     // W6^T
+    dense<P, 9, 8, false, kBwdPrefetch>(ws, X, 0, ldH(7), mask_store(Y, delta_h + 7 * PS, 256), P::kTileOps, P::kTileOps);     // Whead^T
+    dense<P, 8, 8, false, kBwdPrefetch>(ws, Y, 0, ldH(6), mask_store(X, delta_h + 6 * PS, 256), P::kTileOps, P::kTileOps);     // W7^T
+    dense<P, 8, 8, false, kBwdPrefetch>(ws, X, 0, ldH(5), mask_store(Y, delta_h + 5 * PS, 256), P::kTileOps, P::kTileOps);     // W6^T
     // W5^T: 11 output tiles = [PE (3, dropped) | h4 (8)]
     dense<P, 8, 11, false>(ws, Y, 0,
         [&](int nt) VDN_INL { return nt >= 3 ? P::load_tile(save_h + 4 * PS, p, 256, nt - 3, h) : f32x16{}; },
@@ -116,10 +116,10 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void nerf_bwd_ke
                 else pe_adjoint_tile<4, 10, 2, P::kAccurateTrig>(acc, h, x4, dx4);
             }
         });
-    dense<P, 8, 8, false>(ws, X, 0, ldH(3), mask_store(Y, delta_h + 3 * PS, 256), P::kTileOps, P::kTileOps);     // W4^T
-    dense<P, 8, 8, false>(ws, Y, 0, ldH(2), mask_store(X, delta_h + 2 * PS, 256), P::kTileOps, P::kTileOps);     // W3^T
-    dense<P, 8, 8, false>(ws, X, 0, ldH(1), mask_store(Y, delta_h + 1 * PS, 256), P::kTileOps, P::kTileOps);     // W2^T
-    dense<P, 8, 8, false>(ws, Y, 0, ldH(0), mask_store(X, delta_h + 0 * PS, 256), P::kTileOps, P::kTileOps);      // W1^T
+    dense<P, 8, 8, false, kBwdPrefetch>(ws, X, 0, ldH(3), mask_store(Y, delta_h + 3 * PS, 256), P::kTileOps, P::kTileOps);     // W4^T
+    dense<P, 8, 8, false, kBwdPrefetch>(ws, Y, 0, ldH(2), mask_store(X, delta_h + 2 * PS, 256), P::kTileOps, P::kTileOps);     // W3^T
+    dense<P, 8, 8, false, kBwdPrefetch>(ws, X, 0, ldH(1), mask_store(Y, delta_h + 1 * PS, 256), P::kTileOps, P::kTileOps);     // W2^T
+    dense<P, 8, 8, false, kBwdPrefetch>(ws, Y, 0, ldH(0), mask_store(X, delta_h + 0 * PS, 256), P::kTileOps, P::kTileOps);      // W1^T
     if (want_pts) {
         dense<P, 8, 3, false>(ws, X, 0, NoPre{}, [&](int nt, const f32x16& acc, int) VDN_INL {       // W0^T
             if (nt == 0) pe_adjoint_tile<4, 10, 0, P::kAccurateTrig>(acc, h, x4, dx4);

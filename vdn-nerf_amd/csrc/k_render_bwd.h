@@ -65,10 +65,10 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_b
     };
     ws.all_issue = __any(ok);
     ws.start();
-    dense<P, NT_OUT, 8, false>(ws, X, 0, ldH(3), mask_store(Y, 3), P::kTileOps, P::kTileOps);   // W4^T
-    dense<P, 8, 8, false>(ws, Y, 0, ldH(2), mask_store(X, 2), P::kTileOps, P::kTileOps);        // W3^T
-    dense<P, 8, 8, false>(ws, X, 0, ldH(1), mask_store(Y, 1), P::kTileOps, P::kTileOps);        // W2^T
-    dense<P, 8, 8, false>(ws, Y, 0, ldH(0), mask_store(X, 0), P::kTileOps, P::kTileOps);        // W1^T
+    dense<P, NT_OUT, 8, false, kBwdPrefetch>(ws, X, 0, ldH(3), mask_store(Y, 3), P::kTileOps, P::kTileOps);   // W4^T
+    dense<P, 8, 8, false, kBwdPrefetch>(ws, Y, 0, ldH(2), mask_store(X, 2), P::kTileOps, P::kTileOps);        // W3^T
+    dense<P, 8, 8, false, kBwdPrefetch>(ws, X, 0, ldH(1), mask_store(Y, 1), P::kTileOps, P::kTileOps);        // W2^T
+    dense<P, 8, 8, false, kBwdPrefetch>(ws, Y, 0, ldH(0), mask_store(X, 0), P::kTileOps, P::kTileOps);        // W1^T
     f32x16 SM[2];
     dense<P, 8, 10 + EX, false>(ws, X, 0, NoPre{}, [&](int nt, const f32x16& acc, int) VDN_INL {   // W0^T
         if (nt >= 10) {

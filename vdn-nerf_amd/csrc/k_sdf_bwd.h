@@ -88,12 +88,12 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_rbar_ke
         X.set(kt, t16);
         P::store_tile(ub0, p, 64, kt, h, t16, ok);
     }
-    struct SV { f32x16 s, v; };
+    struct SV { typename P::raw_tile s, v; };
     auto ldSV = [&](int l) VDN_INL {
         return [=](int nt) VDN_INL {
             SV r;
-            r.s = P::load_tile(S + l * PS, p, 256, nt, h);
-            r.v = P::load_tile(V + l * PS, p, 256, nt, h);
+            r.s = P::load_raw(S + l * PS, p, 256, nt, h);
+            r.v = P::load_raw(V + l * PS, p, 256, nt, h);
             return r;
         };
     };
@@ -101,11 +101,12 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_rbar_ke
     auto epi = [&](auto& D, ST* dst, int ld, int l) VDN_INL {
         return [&D, dst, ld, l, EX, PS, p, ok, h, from_h, ex_k](int nt, const f32x16& acc, const SV& sv) VDN_INL {
             f32x16 ub, ex;
+            const f32x16 sr = P::unpack(sv.s), vr = P::unpack(sv.v);
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-                const float s = sprime(sv.s[t], from_h);
+                const float s = sprime(sr[t], from_h);
                 ub[t] = acc[t] * s;
-                ex[t] = ex_k * acc[t] * sv.v[t] * (1.0f - s);
+                ex[t] = ex_k * acc[t] * vr[t] * (1.0f - s);
             }
             D.set(nt, ub);
             P::store_tile(dst, p, ld, nt, h, ub, ok);
@@ -196,12 +197,12 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_fbar_ke
         X.set(kt, t16);
         P::store_tile(ab8, p, 288, kt, h, t16, ok);
     }
-    struct SE { f32x16 s, e; };
+    struct SE { typename P::raw_tile s, e; };
     auto ldSE = [&](int l) VDN_INL {
         return [=](int nt) VDN_INL {
             SE r;
-            r.s = P::load_tile(S + l * PS, p, 256, nt, h);
-            r.e = P::load_tile(EX + l * PS, p, 256, nt, h);
+            r.s = P::load_raw(S + l * PS, p, 256, nt, h);
+            r.e = P::load_raw(EX + l * PS, p, 256, nt, h);
             return r;
         };
     };
@@ -209,8 +210,9 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_fbar_ke
         ST* dst = ab(l);
         return [&D, dst, p, ok, h, from_h](int nt, const f32x16& acc, const SE& se) VDN_INL {
             f32x16 o;
+            const f32x16 sr = P::unpack(se.s), er = P::unpack(se.e);
 #pragma unroll
-            for (int t = 0; t < 16; ++t) o[t] = acc[t] * sprime(se.s[t], from_h) + se.e[t];
+            for (int t = 0; t < 16; ++t) o[t] = acc[t] * sprime(sr[t], from_h) + er[t];
             D.set(nt, o);
             P::store_tile(dst, p, 256, nt, h, o, ok);
         };
@@ -226,21 +228,19 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_fbar_ke
         f32x16 PE4[2];
         dense<P, 8, 9, false, PF>(ws, X, 0,
             [&](int nt) VDN_INL {
-                SE r;
+                SE r{};
                 if (nt < 7) {
-                    r.s = P::load_tile(S + 3 * PS, p, 256, nt, h);
-                    r.e = P::load_tile(EX + 3 * PS, p, 256, nt, h);
-                } else {
-                    r.s = f32x16{};
-                    r.e = f32x16{};
+                    r.s = P::load_raw(S + 3 * PS, p, 256, nt, h);
+                    r.e = P::load_raw(EX + 3 * PS, p, 256, nt, h);
                 }
                 return r;
             },
             [&](int nt, const f32x16& acc, const SE& se) VDN_INL {
                 if (nt < 7) {
                     f32x16 o;
+                    const f32x16 sr = P::unpack(se.s), er = P::unpack(se.e);
 #pragma unroll
-                    for (int t = 0; t < 16; ++t) o[t] = acc[t] * sprime(se.s[t], from_h) + se.e[t];
+                    for (int t = 0; t < 16; ++t) o[t] = acc[t] * sprime(sr[t], from_h) + er[t];
                     Y.set(nt, o);
                     P::store_tile(dst, p, 256, nt, h, o, ok);
                 } else {

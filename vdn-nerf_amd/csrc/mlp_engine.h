@@ -207,6 +207,10 @@ struct F32 {
             *reinterpret_cast<f32x4*>(p + 8 * q) = o;
         }
     }
+    // a tile as loaded, before conversion (what the chains keep in flight across chunk steps): f32 planes need none
+    using raw_tile = f32x16;
+    static VDN_DEV raw_tile load_raw(const float* base, long row, int ld, int tile, int h) { return load_tile(base, row, ld, tile, h); }
+    static VDN_DEV f32x16 unpack(const raw_tile& r) { return r; }
     static VDN_DEV f32x16 load_tile(const float* base, long row, int ld, int tile, int h) {
         const float* p = base + row * ld + tile * 32 + 4 * h;
         f32x16 r;
@@ -372,16 +376,27 @@ struct BF16 {
             *reinterpret_cast<uint4*>(p + 512 * k) = o;
         }
     }
-    static VDN_DEV f32x16 load_tile(const unsigned short* base, long row, int ld, int tile, int h) {
+    // a tile as loaded: 8 registers of packed bf16 (the chains keep these, not the 16 converted values, in flight across steps)
+    struct raw_tile { uint4 k[2]; };
+    static VDN_DEV raw_tile load_raw(const unsigned short* base, long row, int ld, int tile, int h) {
         const unsigned short* p = base + (row >> 5) * (32L * ld) + tile * 1024 + h * 256 + (row & 31) * 8;
+        raw_tile r;
+        r.k[0] = *reinterpret_cast<const uint4*>(p);
+        r.k[1] = *reinterpret_cast<const uint4*>(p + 512);
+        return r;
+    }
+    static VDN_DEV f32x16 unpack(const raw_tile& t) {
         f32x16 r;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const uint4 o = *reinterpret_cast<const uint4*>(p + 512 * k);
+            const uint4 o = t.k[k];
             r[8 * k] = bf16_lo(o.x); r[8 * k + 1] = bf16_hi(o.x); r[8 * k + 2] = bf16_lo(o.y); r[8 * k + 3] = bf16_hi(o.y);
             r[8 * k + 4] = bf16_lo(o.z); r[8 * k + 5] = bf16_hi(o.z); r[8 * k + 6] = bf16_lo(o.w); r[8 * k + 7] = bf16_hi(o.w);
         }
         return r;
+    }
+    static VDN_DEV f32x16 load_tile(const unsigned short* base, long row, int ld, int tile, int h) {
+        return unpack(load_raw(base, row, ld, tile, h));
     }
 };
 
@@ -485,6 +500,12 @@ VDN_DEV void dense(WS& ws, const ActT& X, int x0, Pre&& pre, Epi&& epi, int epi_
         __builtin_amdgcn_sched_barrier(0);
     });
 }
+
+// plane-load prefetch distance of the colour / background backward chains (the SDF chains choose at launch: k_sdf_bwd.h)
+#ifndef VDN_BWD_PF
+#define VDN_BWD_PF 2
+#endif
+constexpr int kBwdPrefetch = VDN_BWD_PF;
 
 // per-point vector -> one activation tile (f32x16), zero beyond NF
 template <int NF>
