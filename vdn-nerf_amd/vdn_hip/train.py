@@ -190,13 +190,14 @@ class TrainEngine:
                 ent.append(dict(net="sdf", name=name, rmap=nm, cmap=km, scale=sc, A=AB(8), B=sl(w["H"], 7), bias=True, Pn=P))
                 continue
             A, A2 = AB(l), sl(w["V"], l)
+            # pipe = l: the layer-pipelined backward (csrc/train_sdf_pipe_bf16.hip) accumulates this entry itself
             if l == 0:
-                ent.append(dict(net="sdf", name=name, rmap=nm, cmap=km, scale=sc, A=A, B=whole(w["PE"]), A2=A2, B2=UB(0), bias=True, Pn=P))
+                ent.append(dict(net="sdf", name=name, rmap=nm, cmap=km, scale=sc, A=A, B=whole(w["PE"]), A2=A2, B2=UB(0), bias=True, Pn=P, pipe=l))
             elif l == 4:
-                ent.append(dict(net="sdf", name=name, rmap=nm, cmap=km[:224], scale=sc, A=A, B=sl(w["H"], 3), A2=A2, B2=UB(4), bias=True, Pn=P))
+                ent.append(dict(net="sdf", name=name, rmap=nm, cmap=km[:224], scale=sc, A=A, B=sl(w["H"], 3), A2=A2, B2=UB(4), bias=True, Pn=P, pipe=l))
                 ent.append(dict(net="sdf", name=name, rmap=nm, cmap=km[224:], scale=sc, A=A, B=whole(w["PE"]), A2=A2, B2=UB(4, 224), bias=False, Pn=P))
             else:
-                ent.append(dict(net="sdf", name=name, rmap=nm, cmap=km, scale=sc, A=A, B=sl(w["H"], l - 1), A2=A2, B2=UB(l), bias=True, Pn=P))
+                ent.append(dict(net="sdf", name=name, rmap=nm, cmap=km, scale=sc, A=A, B=sl(w["H"], l - 1), A2=A2, B2=UB(l), bias=True, Pn=P, pipe=l))
         # d W8[row 0, :] += colsum(ub_8) / scale   (u_8 = W8[0,:] / scale)
         ent.append(dict(net="sdf", name="lin8", rmap=images.ident_map(256), cmap=None, scale=1.0, A=UB(8), B=None, bias=False, Pn=P,
                         extra_row0=True))
@@ -337,6 +338,9 @@ class TrainEngine:
         mm = {"sdf": ent[:n_sdf], "rest": ent[n_sdf:]}
         self.fin_groups = {k: (torch.from_numpy(v.view(np.uint8).copy()).to(dev), len(v), int(max(len(e["rmap"]) for e in mm[k])),
                                bool((v["accumulate"] != 0).any())) for k, v in fg.items() if len(v) and len(mm[k])}
+        self.pipe = None
+        if prec == "bf16" and os.environ.get("VDN_SDF_PIPE", "1") != "0":
+            self._build_sdf_pipe(ent[:n_sdf], dw[:n_sdf], fin[:n_sdf], vfin, ub_off)
         # weight-norm backward table
         rows, row_group = [], []
         for key, net in self.nets.items():          # "sdf" first (dict order of self.nets)
@@ -356,6 +360,8 @@ class TrainEngine:
             idx = [i for i, gk in enumerate(row_group) if gk == k]
             if idx:
                 self.wn_groups[k] = (torch.from_numpy(wn[idx].view(np.uint8).copy()).to(dev), len(idx), max(rows[i][1].shape[0] for i in idx))
+        if "sdf" in self.wn_groups:
+            self.wn_groups["sdf_pipe"] = self.wn_groups["sdf"]
         self._param_ptrs = self._ptr_key()
 
     @property
@@ -364,6 +370,98 @@ class TrainEngine:
         if getattr(self, "join_hook", None) is not None:     # the Trainer's deferred half of the backward (side stream)
             self.join_hook()
         return self._grad_flat
+
+    def _build_sdf_pipe(self, ent, dw, fin, vfin, ub_off):
+        """Tables of the layer-pipelined SDF backward (csrc/train_sdf_pipe_bf16.hip; include/vdn_render.h: VdnSdfPipeStage):
+        17 stages x `lanes` workgroups; the hidden layers' weight gradients leave the launch as 2 * lanes K splits per entry
+        (rbar part, fbar part) for vdn_dw_finalize. What stays with vdn_dw_gemm: layer 4's encoding columns, layer 8, and the
+        column sums behind the sdf row (launch group "sdf_pipe")."""
+        w, dev, P, Pp = self.w, self.dev, self.P, self.Pp
+        NL = int(os.environ.get("VDN_SDF_PIPE_LANES", "15"))
+        img = self.nets["sdf"].img
+        PS = Pp * 256
+        plane = lambda t, off_elems=0: t.data_ptr() + 2 * off_elems
+        ub = lambda l: plane(w["UB"], ub_off[l][0])
+        ab = lambda l: plane(w["AB"], 0) if l == 8 else plane(w["AB"], Pp * 288 + (7 - l) * PS)
+        H = lambda l: plane(w["H"], l * PS)
+        V = lambda l: plane(w["V"], l * PS)
+        EX = lambda l: plane(w["EX"], l * PS)
+        full, fbar = img.blobs["full"].data_ptr(), img.blobs["fbar"].data_ptr()
+        chunk_r = [0, 8, 16, 24, 31, 39, 47, 55]                     # first chunk of hidden layer l in the forward stream
+        chunk_f = {8: 0, 7: 8, 6: 16, 5: 24, 4: 32, 3: 41, 2: 49, 1: 57}   # first chunk of W_l^T in the 'fbar' stream
+        # slabs / column sums of the pipelined entries
+        pe = {e["pipe"]: i for i, e in enumerate(ent) if "pipe" in e}
+        dims = {l: (len(ent[i]["rmap"]), len(ent[i]["cmap"])) for l, i in pe.items()}
+        slab_off, cs_off, so, co = {}, {}, 0, 0
+        for l in range(8):
+            M, N = dims[l]
+            slab_off[l], cs_off[l] = so, co
+            so += 2 * NL * M * N
+            co += 2 * NL * M
+        self.pipe_slab = torch.empty(so, dtype=torch.float32, device=dev)
+        self.pipe_colsum = torch.zeros(co, dtype=torch.float32, device=dev)      # the rbar splits' rows stay zero
+        st = np.zeros(17, dtype=lib.struct_dtype("VdnSdfPipeStage"))
+        for l in range(8):                                # rbar stages
+            d = st[l]
+            M, N = dims[l]
+            d["kind"], d["nt"], d["chunk0"], d["blob"] = 0, M // 32, chunk_r[l], full
+            d["kt_lds"], d["kt_reg"], d["reg_kind"] = (0, 2, 1) if l == 0 else ((7, 2, 1) if l == 4 else (8, 0, 0))
+            d["dw_reg"] = 1 if l == 0 else 0
+            d["in_stage"], d["ex_stage"], d["has_dw"], d["split"] = l - 1, -1, 1, 0
+            d["x_in"], d["in_ld"] = ub(l), ub_off[l][1]
+            d["x_out"], d["out_ld"], d["out_tile0"] = ub(l + 1), ub_off[l + 1][1], 0
+            d["reg_tile0"], d["reg_ld"] = -1, 0
+            if l == 4:                                    # ub_4's encoding part still feeds vdn_dw_gemm (entry cmap[224:])
+                d["reg_out"], d["reg_tile0"], d["reg_ld"] = ub(4), 7, 288
+            d["S"], d["aux"], d["ex_out"], d["own"], d["own_ld"] = H(l), V(l), EX(l), V(l), 256
+            d["slab"], d["slab_m"], d["slab_n"] = self.pipe_slab.data_ptr() + 4 * slab_off[l], M, N
+        for f in range(8):                                # fbar stages W8^T .. W1^T
+            lw = 8 - f
+            d = st[8 + f]
+            d["kind"], d["chunk0"], d["blob"] = 1, chunk_f[lw], fbar
+            d["kt_lds"] = 7 if lw == 3 else 8
+            d["nt"] = 7 if lw == 4 else 8
+            d["kt_reg"], d["reg_kind"] = (1, 2) if lw == 8 else (0, 0)
+            d["in_stage"], d["ex_stage"] = (-1, 7) if lw == 8 else (8 + f - 1, -1)
+            d["x_in"], d["in_ld"] = (w["d_featvec"].data_ptr(), 256) if lw == 8 else (ab(lw), 256)
+            d["x_out"], d["out_ld"], d["out_tile0"] = ab(lw - 1), 256, 0
+            d["reg_tile0"], d["reg_ld"] = -1, 0
+            if lw == 8:                                   # AB(8) = [g_feat | g_sdf / scale]: layer 8 stays with vdn_dw_gemm
+                d["reg_out"], d["reg_tile0"], d["reg_ld"], d["copy_in"] = ab(8), 8, 288, 1
+            d["S"], d["aux"], d["own"], d["own_ld"] = H(lw - 1), EX(lw - 1), H(lw - 1), 256
+            if lw <= 7:
+                M, N = dims[lw]
+                d["has_dw"], d["split"] = 1, NL
+                d["slab"], d["slab_m"], d["slab_n"] = self.pipe_slab.data_ptr() + 4 * slab_off[lw], M, N
+                d["colsum"] = self.pipe_colsum.data_ptr() + 4 * cs_off[lw]
+                assert M == 32 * d["kt_lds"] and N == 32 * d["nt"]
+        d = st[16]                                        # layer 0: d W0 += ab_0 PE^T, d b0 += ab_0
+        M, N = dims[0]
+        d["kind"], d["kt_lds"], d["nt"], d["in_stage"], d["ex_stage"], d["has_dw"], d["split"] = 2, 8, 2, 15, -1, 1, NL
+        d["x_in"], d["in_ld"], d["own"], d["own_ld"] = ab(0), 256, w["PE"].data_ptr(), 64
+        d["reg_tile0"] = -1
+        d["slab"], d["slab_m"], d["slab_n"] = self.pipe_slab.data_ptr() + 4 * slab_off[0], M, N
+        d["colsum"] = self.pipe_colsum.data_ptr() + 4 * cs_off[0]
+        assert (M, N) == (256, 64)
+        stages = torch.from_numpy(st.view(np.uint8).copy()).to(dev)
+        sync = torch.zeros(2 + 17 * NL, dtype=torch.int32, device=dev)
+        # residual GEMM entries (renumbered workgroups) and the group's finalize table
+        res = [i for i, e in enumerate(ent) if "pipe" not in e]
+        dres = dw[res].copy()
+        wg = 0
+        for k, i in enumerate(res):
+            dres[k]["wg_begin"] = wg
+            wg += lib.call_value("vdn_dw_entry_wgs" + self.sfx, int(dw[i]["m_tiles"]), int(dw[i]["n_tiles"]), int(dw[i]["splits"]))
+        self.dw_groups["sdf_pipe"] = (torch.from_numpy(dres.view(np.uint8).copy()).to(dev), len(res), wg)
+        fp = fin.copy()
+        for l, i in pe.items():
+            fp[i]["slab"] = self.pipe_slab.data_ptr() + 4 * slab_off[l]
+            fp[i]["colsum"] = self.pipe_colsum.data_ptr() + 4 * cs_off[l] if fp[i]["colsum"] else 0
+            fp[i]["splits"] = 2 * NL
+        fp = np.concatenate([fp, vfin])
+        self.fin_groups["sdf_pipe"] = (torch.from_numpy(fp.view(np.uint8).copy()).to(dev), len(fp), int(max(len(e["rmap"]) for e in ent)),
+                                       bool((fp["accumulate"] != 0).any()))
+        self.pipe = dict(stages=stages, sync=sync, lanes=NL, n_stages=17)
 
     def _ptr_key(self):
         return tuple(p.data_ptr() for net in self.nets.values() for p in net.module.parameters())
@@ -710,6 +808,22 @@ class TrainEngine:
         if defer_rest and self._side is not None:
             self._ev_heads.record(torch.cuda.current_stream())      # the heads' deltas (operands of the rest group) are complete
 
+        use_pipe = self.pipe is not None and not rg and os.environ.get("VDN_SDF_PIPE", "1") != "0"
+        if use_pipe:
+            # rbar chain, fbar chain and the hidden layers' weight gradients in one layer-pipelined launch
+            pa = lib.VdnSdfPipeArgs()
+            pa.stages, pa.n_stages, pa.lanes, pa.sync = self.pipe["stages"].data_ptr(), self.pipe["n_stages"], self.pipe["lanes"], self.pipe["sync"].data_ptr()
+            pa.rays_o, pa.rays_d, pa.z, pa.n_per_ray, pa.z_ld = rays_o.data_ptr(), rays_d.data_ptr(), w["mid_z"].data_ptr(), self.N, self.N
+            pa.P, pa.scale = self.P, float(r.sdf_network.scale)
+            pa.g_normals, pa.g_sdf = w["d_normals"].data_ptr(), w["d_sdf"].data_ptr()
+            lib.call("vdn_sdf_bwd_pipe_bf16", self._fg(pa), st)
+            if defer_rest:
+                self.weight_grads("sdf_pipe", st, gemm_event)
+                return self._grad_flat
+            self._join()
+            self.weight_grads("sdf_pipe", st)
+            self.weight_grads("rest", st)
+            return self._grad_flat
         rb = lib.VdnSdfRbarArgs()
         img = self.nets["sdf"].img
         rb.blob = img.blobs["full"].data_ptr()
