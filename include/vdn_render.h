@@ -413,26 +413,27 @@ int vdn_sdf_bwd_fbar_bf16(const VdnSdfFbarArgs* args_host, void* stream);   /* b
  * and once more by vdn_dw_gemm. Stage table entries (built by the host, in device memory): */
 typedef struct {
     int32_t kind;              /* 0: rbar stage (forward image), 1: fbar stage (transposed image), 2: no chain (layer 0: gradient only) */
-    int32_t kt_lds;            /* input tiles read from x_in (staged through LDS; their weights stay in LDS) */
-    int32_t kt_reg;            /* further input tiles built in registers (weights in registers): see reg_kind */
+    int32_t kt_lds;            /* input tiles of the chain, staged through LDS per block: the first kt_lds - kt_extra from x_in, the rest from reg_out */
+    int32_t kt_reg;            /* 0 or 2: the weights of the last kt_reg k-tiles (always k-tiles 7, 8) stay in registers, the others in LDS */
     int32_t nt;                /* output tiles of the chain = tiles of the `own` operand = waves with work (<= 8) */
     int32_t chunk0;            /* first chunk of the layer in `blob` (chunk = one output tile, mlp_engine.h format, 20-KiB stride) */
-    int32_t reg_kind;          /* 0: none; 1: scale * J_PE g_normals (39 values: rbar layers 0 and 4); 2: g_sdf / scale (fbar W8^T) */
+    int32_t kt_extra;          /* input tiles taken from the plane reg_out (tiles reg_tile0 ..) instead of x_in: fbar W8^T's sdf adjoint */
     int32_t in_stage;          /* stage whose x_out is this stage's x_in (-1: x_in is an input of the launch) */
     int32_t ex_stage;          /* stage that must have finished a block before this one reads its EX rows (-1: none) */
     int32_t has_dw;            /* this stage accumulates a weight gradient */
-    int32_t dw_reg;            /* the register-built tiles take part in it (rbar layer 0) */
+    int32_t n_dw;              /* input tiles 0 .. n_dw-1 take part in the weight gradient */
     int32_t split;             /* first K split of this stage's slabs: lane l writes split + l */
     int32_t in_ld, out_ld;     /* leading dimensions (elements) of the x_in / x_out planes */
     int32_t out_tile0;         /* x_out tile of output tile 0 */
-    int32_t reg_tile0;         /* x_out-plane tile the register-built tiles are ALSO stored to (-1: not stored): UB(4) tiles 7, 8 and AB(8) tile 8 */
+    int32_t reg_tile0;         /* first of the kt_reg tiles in reg_out: UB(0) tile 0, UB(4) tile 7, AB(8) tile 8 */
     int32_t own_ld;            /* leading dimension of `own` */
     int32_t reg_ld;            /* leading dimension of `reg_out` */
     int32_t copy_in;           /* 1: the input tiles are also copied to reg_out tiles 0 .. kt_lds-1 (fbar W8^T: AB(8) = [g_feat | g_sdf / scale]) */
     const char* blob;          /* weight stream */
     const void* x_in;          /* bf16 plane (PT32), rows = compact work-list rows */
     void* x_out;               /* bf16 plane or NULL */
-    void* reg_out;             /* plane the register-built tiles are stored to (with reg_tile0) or NULL */
+    void* reg_out;             /* plane of the kt_reg extra input tiles (written before the stages run, see ub0 / ub4 / ab8 below); with copy_in
+                                * the x_in tiles are copied into it too */
     const void* S;             /* H plane of the layer whose softplus' multiplies the chain output (units of 1/(100 log2 e)) */
     const void* aux;           /* rbar: V plane of the layer (units of 1/(100 log2 e)); fbar: EX plane that is added */
     void* ex_out;              /* rbar: EX plane written; else NULL */
@@ -456,6 +457,10 @@ typedef struct {
     const float* g_sdf;             /* [P] */
     const int32_t* active_idx;      /* optional work list, as VdnSdfRbarArgs */
     const int32_t* n_active;
+    /* written by the call's first launch from g_normals / g_sdf (the encoding's adjoint, 39 values; g_sdf / scale): */
+    void* ub0;                      /* UB(0) plane [rows, 64] */
+    void* ub4;                      /* UB(4) plane [rows, 288]: tiles 7, 8 */
+    void* ab8;                      /* AB(8) plane [rows, 288]: tile 8 */
 } VdnSdfPipeArgs;
 /* status word (sync[1]) after the launch: 0 = ok, 1 = a wait for another workgroup's counter gave up (results invalid) */
 int vdn_sdf_bwd_pipe_bf16(const VdnSdfPipeArgs* args_host, void* stream);

@@ -500,7 +500,8 @@ def test_pipelined_sdf_backward_equals_the_three_kernel_path(monkeypatch, B, ski
     Pp = e0.Pp
     # planes, valid rows only (block-padded rows hold whatever the producers left there)
     for l in range(8):
-        a, b = (layout.from_pt32(p["EX"].view(8, Pp * 256)[l], Pp, 256)[:n0] for p in (p0, p1))
+        nc = 224 if l == 3 else 256                 # layer 3 has 217 -> 224 outputs: nobody writes its last tile
+        a, b = (layout.from_pt32(p["EX"].view(8, Pp * 256)[l], Pp, 256)[:n0, :nc] for p in (p0, p1))
         assert (a - b).abs().max().item() <= 2e-2 * a.abs().max().item() + 1e-12, ("EX", l)
     off = 0
     for l, cols in enumerate((64, 256, 256, 256, 288, 256, 256, 256, 256)):
@@ -510,7 +511,8 @@ def test_pipelined_sdf_backward_equals_the_three_kernel_path(monkeypatch, B, ski
         off += Pp * cols
     off = 0
     for l, cols in [(8, 288)] + [(k, 256) for k in range(7, -1, -1)]:
-        a, b = (layout.from_pt32(p["AB"][off:off + Pp * cols], Pp, cols)[:n0] for p in (p0, p1))
+        nc = 224 if l == 3 else cols
+        a, b = (layout.from_pt32(p["AB"][off:off + Pp * cols], Pp, cols)[:n0, :nc] for p in (p0, p1))
         assert (a - b).abs().max().item() <= 2e-2 * a.abs().max().item() + 1e-12, ("AB", l)
         off += Pp * cols
     # every parameter gradient

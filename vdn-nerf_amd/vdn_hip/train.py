@@ -338,8 +338,12 @@ class TrainEngine:
         mm = {"sdf": ent[:n_sdf], "rest": ent[n_sdf:]}
         self.fin_groups = {k: (torch.from_numpy(v.view(np.uint8).copy()).to(dev), len(v), int(max(len(e["rmap"]) for e in mm[k])),
                                bool((v["accumulate"] != 0).any())) for k, v in fg.items() if len(v) and len(mm[k])}
+        # The layer-pipelined SDF backward (csrc/train_sdf_pipe_bf16.hip) is built and tested but OFF by default (VDN_SDF_PIPE=1
+        # turns it on): measured on MI355X it moves 18 % fewer bytes yet takes 743 us where rbar + fbar + the SDF group's GEMM
+        # take 524 us (steady-state lists, rocprofv3 trace), and as a persistent launch on every CU it also ends the overlap with
+        # the background network's backward.
         self.pipe = None
-        if prec == "bf16" and os.environ.get("VDN_SDF_PIPE", "1") != "0":
+        if prec == "bf16" and os.environ.get("VDN_SDF_PIPE", "0") != "0":
             self._build_sdf_pipe(ent[:n_sdf], dw[:n_sdf], fin[:n_sdf], vfin, ub_off)
         # weight-norm backward table
         rows, row_group = [], []
@@ -405,23 +409,22 @@ class TrainEngine:
             d = st[l]
             M, N = dims[l]
             d["kind"], d["nt"], d["chunk0"], d["blob"] = 0, M // 32, chunk_r[l], full
-            d["kt_lds"], d["kt_reg"], d["reg_kind"] = (0, 2, 1) if l == 0 else ((7, 2, 1) if l == 4 else (8, 0, 0))
-            d["dw_reg"] = 1 if l == 0 else 0
+            d["kt_lds"], d["kt_reg"] = (2, 0) if l == 0 else ((9, 2) if l == 4 else (8, 0))      # layer 4: [h part (7) | encoding part (2)]
+            d["n_dw"] = N // 32
             d["in_stage"], d["ex_stage"], d["has_dw"], d["split"] = l - 1, -1, 1, 0
             d["x_in"], d["in_ld"] = ub(l), ub_off[l][1]
             d["x_out"], d["out_ld"], d["out_tile0"] = ub(l + 1), ub_off[l + 1][1], 0
-            d["reg_tile0"], d["reg_ld"] = -1, 0
-            if l == 4:                                    # ub_4's encoding part still feeds vdn_dw_gemm (entry cmap[224:])
-                d["reg_out"], d["reg_tile0"], d["reg_ld"] = ub(4), 7, 288
+            d["reg_tile0"], d["reg_ld"] = -1, 0           # (ub_4's encoding tiles 7, 8 - also read by vdn_dw_gemm, entry cmap[224:] -
+            # and ub_0 come from the call's first launch)
             d["S"], d["aux"], d["ex_out"], d["own"], d["own_ld"] = H(l), V(l), EX(l), V(l), 256
             d["slab"], d["slab_m"], d["slab_n"] = self.pipe_slab.data_ptr() + 4 * slab_off[l], M, N
         for f in range(8):                                # fbar stages W8^T .. W1^T
             lw = 8 - f
             d = st[8 + f]
             d["kind"], d["chunk0"], d["blob"] = 1, chunk_f[lw], fbar
-            d["kt_lds"] = 7 if lw == 3 else 8
+            d["kt_lds"] = 7 if lw == 3 else (9 if lw == 8 else 8)       # W8^T: [g_feat (8) | sdf adjoint (1)]
             d["nt"] = 7 if lw == 4 else 8
-            d["kt_reg"], d["reg_kind"] = (1, 2) if lw == 8 else (0, 0)
+            d["kt_reg"], d["kt_extra"] = (2, 1) if lw == 8 else (0, 0)
             d["in_stage"], d["ex_stage"] = (-1, 7) if lw == 8 else (8 + f - 1, -1)
             d["x_in"], d["in_ld"] = (w["d_featvec"].data_ptr(), 256) if lw == 8 else (ab(lw), 256)
             d["x_out"], d["out_ld"], d["out_tile0"] = ab(lw - 1), 256, 0
@@ -434,17 +437,18 @@ class TrainEngine:
                 d["has_dw"], d["split"] = 1, NL
                 d["slab"], d["slab_m"], d["slab_n"] = self.pipe_slab.data_ptr() + 4 * slab_off[lw], M, N
                 d["colsum"] = self.pipe_colsum.data_ptr() + 4 * cs_off[lw]
+                d["n_dw"] = M // 32
                 assert M == 32 * d["kt_lds"] and N == 32 * d["nt"]
         d = st[16]                                        # layer 0: d W0 += ab_0 PE^T, d b0 += ab_0
         M, N = dims[0]
-        d["kind"], d["kt_lds"], d["nt"], d["in_stage"], d["ex_stage"], d["has_dw"], d["split"] = 2, 8, 2, 15, -1, 1, NL
+        d["kind"], d["kt_lds"], d["nt"], d["in_stage"], d["ex_stage"], d["has_dw"], d["split"], d["n_dw"] = 2, 8, 2, 15, -1, 1, NL, 8
         d["x_in"], d["in_ld"], d["own"], d["own_ld"] = ab(0), 256, w["PE"].data_ptr(), 64
         d["reg_tile0"] = -1
         d["slab"], d["slab_m"], d["slab_n"] = self.pipe_slab.data_ptr() + 4 * slab_off[0], M, N
         d["colsum"] = self.pipe_colsum.data_ptr() + 4 * cs_off[0]
         assert (M, N) == (256, 64)
         stages = torch.from_numpy(st.view(np.uint8).copy()).to(dev)
-        sync = torch.zeros(2 + 17 * NL, dtype=torch.int32, device=dev)
+        sync = torch.zeros(2 + 17 * NL + 2 + 16 * 17 * NL, dtype=torch.int32, device=dev)      # (+ room for a diagnostic build's stamps)
         # residual GEMM entries (renumbered workgroups) and the group's finalize table
         res = [i for i, e in enumerate(ent) if "pipe" not in e]
         dres = dw[res].copy()
@@ -461,7 +465,7 @@ class TrainEngine:
         fp = np.concatenate([fp, vfin])
         self.fin_groups["sdf_pipe"] = (torch.from_numpy(fp.view(np.uint8).copy()).to(dev), len(fp), int(max(len(e["rmap"]) for e in ent)),
                                        bool((fp["accumulate"] != 0).any()))
-        self.pipe = dict(stages=stages, sync=sync, lanes=NL, n_stages=17)
+        self.pipe = dict(stages=stages, sync=sync, lanes=NL, n_stages=17, ub0=ub(0), ub4=ub(4), ab8=ab(8))
 
     def _ptr_key(self):
         return tuple(p.data_ptr() for net in self.nets.values() for p in net.module.parameters())
@@ -808,7 +812,7 @@ class TrainEngine:
         if defer_rest and self._side is not None:
             self._ev_heads.record(torch.cuda.current_stream())      # the heads' deltas (operands of the rest group) are complete
 
-        use_pipe = self.pipe is not None and not rg and os.environ.get("VDN_SDF_PIPE", "1") != "0"
+        use_pipe = self.pipe is not None and not rg and os.environ.get("VDN_SDF_PIPE", "0") != "0"
         if use_pipe:
             # rbar chain, fbar chain and the hidden layers' weight gradients in one layer-pipelined launch
             pa = lib.VdnSdfPipeArgs()
@@ -816,6 +820,7 @@ class TrainEngine:
             pa.rays_o, pa.rays_d, pa.z, pa.n_per_ray, pa.z_ld = rays_o.data_ptr(), rays_d.data_ptr(), w["mid_z"].data_ptr(), self.N, self.N
             pa.P, pa.scale = self.P, float(r.sdf_network.scale)
             pa.g_normals, pa.g_sdf = w["d_normals"].data_ptr(), w["d_sdf"].data_ptr()
+            pa.ub0, pa.ub4, pa.ab8 = self.pipe["ub0"], self.pipe["ub4"], self.pipe["ab8"]
             lib.call("vdn_sdf_bwd_pipe_bf16", self._fg(pa), st)
             if defer_rest:
                 self.weight_grads("sdf_pipe", st, gemm_event)
