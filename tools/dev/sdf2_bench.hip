@@ -224,7 +224,7 @@ int main(int argc, char** argv) {
                 for (int d = 0; d < 3; ++d) { e_n = std::max(e_n, std::fabs(nrm[d] - o_n[(size_t)p * 3 + d])); m_n = std::max(m_n, std::fabs(nrm[d])); dot += nrm[d] * o_n[(size_t)p * 3 + d]; na += nrm[d] * nrm[d]; nb += (double)o_n[(size_t)p * 3 + d] * o_n[(size_t)p * 3 + d]; }
                 cosmin = std::min(cosmin, dot / std::sqrt(na * nb + 1e-30));
                 for (int f = 0; f < 256; ++f) {
-                    const size_t idx = (size_t)(p >> 5) * (32 * 256) + (f >> 5) * 1024 + ((f & 31) >> 3) * 256 + ((f & 7) >> 2) * 128 + (p & 31) * 4 + (f & 3);
+                    const size_t idx = (size_t)(p >> 5) * (32 * 256) + (f >> 5) * 1024 + ((f >> 4) & 1) * 512 + ((f >> 2) & 1) * 256 + (p & 31) * 8 + ((f >> 3) & 1) * 4 + (f & 3);      // PT32 (mlp_engine.h)
                     e_f = std::max(e_f, std::fabs(feat[f] - bf2f(o_f[idx]))); m_f = std::max(m_f, std::fabs(feat[f]));
                 }
             }

@@ -223,6 +223,9 @@ struct F32 {
     }
 };
 
+#ifndef VDN_WT_PLANES
+#define VDN_WT_PLANES 0       // write-through plane stores in every chain kernel: measured neutral on the step (same-box A/B of two builds), off
+#endif
 struct BF16 {
     // 4 waves per workgroup and two workgroups resident per CU (2 waves / SIMD): the workgroups run their
     // chunk barriers independently, so one computes while the other waits on memory
@@ -373,7 +376,15 @@ struct BF16 {
             o.y = pack_bf16x2(v[8 * k + 2], v[8 * k + 3]);
             o.z = pack_bf16x2(v[8 * k + 4], v[8 * k + 5]);
             o.w = pack_bf16x2(v[8 * k + 6], v[8 * k + 7]);
+#if VDN_WT_PLANES
+            // write-through (sc1): the line is not kept in this XCD's L2 - saved planes and deltas are next read by other
+            // kernels, while the L2 is what feeds every MLP kernel's weight stream
+            typedef unsigned wt_u32x4 __attribute__((ext_vector_type(4)));
+            const wt_u32x4 ov = {o.x, o.y, o.z, o.w};
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p + 512 * k), "v"(ov) : "memory");
+#else
             *reinterpret_cast<uint4*>(p + 512 * k) = o;
+#endif
         }
     }
     // a tile as loaded: 8 registers of packed bf16 (the chains keep these, not the 16 converted values, in flight across steps)
