@@ -32,7 +32,7 @@ import torch
 # algorithmic FLOPs (2 per MAC, GEMM work only) - SURVEY.md 8d
 F_SDF, F_SDF1, F_GRAD, F_COL, F_VDN, F_NERF, F_NERF_DPT = 1049088, 918016, 918016, 542720, 590336, 1208320, 1232896
 PEAK = {"f32": 157.3e12, "bf16": 2.5e15}     # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
-PROFILE_ROUND = "r02"      # profiles/<round>_traffic_*.json: the PMC traffic figures quoted in `roofline.traffic`
+PROFILE_ROUND = "r03"      # profiles/<round>_traffic_*.json: the PMC traffic figures quoted in `roofline.traffic`
 
 
 def flop_per_ray(wdepth, fg_frac=1.0, bg_frac=1.0):
@@ -245,11 +245,12 @@ class Leg:
     def dw_roofline(self):
         eng = self.trainer.engine
         dtype = "f32" if self.precision == "fp32" else "bf16"
-        tdw = time_kernel(lambda: eng._launch_dw())
+        tdw = time_kernel(lambda: eng._launch_dw_groups())       # two launches: the SDF network's entries, then the rest
         dw_bytes, dw_flops = eng.dw_bytes(), eng.dw_flops()
         tdwf = os.path.join(ROOT, "profiles", "%s_traffic_dw_gemm_%s.json" % (PROFILE_ROUND, dtype))
         traffic = json.load(open(tdwf)).get("hbm_bytes_per_launch") if (os.path.exists(tdwf) and not self.wdepth) else None
-        return {"bound": "hbm", "kernel": "dw_gemm_%s_kernel (batched split-K weight-gradient GEMM, longest kernel of the step)" % dtype,
+        return {"bound": "hbm", "kernel": "dw_gemm_%s_kernel (batched split-K weight-gradient GEMM, longest kernel of the step; its two launches - "
+                                          "SDF entries, the rest - timed back to back)" % dtype,
                 "achieved": dw_bytes / tdw / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": dw_bytes / tdw / 8e12,
                 "traffic": traffic, "kernel_ms": tdw * 1e3, "tflops": dw_flops / tdw / 1e12}
 

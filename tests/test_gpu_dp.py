@@ -203,7 +203,7 @@ def test_bench_line_carries_every_leg():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     d = _bench([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-              "data", "config", "roofline", "cpu_baseline", "trials", "parity_path", "wdepth", "all_samples_evaluated"):
+              "data", "config", "roofline", "cpu_baseline", "trials", "parity_path", "wdepth", "all_samples_evaluated", "object_centric"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["dtype"] == "bf16" and d["vs_baseline"] is None and "workload" in d["config"]
     assert d["trials"]["regions"] >= 5 and d["trials"]["timed_seconds"] >= 1.0
@@ -212,4 +212,8 @@ def test_bench_line_carries_every_leg():
     # model FLOP/s counts executed points only: never above the all-samples convention
     assert d["model_flops_per_s"] <= d["value"] * d["config"]["flop_per_ray"] * (1 + 1e-9)
     assert d["config"]["executed_flop_per_ray"] <= d["config"]["flop_per_ray"]
-    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "inference_launch", "training_launch_full_rows"}
+    # the object-centric leg evaluates (nearly) every foreground sample and fewer background samples than the full-frame headline
+    oc = d["object_centric"]
+    assert oc["value"] > 0 and oc["foreground_points_evaluated_last_step"] > d["config"]["foreground_points_evaluated_last_step"]
+    assert oc["background_points_evaluated_last_step"] < d["config"]["background_points_evaluated_last_step"]

@@ -5,8 +5,8 @@
 #   other's durations in a trace). Summaries are written under gpurun_out/<round>_*; tools/summarise_counters.py and
 #   tools/traffic_json.py turn them into the files committed under profiles/.
 #   usage: bash tools/profile_round.sh r02
-R=${1:-r02}
-export VDN_SIDE_STREAM=0
+R=${1:-r03}
+export VDN_SIDE_STREAM=0 VDN_OVERLAP=0
 bash tools/collect_counters.sh ${R}_sdf1 python3 tools/kernel_loop.py sdf1 65536 bf16 8
 bash tools/collect_counters.sh ${R}_sdf1t python3 tools/kernel_loop.py sdf1t 65536 bf16 8
 bash tools/collect_counters.sh ${R}_step python3 bench.py --headline-only --no-cpu-baseline --steps 10
@@ -15,7 +15,15 @@ for t in sdf1 sdf1t step; do
   rm -rf gpurun_out/${R}_$t/pass*/ gpurun_out/${R}_$t/trace          # raw per-dispatch csv files: tens of MB; the summary keeps the means
 done
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_trace -- python3 bench.py --headline-only --no-cpu-baseline --steps 20 > gpurun_out/${R}_trace_bench.json 2> gpurun_out/${R}_trace.log
-find gpurun_out/${R}_trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${R}_train_bf16_kernel_stats.csv
+# kernel trace of the headline command with nothing but the timed step's own launches in it (--no-roofline), reduced to the
+# steady-state tail (tools/steady_stats.py: the work lists shrink over the first ~600 steps; `value` is decided behind that)
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_trace -- python3 bench.py --headline-only --no-cpu-baseline --no-roofline --steps 20 > gpurun_out/${R}_trace_bench.json 2> gpurun_out/${R}_trace.log
+find gpurun_out/${R}_trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${R}_train_bf16_kernel_stats_whole_run.csv
+find gpurun_out/${R}_trace -name "*kernel_trace.csv" | head -1 | xargs -I{} python3 tools/steady_stats.py {} 0.3 > gpurun_out/${R}_train_bf16_kernel_stats.csv
 rm -rf gpurun_out/${R}_trace
+# the same with both streams in use (the default schedule): kernels overlap, their durations inflate each other
+unset VDN_SIDE_STREAM
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${R}_trace2 -- python3 bench.py --headline-only --no-cpu-baseline --no-roofline --steps 20 > gpurun_out/${R}_trace2_bench.json 2> gpurun_out/${R}_trace2.log
+find gpurun_out/${R}_trace2 -name "*kernel_trace.csv" | head -1 | xargs -I{} python3 tools/steady_stats.py {} 0.3 > gpurun_out/${R}_train_bf16_kernel_stats_two_streams.csv
+rm -rf gpurun_out/${R}_trace2
 echo profile_round done

@@ -22,6 +22,7 @@
 // Weight stream ("sdf2" / "full2", vdn_hip/images.py): chunk format of mlp_engine.h (BF16 policy), uniform 20-KiB stride,
 // same chunk order as the first kernel's streams.
 #pragma once
+#include <cstdlib>
 #include "mlp_engine.h"
 #include "vdn_kernels.h"
 
@@ -644,10 +645,17 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
 
 template <int MODE, bool SAVE, int NSLOT, int DEPTH, int VID = 0>
 int launch(const VdnSdfArgs* args, hipStream_t stream) {
-    constexpr size_t lds = MODE == 1 ? 160 * 1024 : NSLOT * kStride;
-    static bool once = (allow_big_lds(sdf_fwd2_kernel<MODE, SAVE, NSLOT, DEPTH, VID>, lds), true);
+    constexpr size_t lds_min = MODE == 1 ? 160 * 1024 : NSLOT * kStride;
+    constexpr size_t lds_solo = 96 * 1024;          // more than half a CU's LDS: one workgroup per CU
+    static bool once = (allow_big_lds(sdf_fwd2_kernel<MODE, SAVE, NSLOT, DEPTH, VID>, lds_min > lds_solo ? lds_min : lds_solo), true);
     (void)once;
     const int grid = (args->P + kWaves * 32 - 1) / (kWaves * 32);
+    // MODE 0 may run two workgroups per CU, but two waves on a SIMD serialise their VALU work (they only hide each other's
+    // stalls). VDN_SDF0_SOLO=1: a launch that fits the chip at one workgroup per CU (the sampler's passes: 64 or 256
+    // workgroups) asks for enough LDS to get a CU to itself. Measured neutral on the step (same-box A/B, +-10 us): the
+    // dispatcher already spreads 64 workgroups over 64 CUs; off by default
+    static const bool solo = [] { const char* e = getenv("VDN_SDF0_SOLO"); return e != nullptr && e[0] == '1'; }();
+    const size_t lds = (MODE == 0 && solo && grid <= 256) ? lds_solo : lds_min;
     hipLaunchKernelGGL((sdf_fwd2_kernel<MODE, SAVE, NSLOT, DEPTH, VID>), dim3(grid), dim3(kWaves * 64), lds, stream, *args);
     return (int)hipGetLastError();
 }

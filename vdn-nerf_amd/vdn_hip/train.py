@@ -675,6 +675,13 @@ class TrainEngine:
     def _launch_dw(self):
         lib.call("vdn_dw_gemm" + self.sfx, lib.ptr(self.dw_table), self.n_dw, self.dw_total_wgs, _stream())
 
+    def _launch_dw_groups(self):
+        """The weight-gradient GEMM as the Trainer's step launches it: one launch per group (bench.py times this)."""
+        for group in ("sdf", "rest"):
+            if group in self.dw_groups:
+                tab, n, wgs = self.dw_groups[group]
+                lib.call("vdn_dw_gemm" + self.sfx, lib.ptr(tab), n, wgs, _stream())
+
     def rest_weight_grads(self, after=None):
         """Second half of backward(defer_rest=True): the colour / VDN / background networks' weight gradients, issued on the side
         stream behind the background network's backward (or, without a side stream, on the caller's stream). `after`: an event
