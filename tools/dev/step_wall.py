@@ -1,6 +1,6 @@
 """Wall time per training step at the steady-state work lists, for A/B runs of process-wide switches (environment variables
 read once per process): run the same command once per setting inside ONE gpurun call.
-usage: step_wall.py [tag] [steps_per_region=40] [regions=6] [config: white|wdepth] [crop]"""
+usage: step_wall.py [tag] [steps_per_region=40] [regions=6] [config: white|wdepth] [crop|-] [bf16|fp32]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -13,10 +13,11 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "run"
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 R = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 wdepth = len(sys.argv) > 4 and sys.argv[4] == "wdepth"
-crop = int(sys.argv[5]) if len(sys.argv) > 5 else None
+crop = int(sys.argv[5]) if len(sys.argv) > 5 and sys.argv[5] != "-" else None
+prec = sys.argv[6] if len(sys.argv) > 6 else "bf16"
 args = argparse.Namespace(batch=512)
-leg = bench.Leg(args, torch.device("cuda:0"), 1, 0, "bf16", wdepth, 64, crop=crop)
-for i in range(700):
+leg = bench.Leg(args, torch.device("cuda:0"), 1, 0, prec, wdepth, 64, crop=crop)
+for i in range(700 if prec == "bf16" else 120):
     leg.step(i)
 torch.cuda.synchronize()
 res = []

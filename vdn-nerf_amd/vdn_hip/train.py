@@ -18,13 +18,18 @@ from . import images, layout, lib
 PTS_PER_SPLIT = int(os.environ.get("VDN_DW_SPLIT_PTS", "4096"))        # rows one workgroup of the weight-gradient GEMM contracts
 
 
-def _pts_per_split(net):
+def _pts_per_split(net, precision="bf16"):
     """Rows per K split of the weight-gradient GEMM, per launch group (SDF network / the rest): read when an engine is built.
     Measured at the bench's steady-state lists (tools/dev/dw_split_sweep.py, all settings interleaved in one process): the SDF
     group at 6144 rows per split is 231 workgroups - ONE round of the 256 CUs (this kernel runs one 128-KiB-LDS workgroup per
     CU) - and the step is 3.1 % shorter than at 4096 (336 workgroups = 1.3 rounds); 8192 (168 workgroups) gives part of that
     back, 3072 (462) is in between. The rest group is best at 4096 (376 workgroups; 6144: +1.4 %, 3072 = 510 workgroups,
     two full rounds: +17 %)."""
+    if precision == "fp32":
+        # the fp32 GEMM is MFMA-bound (128 x 128 tiles), not HBM-bound: more, shorter splits balance better (2048 / 2048: 8.27 ms per
+        # step against 8.60 at 4096 and 8.77 at 6144 / 4096; 1024: 8.32; tools/dev/step_wall.py ... fp32, same box)
+        dflt = "2048"
+        return int(os.environ.get("VDN_DW_SPLIT_PTS_SDF" if net == "sdf" else "VDN_DW_SPLIT_PTS_REST", dflt))
     if net == "sdf":
         return int(os.environ.get("VDN_DW_SPLIT_PTS_SDF", os.environ.get("VDN_DW_SPLIT_PTS", "6144")))
     return int(os.environ.get("VDN_DW_SPLIT_PTS_REST", str(PTS_PER_SPLIT)))
@@ -257,7 +262,7 @@ class TrainEngine:
             # bandwidth-bound - and 2048 / 8192 rows per split are 10 % slower (more slab traffic / a coarser tail).
             segs = 2 if e.get("A2") is not None else 1
             K = e["Pn"] * segs
-            pps = _pts_per_split(e["net"])
+            pps = _pts_per_split(e["net"], prec)
             splits = max(1, (K + pps - 1) // pps)
             if segs == 2:
                 splits += splits % 2          # first half of the splits = segment 1, second half = segment 2
