@@ -753,3 +753,45 @@ def test_train_prep_equals_the_separate_launches(dev):
             assert torch.equal(got[k][0][:n], ref[k][0][:n]) and torch.equal(got[k][2], ref[k][2]), k
         if not with_fg:
             assert int(got["fg"][1].item()) == -7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wdepth", [False, True], ids=["womsk_white", "womsk_white_wdepth"])
+def test_render_plan_replays_equal_render_calls(wdepth):
+    """NeuSRenderer.plan(): render() captured once as a HIP graph and replayed on new
+    rays is bit-identical to plain render() calls; a parameter changed in place is picked up by the next replay; with the
+    jitter on, every replay draws its own."""
+    from vdn_train import synth, factory
+    dev = torch.device("cuda:0")
+    rend = factory.build_renderer(wdepth=wdepth, device=dev, states=synth.make_all_states(3, wdepth=wdepth), precision="bf16")
+    cams = synth.make_cameras(3)
+    bg = torch.ones(1, 3, device=dev)
+    kw = dict(background_rgb=bg, cos_anneal_ratio=0.7, perturb_overwrite=0, depth_before_color=False)
+
+    def batch(step):
+        o, d = synth.random_pixel_batch(3, step, step % len(cams), 512, rank=0, cams=cams)
+        near, far = synth.near_far_from_sphere(o, d)
+        return tuple(torch.tensor(x).to(dev) for x in (o, d, near, far))
+    with torch.no_grad():
+        plan = rend.plan(512, **kw)
+        for step in range(3):
+            if step == 2:
+                for p in rend.sdf_network.parameters():
+                    p.mul_(1.01)
+                rend.color_network.parameters().__next__().add_(0.003)
+            b = batch(step)
+            got = {k: v.clone() for k, v in plan(*b).items() if v is not None}
+            want = rend.render(*b, **kw)
+            for k, v in got.items():
+                assert torch.equal(v, want[k]), (step, k)
+        with pytest.raises(ValueError):
+            plan(*[t[:100] for t in batch(0)])
+        jit = rend.plan(512, background_rgb=bg, cos_anneal_ratio=0.7, perturb_overwrite=1)
+        b = batch(0)
+        z0 = jit(*b)["z_vals"][:, :128].clone()
+        z1 = jit(*b)["z_vals"][:, :128].clone()
+        assert not torch.equal(z0, z1) and (z0 - z1).abs().max() < 0.5
+    with pytest.raises(RuntimeError):
+        for p in rend.sdf_network.parameters():
+            p.requires_grad_(True)
+        rend.plan(512, **kw)

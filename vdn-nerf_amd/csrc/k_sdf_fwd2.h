@@ -403,7 +403,7 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
 #pragma unroll
         for (int i = 0; i < 39; ++i) pe[i] = pe39[i] * kC1;
 #pragma unroll
-        for (int i = 0; i < 25; ++i) pe[39 + i] = pe[i] - bf16_lo(pack_bf16x2(pe[i], 0.0f));
+        for (int i = 0; i < 25; ++i) pe[39 + i] = fmaf(pe39[i], kC1, -bf16_lo(pack_bf16x2(pe[i], 0.0f)));      // (the residue of the exact product)
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) X.set(kt, vals_tile<64>(pe, h, kt));
         if constexpr (SAVE) {       // saved in the same scaled units as H and V (include/vdn_render.h: VdnSdfArgs); the residue

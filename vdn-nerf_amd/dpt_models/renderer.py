@@ -355,6 +355,10 @@ class NeuSRenderer:
             "inside_sphere": inside,
         }
 
+    def plan(self, batch, **render_kwargs):
+        """A replayable whole-batch render() for `batch` rays with fixed keyword arguments -> RenderPlan."""
+        return RenderPlan(self, batch, **render_kwargs)
+
     def _all_parameters(self):
         """dpt_runner.py:121-130 order: nerf, sdf, variance, colour, (vdn)."""
         ps = []
@@ -434,3 +438,56 @@ class NeuSRenderer:
     def extract_geometry(self, bound_min, bound_max, resolution, threshold=0.0):
         return extract_geometry(bound_min, bound_max, resolution=resolution, threshold=threshold,
                                 query_func=lambda pts: -self.sdf_network.sdf(pts))
+
+
+class RenderPlan:
+    """render() of one fixed batch size captured once as a HIP graph and replayed per batch.
+
+    The inference render() is ~20 launches of 5-130 us plus ~25 buffer allocations; issued one by one from Python the host
+    needs ~350 us per 512-ray batch against ~400 us of device time (measured, tools/dev/fwd_probe.py): the device is still the
+    bound, but barely. The plan runs render() once under stream capture on fixed input buffers - every buffer render()
+    allocates lands in the graph's private pool - and each call copies the rays in, refreshes the weight images if a
+    parameter changed (the launches read them through fixed pointers) and replays: ~75 us of host time per batch. The replay
+    itself is ~3% slower on the device than the eager launches (gaps between graph nodes), so the image loops
+    (vdn_train/validate.py) use it only on request (VDN_RENDER_GRAPH=1): it is for hosts that are busy with something else.
+
+    The returned dict is the one render() returned at capture: its tensors are overwritten by the next call. Keyword
+    arguments (background_rgb, cos_anneal_ratio, perturb_overwrite, depth_before_color) are fixed at construction; the
+    jitter, when perturb is on, is drawn inside the graph from torch's generator and differs per replay.
+    """
+
+    def __init__(self, renderer, batch, **render_kwargs):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in renderer._all_parameters()):
+            raise RuntimeError("RenderPlan is the inference path: build and call it under torch.no_grad()")
+        dev = next(renderer.sdf_network.parameters()).device
+        self.renderer, self.batch, self.kw = renderer, int(batch), dict(render_kwargs)
+        bg = self.kw.get("background_rgb")
+        if bg is not None:
+            self.kw["background_rgb"] = bg.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous().clone()
+        self.o, self.d = torch.zeros(batch, 3, device=dev), torch.zeros(batch, 3, device=dev)
+        self.d[:, 2] = 1.0
+        self.near, self.far = torch.zeros(batch, 1, device=dev), torch.ones(batch, 1, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                         # warm-up outside capture: weight images, lazy workspaces
+            renderer.render(self.o, self.d, self.near, self.far, **self.kw)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = renderer.render(self.o, self.d, self.near, self.far, **self.kw)
+
+    def _nets(self):
+        r = self.renderer
+        return [m for m in (r.nerf, r.sdf_network, r.color_network, r.depth_network) if m is not None]
+
+    def __call__(self, rays_o, rays_d, near, far):
+        if rays_o.shape[0] != self.batch:
+            raise ValueError("this plan renders batches of %d rays, got %d" % (self.batch, rays_o.shape[0]))
+        for m in self._nets():
+            m._images()                                       # re-materialise the weight images if a parameter changed
+        self.o.copy_(rays_o.detach())
+        self.d.copy_(rays_d.detach())
+        self.near.copy_(near.detach().reshape(-1, 1))
+        self.far.copy_(far.detach().reshape(-1, 1))
+        self.graph.replay()
+        return self.out

@@ -210,7 +210,7 @@ class Trainer:
         grad = eng._grad_flat
         eng.backward(self.g_color, g_feats, g_weights, self.g_eik, defer_rest=True, gemm_event=self._ev_gemm if self.overlap else None)
         update_sdf(st)
-        side = eng.rest_weight_grads(after=self._ev_gemm) if self.overlap else None
+        side = eng.rest_weight_grads(after=self._ev_gemm if os.environ.get("VDN_REST_AFTER_SDF", "1") != "0" else None) if self.overlap else None
         if side is None:
             if not self.overlap:
                 eng._join()                     # the background network's backward (side stream) feeds the rest group
