@@ -212,6 +212,12 @@ class Leg:
         o, d = self.batches[0][0], self.batches[0][1]
         with torch.no_grad():
             tk_inf = time_kernel(lambda: rend.sdf_network._run(1, rays=(o, d, eng.w["mid_z"])))
+            # SURVEY.md 8d's configuration C2 on the same 65 536 points: K1 + K3 + K5 + K6 = PE + SDF MLP + gradient sweep, colour
+            # head, NeuS alpha + compositing (NeuSRenderer._shade, renderer.py:239-315). The north star names these as ONE
+            # kernel; they are three launches here (the heads and the compositor are launches of their own: DESIGN.md 3a),
+            # timed as render() issues them, end to end
+            bgc = torch.ones(3, device=self.dev)
+            tk_c2 = time_kernel(lambda: rend._shade(o, d, eng.w["dists"], eng.w["mid_z"], None, bgc, 0.5))
         # the training-mode launch over ALL rows (what the step launches on a scene whose samples all lie inside the relaxed
         # sphere, and in the all-samples leg): no work list
         fgc, eng._fg_compact = eng._fg_compact, False
@@ -240,7 +246,13 @@ class Leg:
                                      "frac": fl_inf / tk_inf / PEAK[dtype], "traffic": tr_inf, "traffic_source": src_inf},
                 "training_launch_full_rows": {"kernel_ms": tk_full * 1e3, "points": eng.P, "achieved": fl_inf / tk_full / 1e12,
                                               "frac": fl_inf / tk_full / PEAK[dtype],
-                                              "traffic": None if tr_train is None else tr_train * float(eng.P) / rows_mean}}
+                                              "traffic": None if tr_train is None else tr_train * float(eng.P) / rows_mean},
+                "c2_forward": {"what": "SURVEY.md 8d C2: PE + SDF MLP + gradient sweep + colour%s head + NeuS alpha / compositing on %d points, "
+                                       "as render() launches them (%d launches, not one fused kernel)"
+                                       % (" + VDN" if self.wdepth else "", eng.P, 4 if self.wdepth else 3),
+                               "chain_ms": tk_c2 * 1e3, "points": eng.P, "points_per_s": eng.P / tk_c2,
+                               "achieved": (F_SDF + F_GRAD + F_COL + (F_VDN if self.wdepth else 0)) * eng.P / tk_c2 / 1e12,
+                               "frac": (F_SDF + F_GRAD + F_COL + (F_VDN if self.wdepth else 0)) * eng.P / tk_c2 / PEAK[dtype]}}
 
     def dw_roofline(self):
         eng = self.trainer.engine

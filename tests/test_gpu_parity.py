@@ -795,3 +795,31 @@ def test_render_plan_replays_equal_render_calls(wdepth):
         for p in rend.sdf_network.parameters():
             p.requires_grad_(True)
         rend.plan(512, **kw)
+
+
+@pytest.mark.gpu
+def test_small_sdf_passes_equal_the_large_kernel_bit_for_bit():
+    """vdn_sdf_mlp_fwd_bf16(mode 0) routes launches of <= 8192 points (the sampler's up-sampling passes, renderer.py:352-372)
+    to the feature-split kernel (csrc/k_sdf_fwd0_split.h) and larger ones to the 128-point kernel: same values, bit for bit,
+    for point input and for the sampler's ray form (column slices of wider buffers), full and ragged sizes."""
+    from vdn_train import synth, factory
+    dev = torch.device("cuda:0")
+    rend = factory.build_renderer(device=dev, states=synth.make_all_states(5), precision="bf16")
+    net = rend.sdf_network
+    g = torch.Generator(device=dev).manual_seed(11)
+    with torch.no_grad():
+        for P in (8192, 8191, 37, 1):
+            pts = (torch.rand(P, 3, device=dev, generator=g) * 2 - 1) * 1.2
+            small = net._run(0, pts=pts)
+            reps = (16384 + P - 1) // P + 1                    # the same points inside a launch the large kernel takes
+            large = net._run(0, pts=pts.repeat(reps, 1))
+            assert large.shape[0] > 8192 and torch.equal(small, large[:P]), P
+            assert torch.isfinite(small).all()
+        B = 512
+        o = torch.rand(B, 3, device=dev, generator=g) - 0.5
+        d = torch.nn.functional.normalize(torch.rand(B, 3, device=dev, generator=g) - 0.5, dim=1)
+        z = torch.rand(B, 128, device=dev, generator=g) * 2
+        s16, s64 = torch.zeros(B, 128, device=dev), torch.zeros(B, 128, device=dev)
+        net._run(0, rays=(o, d, z[:, 64:80]), sdf_out=s16[:, 64:80])       # 8192 points: split kernel
+        net._run(0, rays=(o, d, z[:, 32:96]), sdf_out=s64[:, 32:96])       # 32768 points: large kernel
+        assert torch.equal(s16[:, 64:80], s64[:, 64:80]) and (s16[:, :64] == 0).all() and (s16[:, 80:] == 0).all()

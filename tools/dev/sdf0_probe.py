@@ -12,7 +12,7 @@ rend = factory.build_renderer(wdepth=False, device=dev, states=synth.make_all_st
 net = rend.sdf_network
 out = {}
 g = torch.Generator(device=dev).manual_seed(1)
-for P in (100, 2048, 8192, 16384, 32768, 65536):
+for P in (100, 8192, 16384, 32768, 65536, 262144):
     pts = (torch.rand(P, 3, device=dev, generator=g) * 2 - 1) * 1.1
     with torch.no_grad():
         for _ in range(5):

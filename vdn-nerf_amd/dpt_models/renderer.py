@@ -302,8 +302,19 @@ class NeuSRenderer:
                 bg_dists, bg_mid = self._sections(z_feed, T, sample_dist)
                 bg_density, bg_rgb, bg_feat = self.nerf._run(rays=(rays_o, rays_d, bg_mid), active=None)
 
-        ws = {}
-        sdf, feat, normals = self.sdf_network._run(1, rays=(rays_o, rays_d, mid_z), workspace=ws)   # renderer.py:239-243
+        return self._shade(rays_o, rays_d, dists, mid_z, (bg_density, bg_rgb, bg_feat, bg_dists, bg_mid) if O > 0 else None,
+                           background_rgb, cos_anneal_ratio, depth_before_color)
+
+    def _shade(self, rays_o, rays_d, dists, mid_z, bg, background_rgb, cos_anneal_ratio, depth_before_color=False):
+        """render_core of the reference on sampled rays (renderer.py:239-315; SURVEY.md 8d "C2": PE + SDF MLP + gradient sweep,
+        colour / VDN heads, NeuS alpha + compositing) - three launches (four with the VDN head) on B x N points. `bg`: the
+        background pass' (density, rgb, feat, dists, mid_z) over all N + n_outside sections, or None."""
+        B, N = mid_z.shape
+        dev, st = mid_z.device, _stream()
+        bg_density, bg_rgb, bg_feat, bg_dists, bg_mid = bg if bg is not None else (None,) * 5
+        O = 0 if bg is None else bg_dists.shape[1] - N
+        T = N + O
+        sdf, feat, normals = self.sdf_network._run(1, rays=(rays_o, rays_d, mid_z))          # renderer.py:239-243
         sampled_feat = None
         if self.depth_network is not None:                                       # renderer.py:245-249
             sampled_feat = self.depth_network._run(normals, feat, rays=(rays_o, rays_d, mid_z))

@@ -325,6 +325,18 @@ class TrainEngine:
         self.dw_groups = {"sdf": (self.dw_table, n_sdf, wg_sdf)}
         if len(rest):
             self.dw_groups["rest"] = (torch.from_numpy(rest.view(np.uint8)).to(dev), len(rest), wg - wg_sdf)
+        # the rest group once more as its two halves (the Trainer's schedule launches them at different times: DESIGN.md 3d):
+        # "heads" = colour / VDN heads, "nerf" = the background network. `ent` lists sdf, heads, nerf in this order.
+        n_heads_end = n_sdf + sum(1 for e in ent if e["net"] not in ("sdf", "nerf"))
+        assert all(e["net"] == "nerf" for e in ent[n_heads_end:])
+        sub_ranges = {"heads": (n_sdf, n_heads_end), "nerf": (n_heads_end, len(ent))}
+        for gname, (lo, hi) in sub_ranges.items():
+            if hi > lo:
+                sub = dw[lo:hi].copy()
+                wg_lo = int(dw[lo]["wg_begin"])
+                wg_hi = int(dw[hi]["wg_begin"]) if hi < len(ent) else wg
+                sub["wg_begin"] -= wg_lo
+                self.dw_groups[gname] = (torch.from_numpy(sub.view(np.uint8)).to(dev), hi - lo, wg_hi - wg_lo)
         # one more finalize descriptor: d loss / d variance = sum over rays of the compositor's per-ray partials (a [B,1] "column
         # sum" with one row): the reduction rides in the finalize launch instead of a launch of its own
         vfin = np.zeros(1, dtype=fin.dtype)
@@ -341,6 +353,8 @@ class TrainEngine:
         # per-group finalize tables (the variance's reduction rides with the SDF group)
         fg = {"sdf": np.concatenate([fin[:n_sdf], vfin]), "rest": fin[n_sdf:]}
         mm = {"sdf": ent[:n_sdf], "rest": ent[n_sdf:]}
+        for gname, (lo, hi) in sub_ranges.items():
+            fg[gname], mm[gname] = fin[lo:hi], ent[lo:hi]
         self.fin_groups = {k: (torch.from_numpy(v.view(np.uint8).copy()).to(dev), len(v), int(max(len(e["rmap"]) for e in mm[k])),
                                bool((v["accumulate"] != 0).any())) for k, v in fg.items() if len(v) and len(mm[k])}
         # The layer-pipelined SDF backward (csrc/train_sdf_pipe_bf16.hip) is built and tested but OFF by default (VDN_SDF_PIPE=1
@@ -356,7 +370,7 @@ class TrainEngine:
             for name, (g, v, b) in net.img.matrices.items():
                 if g is not None:
                     rows.append((g, v, net.img.inv_norm[net.img.r_off[name]:], net.dweff_view(name), net.grads[id(g)], net.grads[id(v)]))
-                    row_group.append("sdf" if key == "sdf" else "rest")
+                    row_group.append(("sdf",) if key == "sdf" else ("rest", "nerf" if key == "nerf" else "heads"))
         wn = np.zeros(len(rows), dtype=lib.struct_dtype("VdnWeightNormBwdDesc"))
         for i, (g, v, inv, dwe, dg, dv) in enumerate(rows):
             wn[i]["g"], wn[i]["v"], wn[i]["inv_norm"], wn[i]["dw_eff"] = g.data_ptr(), v.data_ptr(), inv.data_ptr(), dwe.data_ptr()
@@ -365,8 +379,8 @@ class TrainEngine:
         self.n_wn = len(rows)
         self.wn_max_rows = max([r[1].shape[0] for r in rows] + [1])
         self.wn_groups = {}
-        for k in ("sdf", "rest"):
-            idx = [i for i, gk in enumerate(row_group) if gk == k]
+        for k in ("sdf", "rest", "heads", "nerf"):
+            idx = [i for i, gk in enumerate(row_group) if k in gk]
             if idx:
                 self.wn_groups[k] = (torch.from_numpy(wn[idx].view(np.uint8).copy()).to(dev), len(idx), max(rows[i][1].shape[0] for i in idx))
         if "sdf" in self.wn_groups:
@@ -686,6 +700,22 @@ class TrainEngine:
             if group in self.dw_groups:
                 tab, n, wgs = self.dw_groups[group]
                 lib.call("vdn_dw_gemm" + self.sfx, lib.ptr(tab), n, wgs, _stream())
+
+    def side_weight_grads(self, group, after=None):
+        """One half of the rest group on the side stream (backward(defer_rest=True) came first): "nerf" = the background
+        network's weight gradients, behind its backward on that stream; "heads" = the colour / VDN heads', behind the heads'
+        backward on the caller's stream. `after`: one more event to wait for. Returns the torch stream (None without a side
+        stream: the work was issued on the caller's)."""
+        if self._side is None:
+            self.weight_grads(group, _stream())
+            return None
+        if group != "nerf":
+            self._side.wait_event(self._ev_heads)
+        if after is not None:
+            self._side.wait_event(after)
+        self.weight_grads(group, self._side.cuda_stream)
+        self._pending = False            # joined by the caller's own event, not by _join()
+        return self._side
 
     def rest_weight_grads(self, after=None):
         """Second half of backward(defer_rest=True): the colour / VDN / background networks' weight gradients, issued on the side

@@ -6,12 +6,14 @@ The hot loop does not go through autograd: TrainEngine.forward -> fused loss ker
 TrainEngine.backward -> (all-reduce of the gradient slices) -> fused Adam on flat buffers.
 
 Schedule of one step (overlap=True, the default): the next step begins with the sampler - four dependent SDF-only passes
-that fill a quarter of the chip - so the step ends in two halves:
+that need only the SDF weights - so the step ends in three pieces:
   main stream   ... SDF backward -> SDF weight-gradient GEMM -> [all-reduce SDF slice] -> Adam(SDF, variance) -> SDF images
                 -> next step's sampler ...
-  side stream   background backward -> (SDF GEMM done) -> colour / VDN / background weight-gradient GEMM ->
-                [all-reduce their slices] -> Adam(rest) -> their images            (joined before the next forward)
-The HBM-bound second GEMM and the collectives run beside the latency-bound sampler. Results are identical to the in-order
+  side stream   background backward -> background weight-gradient GEMM -> [all-reduce] -> Adam -> images   (beside the SDF
+                backward) -> (SDF update done) -> colour / VDN heads' weight-gradient GEMM -> [all-reduce] -> Adam -> images
+                (beside the next step's sampler; joined before the next forward)
+The heads' HBM-bound GEMM and the collectives run beside the latency-bound sampler; the small launches of the SDF update
+have no GEMM beside them. Results are identical to the in-order
 schedule (overlap=False) bit for bit: the same launches on the same data, only on two streams.
 """
 import math
@@ -97,7 +99,7 @@ class Trainer:
             self.coll.broadcast(self._param_flat, 0)     # replicas must start from rank 0's parameters (e.g. per-process random init)
         self.engine = TrainEngine(renderer, batch_size, self.dev)
         self.overlap = (os.environ.get("VDN_OVERLAP", "1") != "0") if overlap is None else bool(overlap)
-        self._ev_gemm, self._ev_rest = torch.cuda.Event(), torch.cuda.Event()
+        self._ev_gemm, self._ev_rest, self._ev_tail = (torch.cuda.Event() for _ in range(3))
         self._rest_pending = False
         self.engine.join_hook = self.join
         self._eik_global = torch.zeros(3, dtype=torch.float32, device=self.dev)
@@ -154,8 +156,9 @@ class Trainer:
             z, z_out = r._sample(rays_o, rays_d, near.reshape(B), far.reshape(B), r.perturb, t_rand, t_rand_out, z_vals_inject,
                                  defer_last_merge=True)
         self.join()
+        after_sdf = self._eikonal_begin if self.coll.enabled else None
         w = eng.forward(rays_o, rays_d, z.contiguous(), z_out, self.bg, self.cos_anneal_ratio(), skip_far=True,
-                        pending_merge=r._pending_merge, after_sdf=self._eikonal_begin if self.coll.enabled else None)
+                        pending_merge=r._pending_merge, after_sdf=after_sdf)
         if self.coll.enabled:
             # the eikonal term is a ratio of sums over the GLOBAL batch (renderer.py:313-315): its two sums were
             # on their way since the SDF kernel finished; the loss kernel and the compositor's adjoint read w["eik"]
@@ -194,13 +197,22 @@ class Trainer:
             self._depth_adam_steps += 1
         depth_step = self._depth_adam_steps if (depth_on and self._depth_ranges) else 0
 
-        def update_rest(stream):
-            self.coll.finish(self.coll.begin([grad[b:e] for b, e in self._slices_rest]))
-            if self._rest_ranges:
-                adam(self._rest_ranges, main_step, stream)
-            if depth_step:
-                adam(self._depth_ranges, depth_step, stream)
-            images.refresh_together([eng.nets[k].img for k in rest_nets], stream, self._img_cache.setdefault("rest", {}))
+        sdf_begin = self._sdf_ranges[0][0]
+
+        def update_rest(stream, part="rest"):
+            """all-reduce, Adam and weight images of the parameters outside the SDF group: all of them ("rest"), or only those
+            in front of the SDF network in the flat buffer ("nerf": the background network) / behind it ("heads")."""
+            keep = {"rest": lambda b: True, "nerf": lambda b: b < sdf_begin, "heads": lambda b: b >= sdf_begin}[part]
+            nets = [k for k in rest_nets if part == "rest" or (k == "nerf") == (part == "nerf")]
+            self.coll.finish(self.coll.begin([grad[b:e] for b, e in self._slices_rest if keep(b)]))
+            rr = [r_ for r_ in self._rest_ranges if keep(r_[0])]
+            if rr:
+                adam(rr, main_step, stream)
+            dr = [r_ for r_ in self._depth_ranges if keep(r_[0])] if depth_step else []
+            if dr:
+                adam(dr, depth_step, stream)
+            if nets:
+                images.refresh_together([eng.nets[k].img for k in nets], stream, self._img_cache.setdefault(part, {}))
 
         def update_sdf(stream):
             self.coll.finish(self.coll.begin([grad[b:e] for b, e in self._sdf_ranges]))
@@ -209,18 +221,44 @@ class Trainer:
 
         grad = eng._grad_flat
         eng.backward(self.g_color, g_feats, g_weights, self.g_eik, defer_rest=True, gemm_event=self._ev_gemm if self.overlap else None)
+        split = self.overlap and os.environ.get("VDN_SPLIT_REST", "1") != "0" and "nerf" in eng.dw_groups and "heads" in eng.dw_groups
+        side = None
+        if split:
+            # the background network's half right behind its backward, beside the SDF backward on the main stream ...
+            side = eng.side_weight_grads("nerf")
+            if side is not None:
+                with torch.cuda.stream(side):
+                    update_rest(side.cuda_stream, "nerf")
         update_sdf(st)
-        side = eng.rest_weight_grads(after=self._ev_gemm if os.environ.get("VDN_REST_AFTER_SDF", "1") != "0" else None) if self.overlap else None
-        if side is None:
-            if not self.overlap:
-                eng._join()                     # the background network's backward (side stream) feeds the rest group
-                eng.weight_grads("rest", st)
-            update_rest(st)
-        else:
+        if split and side is not None:
+            # ... and the heads' half behind the SDF group's update: their GEMM runs beside the next step's sampler (which leaves
+            # most of the chip idle) instead of beside the SDF update's small launches, which it starved: 200 us for launches that
+            # take 55 us alone. Measured (same box, 3 alternating runs each): 1.410 ms / step against 1.427 with one GEMM for both
+            # halves behind the SDF GEMM; deferring the background half too (its next forward has slack) costs 1.48 - its GEMM
+            # then starves the sampler's 256-workgroup SDF passes (150 us for an 18-us pass)
+            self._ev_tail.record(torch.cuda.current_stream())
+            eng.side_weight_grads("heads", after=self._ev_tail)
             with torch.cuda.stream(side):
-                update_rest(side.cuda_stream)
+                update_rest(side.cuda_stream, "heads")
                 self._ev_rest.record(side)
             self._rest_pending = True
+        else:
+            if split:                            # no side stream: both halves on the caller's stream
+                update_rest(st, "nerf")
+                eng.weight_grads("heads", st)
+                update_rest(st, "heads")
+            else:
+                side = eng.rest_weight_grads(after=self._ev_gemm) if self.overlap else None
+                if side is None:
+                    if not self.overlap:
+                        eng._join()                     # the background network's backward (side stream) feeds the rest group
+                        eng.weight_grads("rest", st)
+                    update_rest(st)
+                else:
+                    with torch.cuda.stream(side):
+                        update_rest(side.cuda_stream)
+                        self._ev_rest.record(side)
+                    self._rest_pending = True
         self.iter_step += 1
         return self.scalars        # device tensor [loss, color_loss, psnr, eikonal, depth_loss, mask_loss]; no host sync here
 
