@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VDN_ABI_VERSION 19
+#define VDN_ABI_VERSION 20
 
 int vdn_abi_version(void);
 
@@ -219,6 +219,12 @@ int vdn_merge_sorted(const VdnMergeArgs* args_host, void* stream);
  * z / sdf / ld are ignored: the rows are handed over on chip) - cat_z_vals of round i and up_sample of round i+1
  * (renderer.py:372-386) in one launch. Same results as the two calls. */
 int vdn_merge_upsample(const VdnMergeArgs* merge_host, const VdnUpsampleArgs* upsample_host, void* stream);
+/* vdn_sdf_mlp_fwd_bf16(mode 0) on the new samples of a round (renderer.py:201; ray form: sdf.z = merge.new_z [B,16],
+ * sdf.sdf = merge.new_sdf [B,16]) followed by vdn_merge_upsample on those rays (renderer.py:372-386), in ONE launch: a
+ * 32-point workgroup of the small-pass kernel is two rays, whose waves go on to merge and up-sample their rows. Same results
+ * as the two calls, bit for bit. Covers 16 new samples per ray, no work list; returns -10 for any other shape (the caller
+ * then makes the two calls). */
+int vdn_sdf_merge_upsample_bf16(const VdnSdfArgs* sdf_host, const VdnMergeArgs* merge_host, const VdnUpsampleArgs* upsample_host, void* stream);
 
 /* renderer.py:228-230 / 107-109: dists = diff(z) with last = sample_dist; mid_z = z + dists/2. */
 typedef struct {

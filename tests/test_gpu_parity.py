@@ -823,3 +823,30 @@ def test_small_sdf_passes_equal_the_large_kernel_bit_for_bit():
         net._run(0, rays=(o, d, z[:, 64:80]), sdf_out=s16[:, 64:80])       # 8192 points: split kernel
         net._run(0, rays=(o, d, z[:, 32:96]), sdf_out=s64[:, 32:96])       # 32768 points: large kernel
         assert torch.equal(s16[:, 64:80], s64[:, 64:80]) and (s16[:, :64] == 0).all() and (s16[:, 80:] == 0).all()
+
+
+@pytest.mark.gpu
+def test_fused_sampler_rounds_equal_the_two_launch_rounds(monkeypatch):
+    """vdn_sdf_merge_upsample_bf16 (the SDF pass of an up-sampling round, renderer.py:201, and cat_z_vals + the next up_sample,
+    renderer.py:372-386, in one launch) against the two launches it replaces: every output of render() bit for bit, jitter on."""
+    from vdn_train import synth, factory
+    dev = torch.device("cuda:0")
+    rend = factory.build_renderer(device=dev, states=synth.make_all_states(4), precision="bf16")
+    cams = synth.make_cameras(4)
+    outs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("VDN_FUSE_SDF_ROUNDS", fused)
+        res = []
+        for B in (512, 77):                     # 77 rays: the last workgroup holds one ray
+            o, d = synth.random_pixel_batch(4, 1, 1, B, rank=0, cams=cams)
+            near, far = synth.near_far_from_sphere(o, d)
+            torch.manual_seed(3)
+            with torch.no_grad():
+                res.append(rend.render(*(torch.tensor(x).to(dev) for x in (o, d, near, far)), background_rgb=torch.ones(1, 3, device=dev),
+                                       cos_anneal_ratio=0.6))
+        outs[fused] = res
+    for a, b in zip(outs["1"], outs["0"]):
+        for k, v in a.items():
+            if v is not None:
+                assert torch.equal(v, b[k]), k
+    assert torch.isfinite(outs["1"][0]["z_vals"]).all()

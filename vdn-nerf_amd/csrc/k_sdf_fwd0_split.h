@@ -16,8 +16,14 @@
 //    into the accumulator, k-steps in order, softplus in scaled units, bf16 packing of the hidden activations, and the
 //    last layer's sdf row as ONE f32 fma chain over the unrounded activations of layer 7 in MODE 0's order (wave 0 runs
 //    it from LDS). The two kernels return bit-identical values (tests/test_gpu_parity.py).
+//
+// ROUNDS = true appends the rest of an up-sampling round (renderer.py:372-386) to the pass: with 16 new samples per ray a
+// workgroup's 32 points are exactly two rays, so waves 0 and 1 go on to merge their ray's new samples (z and the sdf values
+// just computed, handed over in LDS) into its sorted row and to draw the next round's samples from it - vdn_merge_upsample's
+// work (k_ray_rows.h: the same device functions, the same bits) without its launch and its trip through HBM.
 #pragma once
 #include "k_sdf_fwd2.h"
+#include "k_ray_rows.h"
 
 namespace vdn {
 namespace sdf0s {
@@ -98,8 +104,11 @@ VDN_DEV f32x16 layer_mma(const WSet& W, const char* smem, int lane) {
     return acc;
 }
 
-template <int VID = 0>
-__global__ __launch_bounds__(kWaves * 64, 1) void sdf_fwd0_split_kernel(SdfArgs a) {
+constexpr int kRows = kG;                       // ROUNDS: per-ray scratch rows (4 x kMaxT floats per ray) where layer 7's activations were
+constexpr int kNewSdf = kW8;                    // ROUNDS: the 32 new sdf values, where the last layer's row was
+
+template <bool ROUNDS = false, int VID = 0>
+__global__ __launch_bounds__(kWaves * 64, 1) void sdf_fwd0_split_kernel(SdfArgs a, MergeArgs mg, UpsampleArgs up) {
     using P = BF16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -184,7 +193,8 @@ __global__ __launch_bounds__(kWaves * 64, 1) void sdf_fwd0_split_kernel(SdfArgs 
     hidden(std::integral_constant<int, 6>{}, WA);
     hidden(std::integral_constant<int, 7>{}, WB);
 
-    if (wave != 0) return;
+    if (wave > (ROUNDS ? 1 : 0)) return;
+    if (wave == 0) {
     // sdf = W8[0,:] . h8 + b8[0]: MODE 0's f32 chain (k_sdf_fwd2.h, layer 7's epilogue), tile by tile, pair by pair
     float sdf_dot = 0.0f;
 #pragma unroll
@@ -198,15 +208,32 @@ __global__ __launch_bounds__(kWaves * 64, 1) void sdf_fwd0_split_kernel(SdfArgs 
         }
     }
     const float dot = sdf_dot + __shfl_xor(sdf_dot, 32);
-    if (wr.ok && h == 0) a.sdf[sdf_idx] = fmaf(dot, 1.0f / sdf2::kC1, b0) * (1.0f / a.scale);
+    const float sdf = fmaf(dot, 1.0f / sdf2::kC1, b0) * (1.0f / a.scale);
+    if (wr.ok && h == 0) a.sdf[sdf_idx] = sdf;
+    if constexpr (ROUNDS) {
+        if (h == 0) *reinterpret_cast<float*>(smem + kNewSdf + c * 4) = sdf;
+    }
+    }
+    if constexpr (ROUNDS) {
+        lds_barrier();                              // waves 0 and 1 (the others have left): the new sdf values are in LDS, G is free
+        const int r = blockIdx.x * 2 + wave;        // point c of this workgroup = ray c / 16, new sample c % 16
+        if (r >= mg.B) return;
+        float* rows = reinterpret_cast<float*>(smem + kRows) + wave * 4 * kMaxT;
+        float *za = rows, *zb = rows + kMaxT, *lz = rows + 2 * kMaxT, *ls = rows + 3 * kMaxT;
+        merge_row(mg, r, lane, za, zb, lz, ls, nullptr, reinterpret_cast<const float*>(smem + kNewSdf) + wave * 16);
+        __builtin_amdgcn_wave_barrier();
+        upsample_row(up, r, lane, mg.M + mg.K, lz, ls, za);     // the old row's scratch serves as the cdf row
+    }
 }
 
-template <int VID = 0>
-int launch(const VdnSdfArgs* args, hipStream_t stream) {
-    static bool once = (allow_big_lds(sdf_fwd0_split_kernel<VID>, kLds), true);
+template <bool ROUNDS = false, int VID = 0>
+int launch(const VdnSdfArgs* args, hipStream_t stream, const VdnMergeArgs* mg = nullptr, const VdnUpsampleArgs* up = nullptr) {
+    static bool once = (allow_big_lds(sdf_fwd0_split_kernel<ROUNDS, VID>, kLds), true);
     (void)once;
+    static_assert(kRows + 2 * 4 * kMaxT * 4 <= kLds && 32 * 4 <= 1024, "ROUNDS scratch fits the regions it reuses");
     const int grid = (args->P + 31) / 32;
-    hipLaunchKernelGGL((sdf_fwd0_split_kernel<VID>), dim3(grid), dim3(kWaves * 64), kLds, stream, *args);
+    hipLaunchKernelGGL((sdf_fwd0_split_kernel<ROUNDS, VID>), dim3(grid), dim3(kWaves * 64), kLds, stream, *args,
+                       mg != nullptr ? *mg : VdnMergeArgs{}, up != nullptr ? *up : VdnUpsampleArgs{});
     return (int)hipGetLastError();
 }
 

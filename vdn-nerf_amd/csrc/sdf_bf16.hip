@@ -13,7 +13,7 @@ extern "C" int vdn_sdf_mlp_fwd_bf16(int mode, const VdnSdfArgs* args, void* stre
         // few points (the sampler's up-sampling passes): features split over the waves, 32 points per workgroup (k_sdf_fwd0_split.h);
         // otherwise 128 points per workgroup, 80 KiB of LDS: two workgroups per CU. Same values either way.
         static const long split_max = [] { const char* e = getenv("VDN_SDF0_SPLIT_MAX"); return e != nullptr ? atol(e) : 8192L; }();
-        if (args->P <= split_max) return vdn::sdf0s::launch<>(args, stream);
+        if (args->P <= split_max) return vdn::sdf0s::launch<false>(args, stream);
         return vdn::sdf2::launch<0, false, 4, 3>(args, stream);
     }
     if (mode != 1) return -4;
@@ -23,4 +23,20 @@ extern "C" int vdn_sdf_mlp_fwd_bf16(int mode, const VdnSdfArgs* args, void* stre
         return vdn::sdf2::launch<1, true, 4, 3>(args, stream);
     }
     return vdn::sdf2::launch<1, false, 4, 3>(args, stream);
+}
+
+// One up-sampling round behind its SDF pass (renderer.py:201 + 372-386) in one launch: vdn_sdf_mlp_fwd_bf16(mode 0) on the new
+// samples (ray form, 16 per ray), then vdn_merge_upsample on the rows of those rays. Same values as the two calls.
+extern "C" int vdn_sdf_merge_upsample_bf16(const VdnSdfArgs* args, const VdnMergeArgs* m, const VdnUpsampleArgs* u, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (args == nullptr || m == nullptr || u == nullptr || args->P <= 0 || args->blob == nullptr) return -1;
+    if (args->rays_o == nullptr || args->rays_d == nullptr || args->z == nullptr || args->sdf == nullptr) return -2;
+    // the shape the fusion covers: 16 new samples per ray (two rays per 32-point workgroup), no work list, the pass' input
+    // and output ARE the merge's new rows
+    if (args->pts != nullptr || args->active_idx != nullptr || args->n_per_ray != 16 || m->K != 16 || args->P != (int64_t)m->B * 16 ||
+        args->z != m->new_z || args->sdf != m->new_sdf || args->z_ld != 16 || args->sdf_ld != 16) return -10;
+    if (m->B <= 0 || !m->z || !m->z_out || !m->sdf || !m->sdf_out) return -3;
+    if (m->M < 1 || m->M + m->K > vdn::kMaxT || m->ld < m->M || m->ld_out < m->M + m->K) return -4;
+    if (u->B != m->B || u->M != m->M + m->K || u->weights || !u->rays_o || !u->rays_d || !u->u || !u->new_z || u->n_imp < 1 || u->n_imp > 64) return -5;
+    return vdn::sdf0s::launch<true>(args, stream, m, u);
 }

@@ -127,6 +127,21 @@ class SDFNetwork(_HipNet):
         return images.sdf_streams(scaled=(self.precision == "bf16"), **self.conf)
 
     # -- kernels ------------------------------------------------------------------------------
+    def _run_round(self, rays, sdf_out, merge, upsample):
+        """One up-sampling round in one launch (vdn_sdf_merge_upsample_bf16): the sdf-only pass on the round's new samples
+        `rays` = (rays_o, rays_d, new_z [B,16]) -> sdf_out [B,16], then `merge` (VdnMergeArgs) and `upsample` (VdnUpsampleArgs) on
+        those rays. False = this shape / precision is not covered and nothing was launched (make the two calls)."""
+        rays_o, rays_d, z = rays
+        if self.precision != "bf16" or z.shape[1] != 16 or not z.is_contiguous() or not sdf_out.is_contiguous():
+            return False
+        img = self._images()
+        a = lib.VdnSdfArgs()
+        a.rays_o, a.rays_d, a.z, a.n_per_ray, a.z_ld = rays_o.data_ptr(), rays_d.data_ptr(), z.data_ptr(), 16, 16
+        a.P, a.scale, a.sdf, a.sdf_ld = z.shape[0] * 16, float(self.scale), sdf_out.data_ptr(), 16
+        a.w8row = img.weff_view("lin8").data_ptr()
+        a.blob = img.blobs["sdf"].data_ptr()
+        return lib.try_call("vdn_sdf_merge_upsample_bf16", a, merge, upsample, _stream())
+
     def _run(self, mode, pts=None, rays=None, workspace=None, sdf_out=None):
         """mode 0 -> sdf [P]; mode 1 -> (sdf [P], feat [P,256], normals [P,3]). `rays` = (rays_o, rays_d, z[B,n])."""
         img = self._images()

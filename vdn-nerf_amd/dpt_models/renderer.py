@@ -59,6 +59,12 @@ def extract_geometry(bound_min, bound_max, resolution, threshold, query_func):
 _FUSE_ROUNDS = __import__("os").environ.get("VDN_FUSE_ROUNDS", "1") != "0"      # A/B switch: vdn_merge_upsample vs the two launches
 
 
+def fuse_sdf_rounds():
+    """VDN_FUSE_SDF_ROUNDS=0: the sampler's rounds as two launches each (SDF pass, merge + up-sample) instead of one."""
+    import os
+    return os.environ.get("VDN_FUSE_SDF_ROUNDS", "1") != "0"
+
+
 def bg_compaction():
     """VDN_BG_COMPACT=0 evaluates every background sample as the reference does (A/B switch for the parity tests)."""
     import os
@@ -214,8 +220,13 @@ class NeuSRenderer:
                     m.z, m.new_z, m.z_out = z.data_ptr(), new_z.data_ptr(), z.data_ptr()
                     m.B, m.M, m.K, m.ld, m.ld_out = B, M, n_imp, N, N
                     if not last:
-                        self.sdf_network._run(0, rays=(rays_o, rays_d, new_z), sdf_out=new_sdf)         # renderer.py:201
                         m.sdf, m.new_sdf, m.sdf_out = sdf.data_ptr(), new_sdf.data_ptr(), sdf.data_ptr()
+                        # the whole round in one launch where the kernel covers the shape (bf16, 16 new samples per ray)
+                        if _FUSE_ROUNDS and fuse_sdf_rounds() and self.sdf_network._run_round(
+                                (rays_o, rays_d, new_z), new_sdf, m, upsample_args(i + 1, M + n_imp)):
+                            M += n_imp
+                            continue
+                        self.sdf_network._run(0, rays=(rays_o, rays_d, new_z), sdf_out=new_sdf)         # renderer.py:201
                         # cat_z_vals of this round + up_sample of the next one (renderer.py:372-386) in one launch: the new
                         # samples of round i are read before those of round i+1 are written over them
                         if _FUSE_ROUNDS:

@@ -108,6 +108,18 @@ def call(fn_name, *args):
         raise VdnError("%s failed with status %d (%s)" % (fn_name, rc, "argument error" if rc < 0 else "hipError_t"))
 
 
+def try_call(fn_name, *args, unsupported=-10):
+    """call() for an entry point that may decline a shape: False (nothing launched) on the status `unsupported`."""
+    lib = load()
+    cargs = [ctypes.byref(a) if isinstance(a, ctypes.Structure) else a for a in args]
+    rc = getattr(lib, fn_name)(*cargs)
+    if rc == unsupported:
+        return False
+    if rc != 0:
+        raise VdnError("%s failed with status %d (%s)" % (fn_name, rc, "argument error" if rc < 0 else "hipError_t"))
+    return True
+
+
 def call_value(fn_name, *args):
     """Invoke an entry point whose int return is a value, not a status (vdn_abi_version, vdn_dw_entry_wgs_*)."""
     return int(getattr(load(), fn_name)(*args))
