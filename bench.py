@@ -333,7 +333,7 @@ def main():
                 head.rend.render(*head.batches[i][:4], background_rgb=bg, cos_anneal_ratio=0.5)
             head.fence()
             t1 = time.time()
-            nf = max(10, K)
+            nf = max(100, K)
             for i in range(nf):
                 head.rend.render(*head.batches[i % nb][:4], background_rgb=bg, cos_anneal_ratio=0.5)
             head.fence()

@@ -189,6 +189,10 @@ class NeuSRenderer:
             a.lin_outside, a.out_lower, a.out_upper = (c[k].data_ptr() for k in ("lin_outside", "out_lower", "out_upper"))
             a.z_out = z_out.data_ptr()
         if perturb > 0:
+            if t_rand is None and t_rand_out is None and O > 0:
+                # the two uniform draws of renderer.py:348,355 from one generator call (a launch less per batch)
+                u = torch.rand(B * (1 + O), device=dev)
+                t_rand, t_rand_out = u[:B].view(B, 1), u[B:].view(B, O)
             if t_rand is None:
                 t_rand = torch.rand([B, 1], device=dev)                  # renderer.py:348
             a.t_rand = t_rand.data_ptr()
@@ -281,9 +285,12 @@ class NeuSRenderer:
             raise ValueError("empty ray batch")
         st = _stream()
 
-        z, z_out = self._sample(rays_o, rays_d, near, far, perturb, t_rand, t_rand_out, z_vals_inject)
         params = self._all_parameters()
-        if torch.is_grad_enabled() and (attached is not None or any(p.requires_grad for p in params)):
+        differentiable = torch.is_grad_enabled() and (attached is not None or any(p.requires_grad for p in params))
+        # inference with the background work list: the last round's merge rides in vdn_train_prep (as in the training engine)
+        defer = (not differentiable) and O > 0 and bg_compaction()
+        z, z_out = self._sample(rays_o, rays_d, near, far, perturb, t_rand, t_rand_out, z_vals_inject, defer_last_merge=defer)
+        if differentiable:
             if attached is not None:
                 rays_o, rays_d, z, z_out = self._attach_rays(attached, near, far, z, z_out)
             return self._render_train(rays_o, rays_d, z, z_out, background_rgb, cos_anneal_ratio, params)
@@ -300,6 +307,8 @@ class NeuSRenderer:
             tp.B, tp.N, tp.T, tp.z_ld, tp.sample_dist, tp.fg_radius = B, N, T, z.stride(0), sample_dist, 1.2
             tp.dists, tp.mid_z, tp.bg_dists, tp.bg_mid = (t.data_ptr() for t in (dists, mid_z, bg_dists, bg_mid))
             tp.bg_active_idx, tp.bg_n_active, tp.bg_ray_counts = (t.data_ptr() for t in active3)
+            if self._pending_merge is not None:
+                tp.new_z, tp.M_old = self._pending_merge[0].data_ptr(), self._pending_merge[1]
             lib.call("vdn_train_prep", tp, st)
             bg_density, bg_rgb, bg_feat = self.nerf._run(rays=(rays_o, rays_d, bg_mid), active=active3[:2])
         else:

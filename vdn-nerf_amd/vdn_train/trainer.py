@@ -147,8 +147,7 @@ class Trainer:
         true_rgb = packed(true_rgb, (B, 3), "true_rgb")
         gt_feats, mask = packed(gt_feats, (B, 96), "gt_feats"), packed(mask, (B, 1), "mask")
         if r.perturb > 0 and t_rand is None and t_rand_out is None and z_vals_inject is None and r.n_outside > 0:
-            # the two uniform draws of renderer.py:348,355 from one generator call (a launch less per step; render() itself
-            # keeps the reference's two calls)
+            # the two uniform draws of renderer.py:348,355 from one generator call (a launch less per step), as render() draws them
             u = torch.rand(B * (1 + r.n_outside), device=self.dev)
             t_rand, t_rand_out = u[:B].view(B, 1), u[B:].view(B, r.n_outside)
         with torch.no_grad():
