@@ -338,6 +338,18 @@ def main():
                 head.rend.render(*head.batches[i % nb][:4], background_rgb=bg, cos_anneal_ratio=0.5)
             head.fence()
             extras["forward_only_rays_per_s"] = world * args.batch * nf / (time.time() - t1)
+            # the image loops may hand render() any batch size: 4 of the resident batches at once
+            if nb >= 4:
+                big = [torch.cat([head.batches[(4 * j + k) % nb][c] for k in range(4)]) for j in range(2) for c in range(4)]
+                big = [big[0:4], big[4:8]]
+                for i in range(2):
+                    head.rend.render(*big[i], background_rgb=bg, cos_anneal_ratio=0.5)
+                head.fence()
+                t1 = time.time()
+                for i in range(nf // 2):
+                    head.rend.render(*big[i % 2], background_rgb=bg, cos_anneal_ratio=0.5)
+                head.fence()
+                extras["forward_only_rays_per_s_batch_%d" % (4 * args.batch)] = world * 4 * args.batch * (nf // 2) / (time.time() - t1)
     roof = roof_dw = None
     if not args.no_roofline:
         roof = head.sdf_kernel_roofline()           # every rank takes part (steps hold collectives); rank 0 gets the numbers

@@ -224,6 +224,10 @@ int vdn_merge_upsample(const VdnMergeArgs* merge_host, const VdnUpsampleArgs* up
  * 32-point workgroup of the small-pass kernel is two rays, whose waves go on to merge and up-sample their rows. Same results
  * as the two calls, bit for bit. Covers 16 new samples per ray, no work list; returns -10 for any other shape (the caller
  * then makes the two calls). */
+/* vdn_sdf_mlp_fwd_bf16(mode 0) on the coarse samples (ray form, 64 per ray: renderer.py:369-370) followed by
+ * vdn_upsample_round on those rows (upsample.M = 64; its z / sdf / ld are ignored: the rows are handed over on chip), in one
+ * launch. Same results as the two calls, bit for bit; -10 for any other shape. */
+int vdn_sdf_upsample_bf16(const VdnSdfArgs* sdf_host, const VdnUpsampleArgs* upsample_host, void* stream);
 int vdn_sdf_merge_upsample_bf16(const VdnSdfArgs* sdf_host, const VdnMergeArgs* merge_host, const VdnUpsampleArgs* upsample_host, void* stream);
 
 /* renderer.py:228-230 / 107-109: dists = diff(z) with last = sample_dist; mid_z = z + dists/2. */

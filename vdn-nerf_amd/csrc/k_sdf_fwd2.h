@@ -23,6 +23,7 @@
 // same chunk order as the first kernel's streams.
 #pragma once
 #include <cstdlib>
+#include "k_ray_rows.h"
 #include "mlp_engine.h"
 #include "vdn_kernels.h"
 
@@ -338,8 +339,12 @@ constexpr int pair_begin(int gi, int GA) { return gi >= GA ? 8 : gi * 8 / GA; }
 // MODE 0: sdf only (sampler passes, 2 waves / SIMD). MODE 1: sdf + feature + normals, softplus' on chip (1 wave / SIMD);
 // SAVE adds the training saves (H in scaled units g = 100 log2(e) h, V, PE).
 // (VID only gives the development harness's co-linked tuning variants distinct symbols)
-template <int MODE, bool SAVE, int NSLOT, int DEPTH, int VID = 0>
-__global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kernel(SdfArgs a) {
+// UPS (MODE 0, ray form with 64 samples per ray): the first up-sampling round (renderer.py:147-191 on the coarse samples)
+// behind the pass - a 128-point workgroup is two rays, whose z / sdf rows go through LDS to upsample_row (k_ray_rows.h),
+// vdn_upsample_round's work without its launch.
+template <int MODE, bool SAVE, int NSLOT, int DEPTH, int VID = 0, bool UPS = false>
+__global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kernel(SdfArgs a, UpsampleArgs up) {
+    static_assert(!UPS || MODE == 0, "the up-sampling round follows the sdf-only pass");
     using PG = Prog<MODE>;
     using P = BF16;
     using ST = unsigned short;
@@ -367,6 +372,7 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
 
     float xin[3];
     long sdf_idx = pd;
+    float z_keep = 0.0f, sdf_keep = 0.0f;           // UPS: this point's depth and sdf for the up-sampling round
     if (a.pts != nullptr) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) xin[d] = a.pts[pd * 3 + d] * a.scale;
@@ -374,6 +380,7 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
         const long r = pd / a.n_per_ray;
         const long sidx = pd - r * a.n_per_ray;
         const float z = a.z[r * a.z_ld + sidx];
+        z_keep = z;
         sdf_idx = r * a.sdf_ld + sidx;
 #pragma unroll
         for (int d = 0; d < 3; ++d) xin[d] = (a.rays_o[r * 3 + d] + a.rays_d[r * 3 + d] * z) * a.scale;
@@ -617,7 +624,8 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
                 // chunk's bias block (row 0); the MFMA's own bf16 value of the row is not used
                 const float b0 = *reinterpret_cast<const float*>(pp.template slot<C>() + L.kt * 2048);
                 const float dot = sdf_dot + __shfl_xor(sdf_dot, 32);
-                if (ok && h == 0) a.sdf[sdf_idx] = fmaf(dot, 1.0f / kC1, b0) * inv_scale;
+                sdf_keep = fmaf(dot, 1.0f / kC1, b0) * inv_scale;
+                if (ok && h == 0) a.sdf[sdf_idx] = sdf_keep;
             }
             acc_prev = acc_cur;
             if constexpr (sweep_tile) sq_prev = sq_next;
@@ -634,6 +642,20 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
             for (int d = 0; d < 3; ++d) a.normals[pd * 3 + d] = n[d] * a.scale;
         }
     }
+    if constexpr (UPS) {
+        // wave w holds samples 32 (w & 1) .. +31 of ray w >> 1 of this workgroup; the weight ring is free behind the barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        float* rows = reinterpret_cast<float*>(smem) + (pp.wave >> 1) * 3 * kMaxT;
+        if (h == 0) {
+            rows[(pp.wave & 1) * 32 + c] = z_keep;
+            rows[kMaxT + (pp.wave & 1) * 32 + c] = sdf_keep;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int r = blockIdx.x * 2 + (pp.wave >> 1);
+        if ((pp.wave & 1) == 0 && r < up.B) upsample_row(up, r, lane, 64, rows, rows + kMaxT, rows + 2 * kMaxT);
+    }
 #ifdef VDN_SDF2_STAMP
     if (threadIdx.x == 0 && a.PE != nullptr) {
         unsigned long long* o = reinterpret_cast<unsigned long long*>(a.PE) + 8 * blockIdx.x;
@@ -643,11 +665,11 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
 #endif
 }
 
-template <int MODE, bool SAVE, int NSLOT, int DEPTH, int VID = 0>
-int launch(const VdnSdfArgs* args, hipStream_t stream) {
+template <int MODE, bool SAVE, int NSLOT, int DEPTH, int VID = 0, bool UPS = false>
+int launch(const VdnSdfArgs* args, hipStream_t stream, const VdnUpsampleArgs* up = nullptr) {
     constexpr size_t lds_min = MODE == 1 ? 160 * 1024 : NSLOT * kStride;
     constexpr size_t lds_solo = 96 * 1024;          // more than half a CU's LDS: one workgroup per CU
-    static bool once = (allow_big_lds(sdf_fwd2_kernel<MODE, SAVE, NSLOT, DEPTH, VID>, lds_min > lds_solo ? lds_min : lds_solo), true);
+    static bool once = (allow_big_lds(sdf_fwd2_kernel<MODE, SAVE, NSLOT, DEPTH, VID, UPS>, lds_min > lds_solo ? lds_min : lds_solo), true);
     (void)once;
     const int grid = (args->P + kWaves * 32 - 1) / (kWaves * 32);
     // MODE 0 may run two workgroups per CU, but two waves on a SIMD serialise their VALU work (they only hide each other's
@@ -656,7 +678,8 @@ int launch(const VdnSdfArgs* args, hipStream_t stream) {
     // dispatcher already spreads 64 workgroups over 64 CUs; off by default
     static const bool solo = [] { const char* e = getenv("VDN_SDF0_SOLO"); return e != nullptr && e[0] == '1'; }();
     const size_t lds = (MODE == 0 && solo && grid <= 256) ? lds_solo : lds_min;
-    hipLaunchKernelGGL((sdf_fwd2_kernel<MODE, SAVE, NSLOT, DEPTH, VID>), dim3(grid), dim3(kWaves * 64), lds, stream, *args);
+    hipLaunchKernelGGL((sdf_fwd2_kernel<MODE, SAVE, NSLOT, DEPTH, VID, UPS>), dim3(grid), dim3(kWaves * 64), lds, stream, *args,
+                       up != nullptr ? *up : VdnUpsampleArgs{});
     return (int)hipGetLastError();
 }
 

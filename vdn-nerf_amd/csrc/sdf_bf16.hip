@@ -40,3 +40,16 @@ extern "C" int vdn_sdf_merge_upsample_bf16(const VdnSdfArgs* args, const VdnMerg
     if (u->B != m->B || u->M != m->M + m->K || u->weights || !u->rays_o || !u->rays_d || !u->u || !u->new_z || u->n_imp < 1 || u->n_imp > 64) return -5;
     return vdn::sdf0s::launch<true>(args, stream, m, u);
 }
+
+// The sampler's first pass and first up-sampling round (renderer.py:369-370 + 147-191) in one launch: vdn_sdf_mlp_fwd_bf16
+// (mode 0) on the 64 coarse samples per ray, then vdn_upsample_round on those rows. Same values as the two calls.
+extern "C" int vdn_sdf_upsample_bf16(const VdnSdfArgs* args, const VdnUpsampleArgs* u, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (args == nullptr || u == nullptr || args->P <= 0 || args->blob == nullptr) return -1;
+    if (args->rays_o == nullptr || args->rays_d == nullptr || args->z == nullptr || args->sdf == nullptr) return -2;
+    // covered: ray form, 64 samples per ray = the rows to up-sample (two rays per 128-point workgroup), no work list
+    if (args->pts != nullptr || args->active_idx != nullptr || args->n_per_ray != 64 || u->M != 64 || args->P != (int64_t)u->B * 64 ||
+        args->z_ld < 64 || args->sdf_ld < 64) return -10;
+    if (u->weights || !u->rays_o || !u->rays_d || !u->u || !u->new_z || u->n_imp < 1 || u->n_imp > 64) return -5;
+    return vdn::sdf2::launch<0, false, 4, 3, 0, true>(args, stream, u);
+}

@@ -142,6 +142,20 @@ class SDFNetwork(_HipNet):
         a.blob = img.blobs["sdf"].data_ptr()
         return lib.try_call("vdn_sdf_merge_upsample_bf16", a, merge, upsample, _stream())
 
+    def _run_first(self, rays, sdf_out, upsample):
+        """The sampler's first pass + first up-sampling round in one launch (vdn_sdf_upsample_bf16): `rays` = (rays_o, rays_d,
+        z [B,64] column slice) -> sdf_out [B,64] column slice, then `upsample` (VdnUpsampleArgs, M = 64). False = not covered."""
+        rays_o, rays_d, z = rays
+        if self.precision != "bf16" or z.shape[1] != 64 or z.stride(1) != 1 or sdf_out.stride(1) != 1:
+            return False
+        img = self._images()
+        a = lib.VdnSdfArgs()
+        a.rays_o, a.rays_d, a.z, a.n_per_ray, a.z_ld = rays_o.data_ptr(), rays_d.data_ptr(), z.data_ptr(), 64, z.stride(0)
+        a.P, a.scale, a.sdf, a.sdf_ld = z.shape[0] * 64, float(self.scale), sdf_out.data_ptr(), sdf_out.stride(0)
+        a.w8row = img.weff_view("lin8").data_ptr()
+        a.blob = img.blobs["sdf"].data_ptr()
+        return lib.try_call("vdn_sdf_upsample_bf16", a, upsample, _stream())
+
     def _run(self, mode, pts=None, rays=None, workspace=None, sdf_out=None):
         """mode 0 -> sdf [P]; mode 1 -> (sdf [P], feat [P,256], normals [P,3]). `rays` = (rays_o, rays_d, z[B,n])."""
         img = self._images()

@@ -206,7 +206,6 @@ class NeuSRenderer:
                 z = z_vals_inject.contiguous()
             else:
                 sdf = torch.empty(B, N, dtype=torch.float32, device=dev)
-                self.sdf_network._run(0, rays=(rays_o, rays_d, z[:, :S]), sdf_out=sdf[:, :S])   # renderer.py:369-370
                 n_imp = I // self.up_sample_steps
                 new_z = torch.empty(B, n_imp, dtype=torch.float32, device=dev)
                 new_sdf = torch.empty(B, n_imp, dtype=torch.float32, device=dev)
@@ -217,7 +216,10 @@ class NeuSRenderer:
                     u.rays_o, u.rays_d, u.z, u.sdf, u.u = (t.data_ptr() for t in (rays_o, rays_d, z, sdf, c["u"]))
                     u.new_z, u.inv_s, u.B, u.M, u.ld, u.n_imp = new_z.data_ptr(), float(64 * 2 ** i), B, M, N, n_imp
                     return u
-                lib.call("vdn_upsample_round", upsample_args(0, M), st)
+                # first pass (renderer.py:369-370) and first round, in one launch where the kernel covers the shape
+                if not (_FUSE_ROUNDS and fuse_sdf_rounds() and self.sdf_network._run_first((rays_o, rays_d, z[:, :S]), sdf[:, :S], upsample_args(0, M))):
+                    self.sdf_network._run(0, rays=(rays_o, rays_d, z[:, :S]), sdf_out=sdf[:, :S])
+                    lib.call("vdn_upsample_round", upsample_args(0, M), st)
                 for i in range(self.up_sample_steps):
                     last = (i + 1 == self.up_sample_steps)
                     m = lib.VdnMergeArgs()
