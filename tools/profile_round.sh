@@ -22,7 +22,7 @@ find gpurun_out/${R}_trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {
 find gpurun_out/${R}_trace -name "*kernel_trace.csv" | head -1 | xargs -I{} python3 tools/steady_stats.py {} 0.3 > gpurun_out/${R}_train_bf16_kernel_stats.csv
 rm -rf gpurun_out/${R}_trace
 # the same with both streams in use (the default schedule): kernels overlap, their durations inflate each other
-unset VDN_SIDE_STREAM
+unset VDN_SIDE_STREAM VDN_OVERLAP
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${R}_trace2 -- python3 bench.py --headline-only --no-cpu-baseline --no-roofline --steps 20 > gpurun_out/${R}_trace2_bench.json 2> gpurun_out/${R}_trace2.log
 find gpurun_out/${R}_trace2 -name "*kernel_trace.csv" | head -1 | xargs -I{} python3 tools/steady_stats.py {} 0.3 > gpurun_out/${R}_train_bf16_kernel_stats_two_streams.csv
 rm -rf gpurun_out/${R}_trace2
