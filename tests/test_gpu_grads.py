@@ -522,3 +522,50 @@ def test_pipelined_sdf_backward_equals_the_three_kernel_path(monkeypatch, B, ski
         assert (a - b).abs().max().item() <= 5e-3 * scale + 1e-12, (i, tuple(a.shape), (a - b).abs().max().item(), scale)
     cos = torch.nn.functional.cosine_similarity(g0, g1, dim=0).item()
     assert cos > 0.99999, cos
+
+
+@pytest.mark.parametrize("B,skip_far", [(512, True), (96, True), (37, False)])
+def test_one_launch_sdf_backward_equals_rbar_then_fbar(monkeypatch, B, skip_far):
+    """bf16 path: vdn_sdf_bwd_split_bf16 (both adjoint chains of the SDF network in one feature-split launch, the second-order
+    term ex_l kept in the wave that produced it; csrc/k_sdf_bwd_split.h) against vdn_sdf_bwd_rbar_bf16 + vdn_sdf_bwd_fbar_bf16 on
+    the same forward state: the planes the weight-gradient GEMM reads (UB, AB) and every parameter gradient, bit for bit; full
+    batch with work lists, a ragged batch, a batch with every sample evaluated."""
+    from vdn_train import synth, factory
+    from vdn_hip.train import TrainEngine
+    from vdn_hip import layout
+    dev = torch.device("cuda:0")
+    seed = 33
+    st = synth.make_all_states(seed, wdepth=False)
+    cams = synth.make_cameras(seed)
+    o, d = synth.random_pixel_batch(seed, 0, 3, B, cams=cams)
+    near, far = synth.near_far_from_sphere(o, d)
+    t1, t2 = synth.jitter(seed, 0, B)
+    o, d, near, far, t1, t2 = (g(x, dev) for x in (o, d, near, far, t1, t2))
+    g_color = g(synth.uniform(seed, "split/gc", (B, 3)) - 0.5, dev)
+    g_eik = torch.tensor([0.1], device=dev)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("VDN_SDF_BWD_SPLIT", mode)
+        rend = factory.build_renderer(device=dev, states=st, precision="bf16")
+        eng = TrainEngine(rend, B, dev)
+        with torch.no_grad():
+            z, z_out = rend._sample(o, d, near.reshape(B), far.reshape(B), 1.0, t1, t2, None)
+        eng.forward(o, d, z.contiguous(), z_out, torch.ones(3, device=dev), 0.3, skip_far=skip_far)
+        eng.backward(g_color, None, None, g_eik)
+        torch.cuda.synchronize()
+        res[mode] = (eng.grad_flat.clone(), {k: eng.w[k].clone() for k in ("UB", "AB")}, int(eng.w["fg_active"][1].item()), eng.Pp)
+    (g0, p0, n0, Pp), (g1, p1, n1, _) = res["0"], res["1"]
+    assert n0 == n1 and (n0 < B * 128) == skip_far
+    off = 0
+    for l, cols in enumerate((64, 256, 256, 256, 288, 256, 256, 256, 256)):
+        nc = 224 if l == 4 else cols                # (ub_4's h part is 7 tiles; its PE part sits in columns 224..287)
+        a, b = (layout.from_pt32(p["UB"][off:off + Pp * cols], Pp, cols)[:n0] for p in (p0, p1))
+        assert torch.equal(a, b), ("UB", l, (a.float() - b.float()).abs().max().item())
+        off += Pp * cols
+    off = 0
+    for l, cols in [(8, 288)] + [(k, 256) for k in range(7, -1, -1)]:
+        nc = 224 if l == 3 else cols
+        a, b = (layout.from_pt32(p["AB"][off:off + Pp * cols], Pp, cols)[:n0, :nc] for p in (p0, p1))
+        assert torch.equal(a, b), ("AB", l, (a.float() - b.float()).abs().max().item())
+        off += Pp * cols
+    assert torch.equal(g0, g1) and torch.isfinite(g0).all()
