@@ -479,6 +479,7 @@ def test_pipelined_sdf_backward_equals_the_three_kernel_path(monkeypatch, B, ski
     g_color = g(synth.uniform(seed, "pipe/gc", (B, 3)) - 0.5, dev)
     g_eik = torch.tensor([0.1], device=dev)
     res = {}
+    monkeypatch.setenv("VDN_SDF_BWD_SPLIT", "0")        # the reference arm is the three-kernel path (it writes the EX planes)
     for mode in ("0", "1"):
         monkeypatch.setenv("VDN_SDF_PIPE", mode)
         rend = factory.build_renderer(device=dev, states=st, precision="bf16")
