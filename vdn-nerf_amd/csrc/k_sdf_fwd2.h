@@ -5,7 +5,7 @@
 // of VALU, LDS-read and DMA issue), and its softplus' round trip through HBM was 17x its boundary I/O. Hence:
 //
 //  * softplus'(a_l) of all 8 hidden layers never leaves the chip: 8-bit fixed point (255 sigma; exact at the saturated
-//    values 0 and 1 that Softplus(beta=100) produces almost everywhere), the first tiles in LDS, the rest in registers.
+//    values 0 and 1; on the bench scene 4-5 % of the hidden activations are that far out, tools/dev/saturation.py), the first tiles in LDS, the rest in registers.
 //    That needs the whole register file: 1 wave per SIMD, 4 waves = 128 points per CU.
 //  * activations are carried in units of 1/(100 log2 e):  t = 100 log2(e) a,  g = 100 log2(e) softplus(a) =
 //    max(t, 0) + log2(1 + 2^-|t|),  sigma(100 a) = 1 - 2^-g.  Hidden-layer weights are unchanged by this
