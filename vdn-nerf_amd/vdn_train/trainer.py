@@ -101,6 +101,7 @@ class Trainer:
         self.overlap = (os.environ.get("VDN_OVERLAP", "1") != "0") if overlap is None else bool(overlap)
         self._ev_gemm, self._ev_rest, self._ev_tail = (torch.cuda.Event() for _ in range(3))
         self._rest_pending = False
+        self._jitter, self._jitter_next = None, 0
         self.engine.join_hook = self.join
         self._eik_global = torch.zeros(3, dtype=torch.float32, device=self.dev)
         self._eik_partial = torch.zeros(batch_size, 2, dtype=torch.float32, device=self.dev)
@@ -147,8 +148,12 @@ class Trainer:
         true_rgb = packed(true_rgb, (B, 3), "true_rgb")
         gt_feats, mask = packed(gt_feats, (B, 96), "gt_feats"), packed(mask, (B, 1), "mask")
         if r.perturb > 0 and t_rand is None and t_rand_out is None and z_vals_inject is None and r.n_outside > 0:
-            # the two uniform draws of renderer.py:348,355 from one generator call (a launch less per step), as render() draws them
-            u = torch.rand(B * (1 + r.n_outside), device=self.dev)
+            # the two uniform draws of renderer.py:348,355: one generator call covers the next 32 steps (the 5-us launch of a
+            # per-step draw sits on the critical path in front of the sampler)
+            if self._jitter is None or self._jitter_next >= self._jitter.shape[0]:
+                self._jitter, self._jitter_next = torch.rand(32, B * (1 + r.n_outside), device=self.dev), 0
+            u = self._jitter[self._jitter_next]
+            self._jitter_next += 1
             t_rand, t_rand_out = u[:B].view(B, 1), u[B:].view(B, r.n_outside)
         with torch.no_grad():
             # (the sampler only reads the SDF weight images: it runs beside the previous step's side-stream half)
