@@ -102,6 +102,9 @@ class Trainer:
         self._ev_gemm, self._ev_rest, self._ev_tail = (torch.cuda.Event() for _ in range(3))
         self._rest_pending = False
         self._jitter, self._jitter_next = None, 0
+        self._main = None
+        if self.overlap and self.engine._side is not None and os.environ.get("VDN_MAIN_PRIORITY", "1") != "0":
+            self._main = torch.cuda.Stream(device=self.dev, priority=-1)
         self.engine.join_hook = self.join
         self._eik_global = torch.zeros(3, dtype=torch.float32, device=self.dev)
         self._eik_partial = torch.zeros(batch_size, 2, dtype=torch.float32, device=self.dev)
@@ -129,8 +132,27 @@ class Trainer:
         return 1.0 / (math.exp(-10 * (self.depth_iter / total_iter - 0.5)) + 1.0)
 
     # ---- one iteration of dpt_runner.py:197-259
-    def train_step(self, rays_o, rays_d, near, far, true_rgb, gt_feats=None, mask=None, t_rand=None, t_rand_out=None,
-                   z_vals_inject=None):
+    def train_step(self, *args, **kwargs):
+        """One iteration (dpt_runner.py:197-259) -> device tensor [loss, color_loss, psnr, eikonal, depth_loss, mask_loss].
+        Arguments: rays_o, rays_d, near, far, true_rgb, gt_feats=None, mask=None, t_rand=None, t_rand_out=None, z_vals_inject=None.
+
+        With the two-stream schedule the step's critical chain (sampler -> SDF forward / backward -> SDF update) is issued on a
+        HIGH-PRIORITY stream of the Trainer's own, ordered behind the caller's stream at entry and in front of it at exit: when a
+        CU frees up, the dispatcher then prefers the chain's workgroups to those of the side stream's background-network and
+        weight-gradient kernels, which have slack (same-box A/B over 6 x 400 steps: -15 .. -40 us per step; VDN_MAIN_PRIORITY=0:
+        the caller's stream)."""
+        main = self._main
+        caller = torch.cuda.current_stream()
+        if main is None or caller == main:
+            return self._train_step(*args, **kwargs)
+        main.wait_stream(caller)
+        with torch.cuda.stream(main):
+            out = self._train_step(*args, **kwargs)
+        caller.wait_stream(main)
+        return out
+
+    def _train_step(self, rays_o, rays_d, near, far, true_rgb, gt_feats=None, mask=None, t_rand=None, t_rand_out=None,
+                    z_vals_inject=None):
         r, eng, st = self.r, self.engine, _stream()
         B = self.B
         # the kernels take raw pointers: packed float32 rows on this device, exactly B of them. The reference's flow slices
