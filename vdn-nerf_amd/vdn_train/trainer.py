@@ -103,7 +103,7 @@ class Trainer:
         self._rest_pending = False
         self._jitter, self._jitter_next = None, 0
         self._main = None
-        if self.overlap and self.engine._side is not None and os.environ.get("VDN_MAIN_PRIORITY", "1") != "0":
+        if self.overlap and self.engine._side is not None and os.environ.get("VDN_MAIN_PRIORITY", "0") == "1":
             self._main = torch.cuda.Stream(device=self.dev, priority=-1)
         self.engine.join_hook = self.join
         self._eik_global = torch.zeros(3, dtype=torch.float32, device=self.dev)
@@ -136,11 +136,12 @@ class Trainer:
         """One iteration (dpt_runner.py:197-259) -> device tensor [loss, color_loss, psnr, eikonal, depth_loss, mask_loss].
         Arguments: rays_o, rays_d, near, far, true_rgb, gt_feats=None, mask=None, t_rand=None, t_rand_out=None, z_vals_inject=None.
 
-        With the two-stream schedule the step's critical chain (sampler -> SDF forward / backward -> SDF update) is issued on a
+        VDN_MAIN_PRIORITY=1 (off by default) issues the step's critical chain (sampler -> SDF forward / backward -> SDF update) on a
         HIGH-PRIORITY stream of the Trainer's own, ordered behind the caller's stream at entry and in front of it at exit: when a
-        CU frees up, the dispatcher then prefers the chain's workgroups to those of the side stream's background-network and
-        weight-gradient kernels, which have slack (same-box A/B over 6 x 400 steps: -15 .. -40 us per step; VDN_MAIN_PRIORITY=0:
-        the caller's stream)."""
+        CU frees up, the dispatcher then prefers the chain's workgroups to those of the side stream's kernels, which have slack
+        (-15 .. -40 us per step over 6 x 400 steps, -2.5 % on the object-centric scene). Off by default because streams share a
+        few hardware queues: in a process that had created several Trainers, the fourth one's priority stream landed on its side
+        stream's queue and the two halves of the step ran one after the other (1.82 ms instead of 1.57)."""
         main = self._main
         caller = torch.cuda.current_stream()
         if main is None or caller == main:
