@@ -415,7 +415,9 @@ int vdn_sdf_bwd_fbar_f32(const VdnSdfFbarArgs* args_host, void* stream);
 int vdn_sdf_bwd_fbar_bf16(const VdnSdfFbarArgs* args_host, void* stream);   /* bf16-MFMA variant: bf16 chunk blob, bf16 activation workspaces */
 /* Both chains in ONE launch (bf16, no ray gradients: fbar.d_pts must be NULL, else -10): rbar's second-order term ex_l stays
  * in the wave that produced it (csrc/k_sdf_bwd_split.h), rbar.EX / fbar.EX are not touched. UB and AB come out bit-identical to
- * vdn_sdf_bwd_rbar_bf16 followed by vdn_sdf_bwd_fbar_bf16. The two structs must describe the same rows (P, S, s_from_h, work list). */
+ * vdn_sdf_bwd_rbar_bf16 followed by vdn_sdf_bwd_fbar_bf16. The two structs must describe the same rows (P, S, s_from_h, work list).
+ * Planes are addressed with 32-bit byte offsets: batches whose AB plane (rows x 2336 bf16) would exceed 4 GiB (P > 919 296) are
+ * declined with -10 and nothing is launched; callers then run the two kernels. */
 int vdn_sdf_bwd_split_bf16(const VdnSdfRbarArgs* rbar_host, const VdnSdfFbarArgs* fbar_host, void* stream);
 
 /* The same backward (rbar chain, fbar chain and the weight gradients of the SDF network's hidden layers) as ONE persistent

@@ -1,14 +1,31 @@
 """Train the shipped womsk_white configuration on the synthetic 800x800 scene and report loss / PSNR over time
-(the 'PSNR' half of BASELINE.json's metric). Usage: train_psnr.py [steps] [precision]"""
-import os, sys, time, json
+(the 'PSNR vs ref' half of BASELINE.json's metric; dpt_runner.py:230 for the formula).
+
+  train_psnr.py [steps] [precision] [--views N] [--checkpoints K] [--cross] [--out FILE]
+
+Paired runs: the same seed, the same initial weights (torch.manual_seed(0): the reference's geometric init), the same
+pixel stream (keyed by step) and the same schedule for `precision` = fp32 (the exact-f32 kernels, the path that holds
+the 1e-4 parity) and bf16 (the headline path). Validation: N held-out views (never trained on), a 64 x 64 grid of rays
+each, perturb off; per checkpoint the mean and the standard deviation over the views. --cross also renders the
+checkpoint with the OTHER precision's kernels (same weights): separates what training in bf16 costs from what
+rendering in bf16 costs."""
+import argparse, os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vdn-nerf_amd"))
 import numpy as np, torch
 from vdn_train import synth, factory
 from vdn_train.trainer import Trainer
 
-steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
-prec = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+ap = argparse.ArgumentParser()
+ap.add_argument("steps", nargs="?", type=int, default=3000)
+ap.add_argument("precision", nargs="?", default="bf16")
+ap.add_argument("--views", type=int, default=8)
+ap.add_argument("--checkpoints", type=int, default=10)
+ap.add_argument("--cross", action="store_true")
+ap.add_argument("--out", default=None)
+ap.add_argument("--grid", type=int, default=64)
+args = ap.parse_args()
+steps, prec = args.steps, args.precision
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 B, seed = 512, 0
@@ -16,40 +33,79 @@ B, seed = 512, 0
 rend = factory.build_renderer(device=dev, precision=prec)
 # shortened schedule so that a few thousand steps cover warm-up and annealing
 tr = Trainer(rend, B, dev, conf=dict(warm_up_end=200, end_iter=steps, anneal_end=max(steps // 4, 1)))
+other = None
+if args.cross:
+    oprec = "fp32" if prec == "bf16" else "bf16"
+    other = factory.build_renderer(device=dev, precision=oprec)
 cams = synth.make_cameras(seed)
 g = lambda x: torch.tensor(x).to(dev)
-# validation rays: a fixed 64x64 grid of one held-out view
-vx, vy = np.meshgrid(np.linspace(190, 610, 64), np.linspace(190, 610, 64))
-vo, vd = synth.pixel_rays(cams[7], vx.reshape(-1), vy.reshape(-1))
-vn, vf = synth.near_far_from_sphere(vo, vd)
 ALBEDO = 0.5
 CROP = 420            # train on the central window where the object covers most pixels (object-centric capture)
-vt = g(synth.target_colors(vo, vd, ALBEDO))
+HELD = [3, 7, 13, 18, 23, 27, 33, 38][:args.views]          # never trained on
+G = args.grid
+vx, vy = np.meshgrid(np.linspace(190, 610, G), np.linspace(190, 610, G))
+val = []
+for v in HELD:
+    vo, vd = synth.pixel_rays(cams[v], vx.reshape(-1), vy.reshape(-1))
+    vn, vf = synth.near_far_from_sphere(vo, vd)
+    val.append([g(vo), g(vd), g(vn), g(vf), g(synth.target_colors(vo, vd, ALBEDO))])
+white = torch.ones(1, 3, device=dev)
 
-def validate():
+
+def psnr_views(r):
+    """PSNR (dpt_runner.py:230 with mask = 1) of every held-out view rendered by renderer r."""
+    res = []
     with torch.no_grad():
-        cols = []
-        for i in range(0, vo.shape[0], 512):
-            out = rend.render(g(vo[i:i + 512]), g(vd[i:i + 512]), g(vn[i:i + 512]), g(vf[i:i + 512]), perturb_overwrite=0,
-                              background_rgb=torch.ones(1, 3, device=dev), cos_anneal_ratio=tr.cos_anneal_ratio())
-            cols.append(out["color_fine"])
-        c = torch.cat(cols)
-        return (20.0 * torch.log10(1.0 / ((c - vt) ** 2).mean().sqrt())).item()
+        for vo, vd, vn, vf, vt in val:
+            cols = [r.render(vo[i:i + 512], vd[i:i + 512], vn[i:i + 512], vf[i:i + 512], perturb_overwrite=0, background_rgb=white,
+                             cos_anneal_ratio=tr.cos_anneal_ratio())["color_fine"] for i in range(0, vo.shape[0], 512)]
+            c = torch.cat(cols)
+            res.append((20.0 * torch.log10(1.0 / ((c - vt) ** 2).mean().sqrt())).item())
+    return res
+
+
+def sync_other():
+    """Copy the trained weights into the other-precision renderer (same modules, other kernels)."""
+    with torch.no_grad():
+        for a, b in ((rend.nerf, other.nerf), (rend.sdf_network, other.sdf_network), (rend.deviation_network, other.deviation_network),
+                     (rend.color_network, other.color_network)):
+            for pa, pb in zip(a.parameters(), b.parameters()):
+                pb.copy_(pa)
+
 
 log = []
+out_f = open(args.out, "w") if args.out else None
 t0 = time.time()
 order = (synth.uniform(seed, "trainperm", (steps,)) * 40).astype(np.int64) % 40
+free = [i for i in range(40) if i not in HELD]
+every = max(steps // args.checkpoints, 1)
 for it in range(steps):
-    img = int(order[it])
-    if img == 7:
-        img = 8                                   # view 7 is held out
+    img = free[int(order[it]) % len(free)]
     o, d = synth.random_pixel_batch(seed, it, img, B, cams=cams, crop=CROP)
     near, far = synth.near_far_from_sphere(o, d)
     sc = tr.train_step(g(o), g(d), g(near), g(far), g(synth.target_colors(o, d, ALBEDO)))
-    if it % max(steps // 10, 1) == 0 or it == steps - 1:
+    if (it + 1) % every == 0 or it == 0 or it == steps - 1:
         s = sc.cpu().numpy()
-        log.append(dict(step=it, loss=float(s[0]), train_psnr=float(s[2]), eikonal=float(s[3]), val_psnr=validate(),
-                        inv_s=float(torch.exp(rend.deviation_network.variance * 10).item()), wall_s=time.time() - t0))
-        print(json.dumps(log[-1]), flush=True)
-print(json.dumps({"precision": prec, "steps": steps, "final_val_psnr": log[-1]["val_psnr"], "final_train_psnr": log[-1]["train_psnr"],
-                  "wall_s": time.time() - t0}))
+        tr.join()                                 # (the networks' own weight-image accessor joins too)
+        pv = psnr_views(rend)
+        rec = dict(step=it + 1, precision=prec, loss=float(s[0]), train_psnr=float(s[2]), eikonal=float(s[3]),
+                   val_psnr_mean=float(np.mean(pv)), val_psnr_sd=float(np.std(pv)), val_psnr_views=[round(x, 3) for x in pv],
+                   inv_s=float(torch.exp(rend.deviation_network.variance * 10).item()), wall_s=time.time() - t0)
+        if other is not None:
+            sync_other()
+            po = psnr_views(other)
+            rec["val_psnr_mean_on_%s_kernels" % oprec] = float(np.mean(po))
+            rec["val_psnr_sd_on_%s_kernels" % oprec] = float(np.std(po))
+        log.append(rec)
+        line = json.dumps(rec)
+        print(line, flush=True)
+        if out_f:
+            out_f.write(line + "\n")
+            out_f.flush()
+last = [r["val_psnr_mean"] for r in log[-3:]]
+summary = {"precision": prec, "steps": steps, "views": HELD, "final_val_psnr_mean": log[-1]["val_psnr_mean"], "final_val_psnr_sd": log[-1]["val_psnr_sd"],
+           "mean_of_last_3_checkpoints": float(np.mean(last)), "final_train_psnr": log[-1]["train_psnr"], "wall_s": time.time() - t0}
+print(json.dumps(summary))
+if out_f:
+    out_f.write(json.dumps(summary) + "\n")
+    out_f.close()

@@ -68,6 +68,12 @@ class _HipNet(nn.Module):
         return torch.float32 if self.precision == "fp32" else torch.bfloat16
 
     def _images(self):
+        # A vdn_train.Trainer updates this network's parameters and weight images on its side stream (raw pointers: torch's
+        # version counters do not move). It leaves a hook here that orders torch's current stream behind that update, so
+        # render() / validate_image right after train_step never read half-rebuilt images. (An event wait; free once done.)
+        hook = self.__dict__.get("_stream_join")
+        if hook is not None:
+            hook()
         dev = next(self.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("%s lives on %s; move it to the MI355X with .to('cuda') (no CPU path)"

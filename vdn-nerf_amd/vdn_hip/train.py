@@ -885,8 +885,6 @@ class TrainEngine:
         # bf16 without ray gradients: both chains in one feature-split launch (csrc/k_sdf_bwd_split.h: ex_l never leaves the chip;
         # 218 us against 165 + 140 at the steady-state lists, the step -43 us). VDN_SDF_BWD_SPLIT=0: the two kernels
         one_launch = self.precision == "bf16" and not rg and os.environ.get("VDN_SDF_BWD_SPLIT", "1") != "0"
-        if not one_launch:
-            lib.call("vdn_sdf_bwd_rbar" + self.sfx, self._fg(rb), st)
         fb = lib.VdnSdfFbarArgs()
         fb.blob = img.blobs["fbar"].data_ptr()
         fb.g_sdf, fb.g_feat, fb.S, fb.EX, fb.AB = w["d_sdf"].data_ptr(), w["d_featvec"].data_ptr(), s_planes.data_ptr(), w["EX"].data_ptr(), w["AB"].data_ptr()
@@ -894,9 +892,9 @@ class TrainEngine:
         if rg:
             fb.rays_o, fb.rays_d, fb.z, fb.n_per_ray, fb.z_ld = rays_o.data_ptr(), rays_d.data_ptr(), w["mid_z"].data_ptr(), self.N, self.N
             fb.g_normals, fb.U_pe, fb.acc_pts, fb.d_pts = w["d_normals"].data_ptr(), w["U_pe"].data_ptr(), 1, w["d_pts"].data_ptr()
-        if one_launch:
-            lib.call("vdn_sdf_bwd_split_bf16", self._fg(rb), self._fg(fb), st)
-        else:
+        # (the one-launch kernel declines batches whose planes exceed its 32-bit buffer offsets: status -10 -> the two kernels)
+        if not (one_launch and lib.try_call("vdn_sdf_bwd_split_bf16", self._fg(rb), self._fg(fb), st)):
+            lib.call("vdn_sdf_bwd_rbar" + self.sfx, self._fg(rb), st)
             lib.call("vdn_sdf_bwd_fbar" + self.sfx, self._fg(fb), st)
 
         if defer_rest:

@@ -39,7 +39,8 @@ class Trainer:
         """collectives: None = on when world_size > 1; True runs the collective calls also in a one-rank group (the RCCL path
         on a single GPU). overlap: None = on (VDN_OVERLAP=0 turns it off) - see the module docstring; after train_step the
         colour / VDN / background parameters and gradients are then complete on the side stream: join() before touching them
-        (state_dict, load_checkpoint and TrainEngine.param_grads do)."""
+        (state_dict, load_checkpoint, TrainEngine.param_grads and the networks' own weight-image accessor do: render(),
+        validate_image ... right after train_step are ordered behind the update without an explicit join())."""
         self.r, self.B, self.dev = renderer, batch_size, torch.device(device)
         self.conf = dict(DEFAULT_TRAIN_CONF)
         self.conf.update(conf or {})
@@ -106,6 +107,13 @@ class Trainer:
         if self.overlap and self.engine._side is not None and os.environ.get("VDN_MAIN_PRIORITY", "0") == "1":
             self._main = torch.cuda.Stream(device=self.dev, priority=-1)
         self.engine.join_hook = self.join
+        # the networks this Trainer updates on its side stream wait for that update whenever their weight images are used
+        # (dpt_models/fields.py::_HipNet._images): rendering with the renderer right after train_step needs no explicit join().
+        # The SDF network and the variance are updated on the caller's stream and need none (the next step's sampler runs on
+        # them beside the side-stream half).
+        for m in (renderer.nerf, renderer.color_network, renderer.depth_network):
+            if m is not None:
+                m.__dict__["_stream_join"] = self.join
         self._eik_global = torch.zeros(3, dtype=torch.float32, device=self.dev)
         self._eik_partial = torch.zeros(batch_size, 2, dtype=torch.float32, device=self.dev)
         self._eik_handles = []
@@ -299,9 +307,11 @@ class Trainer:
         """Order torch's current stream behind the side-stream half of the last step (colour / VDN / background gradients,
         their Adam step and weight images). train_step calls it before its forward; call it before reading those parameters
         or rendering with the renderer outside the Trainer."""
+        # `_rest_pending` = a side-stream half has ever been issued. The wait is repeated on every call, on whatever stream is
+        # current: waiting for an event that has completed costs nothing, and a flag cleared by a wait on one stream would
+        # leave a step issued on another stream unordered.
         if self._rest_pending:
             torch.cuda.current_stream().wait_event(self._ev_rest)
-            self._rest_pending = False
 
     def _eikonal_begin(self, eng):
         """Right behind the fused SDF kernel: this rank's eikonal sums (vdn_eikonal_terms: the compositor's own expressions) and
