@@ -58,45 +58,100 @@ def time_kernel(fn, iters=10):
     return float(np.mean([a.elapsed_time(b) for a, b in zip(e0, e1)])) * 1e-3
 
 
-def cpu_baseline(B, seed, wdepth=False, max_seconds=30.0):
-    """The oracle's training step (render forward + loss + autograd backward) on the host cores: a bounded sample of the same
-    workload - half a batch (256 rays x (64+64+32) samples) per iteration, as many iterations as fit in ~30 s after a small
-    warm-up - reported in rays/s. Adam is excluded (negligible against a multi-second step)."""
+def physical_cores():
+    """Physical cores of this host: unique (physical id, core id) pairs of /proc/cpuinfo; os.cpu_count() where that fails."""
+    try:
+        pairs, phys = set(), None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                phys = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                pairs.add((phys, ln.split(":")[1].strip()))
+        if pairs:
+            return len(pairs)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
+def cpu_baseline(B, seed, wdepth=False, full=False, budget_s=75.0):
+    """The oracle (CPU restatement of the reference, verified equal to it: tests/test_oracle_golden.py) on the host cores,
+    SURVEY.md 8d's protocol: batches of B = 512 rays x (64 + 64 + 32) samples, fp32, warm-up iterations first, the MEDIAN of the
+    timed ones; forward only (render) and forward + backward (render + loss + autograd; Adam excluded: negligible against a
+    multi-second step); at the thread count that is fastest on this host AND on all physical cores; plus the C1 reading of
+    BASELINE.json configs[0] (512 rays x 64 samples: n_importance = 0) and the womsk_white_wdepth shapes.
+    `full`: 3 warm-up + 5 timed iterations per figure (minutes of CPU time; --cpu-baseline-full, committed under profiles/).
+    Default: a bounded sample of the same workload (1 warm-up + 3 timed for the headline figure, 1 + 2 / 1 + 1 for the
+    others, within about `budget_s` seconds), so that the default bench run stays within a few minutes."""
     import oracle.neus_oracle as orc
     from vdn_train import synth
-    st = synth.make_all_states(seed, wdepth=wdepth)
     cams = synth.make_cameras(seed)
     tt = torch.tensor
-    nets = orc.nets_from_numpy(st, requires_grad=True)
-    params = [p for _, p in orc.all_params(nets)]
-    # 16 threads: the fastest setting for this oracle on the GPU box's 2 x EPYC host (tests/probes/cpu_threads.py: 8 -> 106,
-    # 16 -> 120, 32 -> 102, 64 -> 62, 128 -> 27 rays/s); more threads only add synchronisation on these tensor sizes
     prev_threads = torch.get_num_threads()
-    cores = min(int(os.environ.get("VDN_CPU_THREADS", "16")), os.cpu_count() or 1)
-    torch.set_num_threads(cores)
+    phys = physical_cores()
+    # the fastest setting for this oracle on the GPU box's 2 x EPYC host (tests/probes/cpu_threads.py: 8 -> 106, 16 -> 120,
+    # 32 -> 102, 64 -> 62, 128 -> 27 rays/s): more threads only add synchronisation on these tensor sizes
+    best = min(int(os.environ.get("VDN_CPU_THREADS", "16")), os.cpu_count() or 1)
+    t_begin = time.time()
+    nets_cache = {}
 
-    def one(n, step):
+    def nets_of(wd):
+        if wd not in nets_cache:
+            nets_cache[wd] = orc.nets_from_numpy(synth.make_all_states(seed, wdepth=wd), requires_grad=True)
+        return nets_cache[wd]
+
+    def one(n, step, wd, backward, conf):
+        nets = nets_of(wd)
         o, d = synth.random_pixel_batch(seed, step, 0, n, cams=cams)
         near, far = synth.near_far_from_sphere(o, d)
         t1, t2 = synth.jitter(seed, step, n)
-        lkw = dict(gt_feats=tt(synth.uniform(seed, "bench/feats", (n, 96)).astype(np.float32)), depth_ramp=0.5) if wdepth else {}
-        out = orc.render(nets, tt(o), tt(d), tt(near), tt(far), background_rgb=torch.ones(1, 3), cos_anneal_ratio=0.5,
-                         t_rand=tt(t1), t_rand_out=tt(t2))
+        kw = dict(background_rgb=torch.ones(1, 3), cos_anneal_ratio=0.5, t_rand=tt(t1), t_rand_out=tt(t2), conf=conf)
+        if not backward:
+            with torch.no_grad():        # (the oracle's SDF gradient is analytic: no autograd needed for the forward)
+                orc.render(nets, tt(o), tt(d), tt(near), tt(far), **kw)
+            return
+        out = orc.render(nets, tt(o), tt(d), tt(near), tt(far), **kw)
+        lkw = dict(gt_feats=tt(synth.uniform(seed, "bench/feats", (n, 96)).astype(np.float32)), depth_ramp=0.5) if wd else {}
         lo = orc.loss_from_render(out, tt(synth.target_colors(o, d)), **lkw)
-        torch.autograd.grad(lo["loss"], params, allow_unused=True)
+        torch.autograd.grad(lo["loss"], [p for _, p in orc.all_params(nets)], allow_unused=True)
 
-    one(32, 0)                                  # warm-up: thread pool, allocator
-    n = max(1, B // 2)
-    times, t_begin = [], time.time()
-    while not times or (time.time() - t_begin + float(np.mean(times)) < max_seconds and len(times) < 5):
-        t = time.time()
-        one(n, 1 + len(times))
-        times.append(time.time() - t)
-    med = float(np.median(times))
+    def figure(threads, wd, backward, conf, warm, timed):
+        torch.set_num_threads(threads)
+        for i in range(warm):
+            one(B, i, wd, backward, conf)
+        ts = []
+        for i in range(timed):
+            t = time.time()
+            one(B, warm + i, wd, backward, conf)
+            ts.append(time.time() - t)
+        return {"rays_per_s": B / float(np.median(ts)), "s_per_batch_median": float(np.median(ts)), "threads": threads,
+                "warmup": warm, "timed": timed}
+
+    C3 = orc.RendererConf()                                  # 64 coarse + 64 importance + 32 outside, as shipped
+    C1 = orc.RendererConf(n_importance=0)                    # BASELINE.json configs[0] reading: 512 rays x 64 samples
+    torch.set_num_threads(best)
+    one(32, 0, wdepth, True, C3)                             # thread pool, allocator (cold first call)
+    w5 = (3, 5) if full else None
+    out = {}
+    out["fwd_bwd"] = figure(best, wdepth, True, C3, *(w5 or (1, 3)))
+    out["fwd_only"] = figure(best, wdepth, False, C3, *(w5 or (1, 2)))
+    left = lambda: budget_s - (time.time() - t_begin)
+    if full or left() > 12:
+        out["c1_64_samples_fwd_bwd"] = figure(best, wdepth, True, C1, *(w5 or (0, 1)))
+    if (full or left() > 12) and not wdepth:
+        out["wdepth_fwd_bwd"] = figure(best, True, True, C3, *(w5 or (0, 1)))
+    if phys != best and (full or left() > 0.6 * B / 25.0):    # all physical cores: ~25 rays/s on the GPU host => ~20 s per batch
+        out["all_physical_cores_fwd_bwd"] = figure(phys, wdepth, True, C3, *(w5 or (0, 1)))
     torch.set_num_threads(prev_threads)
-    return {"value": n / med, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": "%d x (render forward + loss + backward) of %d rays (64+64+32 samples each), oracle fp32 on %d threads, "
-                      "median; %.0f s of CPU work" % (len(times), n, cores, sum(times))}
+    spent = time.time() - t_begin
+    return {"value": out["fwd_bwd"]["rays_per_s"], "unit": "rays/s", "cores": best, "kind": "port",
+            "physical_cores": phys, "logical_cpus": os.cpu_count(),
+            "sample": "oracle fp32, batches of %d rays x (64+64+32) samples: render + loss + autograd backward, median of %d timed "
+                      "batches after %d warm-up on %d threads (the fastest thread count on this host; `all_physical_cores_fwd_bwd` "
+                      "= the same on all %d physical cores); %.0f s of CPU work in all%s"
+                      % (B, out["fwd_bwd"]["timed"], out["fwd_bwd"]["warmup"], best, phys, spent,
+                         "" if full else " (bounded sample of SURVEY.md 8d's 3 + 5 protocol: --cpu-baseline-full runs all of it)"),
+            "figures": out}
 
 
 def spawn_ranks(n):
@@ -274,6 +329,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="SURVEY.md 8d's whole CPU protocol (3 warm-up + 5 timed batches of "
+                    "512 rays per figure: minutes of CPU time) instead of the bounded sample")
     ap.add_argument("--headline-only", action="store_true", help="only the headline leg: keeps a rocprof trace of this command to one "
                     "population of launches per kernel (no all-samples / fp32 / wdepth legs, no forward-only renders)")
     ap.add_argument("--no-all-samples", action="store_true", help="skip the leg with the zero-weight work lists off")
@@ -317,6 +374,15 @@ def main():
     head = Leg(args, dev, world, rank, args.precision, wdepth, nb, crop=args.crop)
     res = head.measure(W, K)
     extras = {}
+    if world > 1:
+        # K more steps with HIP events around every collective's wait (dp.Collectives.finish): how long each stream actually
+        # stood waiting for RCCL - the EXPOSED part of the eikonal reduce and of the three gradient slices - per step, rank 0's
+        # view. (Kept out of the timed regions above: `value` carries no event records.)
+        head.trainer.coll.timing = True
+        head.region(W + K, K)
+        head.trainer.coll.timing = False
+        extras["allreduce_exposed_ms"] = dict(head.trainer.coll.exposed_ms(), note="per call: stream wait bracketed by HIP events; "
+                                              "grad_sdf and eikonal sit on the critical path, grad_nerf / grad_heads on the side stream")
     if not args.headline_only:
         # The same K steps with every sample evaluated, as the reference does: the default path skips samples that enter the loss
         # only through exact zeros ("Work lists") - identical results, reported side by side for transparency.
@@ -415,7 +481,7 @@ def main():
         }
         line.update(extras)
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args.batch, 0, wdepth)
+            line["cpu_baseline"] = cpu_baseline(args.batch, 0, wdepth, full=args.cpu_baseline_full)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

@@ -391,6 +391,91 @@ def raygrad_fixture(fields, renderer):
     return fx
 
 
+def rays_fixture():
+    """The reference's own ray source - RaysGenerator (poses.py:96-252) and Dataset.near_far_from_sphere (dataset.py:111-118) -
+    run on CPU: `cv2` (absent here) is a stub whose imread() hands back injected arrays, the `.cuda()` at the end of
+    gen_random_rays_at / gen_rays_between (poses.py:212, 248-249) is the identity while the generator runs, torch.randint is
+    seeded and its draws are recorded. Both constructor branches (RGBA images composited on white, poses.py:117-122; 3-channel
+    images with mask files, 123-127) and the wavelet-feature branch (global mean / std -> sigmoid -> bilinear up-sampling,
+    133-146) run. load_K_Rt_from_P (dataset.py:13-34) needs cv.decomposeProjectionMatrix and stays out: parity unpinned there."""
+    import importlib.util, tempfile
+    from vdn_train import synth
+    fx = {}
+    store = {}
+    cv = types.ModuleType("cv2")
+    cv.imread = lambda name, flag=None: store[name].copy()
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "dpt_models" or k.startswith("dpt_models.") or k == "cv2"}
+    sys.modules["cv2"] = cv
+    pkg = types.ModuleType("dpt_models")
+    pkg.__path__ = [os.path.join(REFERENCE, "dpt_models")]
+    sys.modules["dpt_models"] = pkg
+    mods = {}
+    orig_cuda = torch.Tensor.cuda
+    try:
+        for name in ("lie_group_helper", "poses", "dataset"):
+            path = os.path.join(REFERENCE, "dpt_models", name + ".py")
+            spec = importlib.util.spec_from_file_location("dpt_models." + name, path)
+            mod = importlib.util.module_from_spec(spec)
+            sys.modules["dpt_models." + name] = mod
+            spec.loader.exec_module(mod)
+            assert os.path.realpath(mod.__file__).startswith(REFERENCE + os.sep), mod.__file__
+            mods[name] = mod
+        poses, dataset = mods["poses"], mods["dataset"]
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        n, H, W, C = 3, 40, 56, 5
+        rng = np.random.RandomState(5)
+        cams = synth.make_cameras(3, n=n).astype(np.float32)
+        K = np.eye(4, dtype=np.float32)
+        K[:3, :3] = np.linalg.inv(synth.intrinsics_inv(focal=60.0, h=H, w=W)).astype(np.float32)
+        pose_all, intr_all = torch.tensor(cams), torch.tensor(np.stack([K] * n))
+        fx["pose_all"], fx["intrinsics_all"] = cams, np.stack([K] * n)
+        tmp = tempfile.mkdtemp(prefix="vdn_rays_fx_")
+        # what cv.imread would hand back: 8-bit images (BGR / BGRA as they lie), 3-channel masks, [1, C, H/2, W/2] feature files
+        bgr = rng.randint(0, 256, (n, H, W, 3)).astype(np.uint8)
+        alpha = (rng.rand(n, H, W, 1) > 0.3).astype(np.uint8) * 255
+        alpha[:, ::7] = 128                                  # some partial coverage
+        bgra = np.concatenate([bgr, alpha], -1)
+        msk = np.repeat((rng.rand(n, H, W, 1) > 0.4).astype(np.uint8) * 255, 3, -1)
+        feats = rng.randn(n, 1, C, H // 2, W // 2).astype(np.float32) * 2.0 + 0.5
+        fx["bgr"], fx["bgra"], fx["mask_files"], fx["feat_files"] = bgr, bgra, msk, feats
+        img3, img4, mk, dp = [], [], [], []
+        for i in range(n):
+            for lis, arr, tag in ((img3, bgr[i], "rgb"), (img4, bgra[i], "rgba"), (mk, msk[i], "mask")):
+                lis.append("%s/%s_%d.png" % (tmp, tag, i))
+                store[lis[-1]] = arr
+            dp.append("%s/feat_%d.npy" % (tmp, i))
+            np.save(dp[-1], feats[i])
+        for tag, imgs, with_depth in (("rgba", img4, True), ("rgbmask", img3, False)):
+            gen = poses.RaysGenerator(imgs, mk, dp, pose_all, intr_all, learnable=False, with_depth=with_depth)
+            fx[tag + "/images"], fx[tag + "/masks"] = gen.images.numpy(), gen.masks.numpy()
+            if with_depth:
+                fx[tag + "/depth_feats"] = gen.depth_feats.numpy()
+            for idx, seed, B in ((1, 11, 64), (2, 12, 33)):
+                torch.manual_seed(seed)
+                data = gen.gen_random_rays_at(idx, B)
+                torch.manual_seed(seed)                     # the two draws of poses.py:193-194, in order
+                px = torch.randint(low=0, high=W, size=[B])
+                py = torch.randint(low=0, high=H, size=[B])
+                k = "%s/rand_%d" % (tag, idx)
+                fx[k + "/img_idx"], fx[k + "/pixels_x"], fx[k + "/pixels_y"], fx[k + "/data"] = idx, px.numpy(), py.numpy(), data.numpy()
+                near, far = dataset.Dataset.near_far_from_sphere(None, data[:, :3], data[:, 3:6])
+                fx[k + "/near"], fx[k + "/far"] = near.numpy(), far.numpy()
+        for idx, l in ((0, 1), (2, 2), (1, 4)):
+            o, v = gen.gen_rays_at(idx, resolution_level=l)
+            fx["at_%d_l%d/rays_o" % (idx, l)], fx["at_%d_l%d/rays_v" % (idx, l)] = o.contiguous().numpy(), v.contiguous().numpy()
+        for ratio, i0, i1, l in ((0.0, 0, 2, 2), (0.3, 0, 2, 2), (0.75, 1, 2, 4), (1.0, 0, 1, 2)):
+            o, v = gen.gen_rays_between(ratio, i0, i1, resolution_level=l)
+            k = "between_%d_%d_r%03d_l%d" % (i0, i1, int(round(ratio * 100)), l)
+            fx[k + "/ratio"], fx[k + "/rays_o"], fx[k + "/rays_v"] = ratio, o.contiguous().numpy(), v.contiguous().numpy()
+        print("[rays] generator fixtures: %d keys; images %s, feats %s" % (len(fx), fx["rgba/images"].shape, fx["rgba/depth_feats"].shape))
+    finally:
+        torch.Tensor.cuda = orig_cuda
+        for k in [k for k in sys.modules if k == "dpt_models" or k.startswith("dpt_models.") or k == "cv2"]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+    return fx
+
+
 CASES = [
     # name, seed, B, wdepth, variance, cos_anneal, perturb, kwargs
     ("white_v03_c0", 1, 24, False, 0.3, 0.0, 1.0, {}),
@@ -430,6 +515,8 @@ def generate(only=None):
         out["adam3"] = adam_fixture(fields, renderer)
     if want("raygrad"):
         out["raygrad"] = raygrad_fixture(fields, renderer)
+    if want("rays"):
+        out["rays"] = rays_fixture()
     return out
 
 

@@ -16,5 +16,5 @@ for T in (8, 16, 32, 64, 128):
         break
     os.environ["VDN_CPU_THREADS"] = str(T)
     t = time.time()
-    r = bench.cpu_baseline(512, 0, max_seconds=12.0)
+    r = bench.cpu_baseline(512, 0, budget_s=0.0)
     print(T, "threads: %.1f rays/s" % r["value"], "(%s; %.1f s)" % (r["sample"].split(" of ")[0], time.time() - t), flush=True)

@@ -124,3 +124,53 @@ def test_palette_image_is_expanded_like_imread_unchanged(tmp_path):
     Image.fromarray(rgb, "RGB").convert("P", palette=Image.ADAPTIVE, colors=64).save(path)
     a = dataset._read_png(path)                      # cv.imread(path, -1) expands palettes to BGR
     np.testing.assert_array_equal(a, rgb[:, :, ::-1].astype(np.float64))
+
+
+def _rays_fx():
+    return dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rays.npz")))
+
+
+def test_image_compositing_and_feature_normalisation_equal_the_reference_constructor():
+    """tests/golden/rays.npz holds what the REFERENCE's RaysGenerator.__init__ (poses.py:96-152, run by make_golden.py with a cv2
+    stub whose imread hands back the arrays below) keeps as images / masks / depth_feats: bit for bit."""
+    fx = _rays_fx()
+    img, msk = dataset.composite_on_white(fx["bgra"])                            # poses.py:117-122
+    assert np.array_equal(img, fx["rgba__images"]) and np.array_equal(msk, fx["rgba__masks"])
+    img, msk = dataset.composite_on_white(fx["bgr"], fx["mask_files"])           # poses.py:123-127
+    assert np.array_equal(img, fx["rgbmask__images"]) and np.array_equal(msk, fx["rgbmask__masks"])
+    stack = np.stack([np.squeeze(f) for f in fx["feat_files"]])                  # poses.py:135
+    feats = dataset.normalise_depth_feats(stack, img.shape[1:3]).numpy()
+    assert feats.shape == fx["rgba__depth_feats"].shape
+    assert np.abs(feats - fx["rgba__depth_feats"]).max() <= 1e-7                 # (sigmoid + bilinear: same torch ops)
+
+
+@pytest.mark.parametrize("rgba", [False, True])
+def test_scene_files_decode_to_the_reference_constructor_arrays(tmp_path, rgba):
+    """The same arrays written as real PNG / npy files (RGB order on disk, as any PNG holds them) and read back through
+    SceneData: the decoder's BGR flip and 8-bit handling land on what cv.imread would have handed the reference."""
+    from PIL import Image
+    fx = _rays_fx()
+    root = str(tmp_path)
+    os.makedirs(os.path.join(root, "image", "mask"))
+    os.makedirs(os.path.join(root, "image", "wavelet_feats", "0"))
+    n = fx["bgr"].shape[0]
+    names = ["%03d" % i for i in range(n)]
+    K4 = fx["intrinsics_all"][0].astype(np.float64)
+    dataset.write_cameras_npz(os.path.join(root, "cameras_sphere.npz"), names, [K4 @ np.linalg.inv(c.astype(np.float64)) for c in fx["pose_all"]],
+                              [np.eye(4)] * n)
+    for i, nm in enumerate(names):
+        if rgba:
+            a = fx["bgra"][i]
+            Image.fromarray(np.concatenate([a[:, :, 2::-1], a[:, :, 3:]], 2), "RGBA").save(os.path.join(root, "image", nm + ".png"))
+        else:
+            Image.fromarray(np.ascontiguousarray(fx["bgr"][i][:, :, ::-1]), "RGB").save(os.path.join(root, "image", nm + ".png"))
+            Image.fromarray(fx["mask_files"][i], "RGB").save(os.path.join(root, "image", "mask", nm + ".png"))
+        np.save(os.path.join(root, "image", "wavelet_feats", "0", nm + ".npy"), fx["feat_files"][i])
+    sc = dataset.SceneData(root, with_depth=rgba)
+    tag = "rgba" if rgba else "rgbmask"
+    assert np.array_equal(sc.images, fx[tag + "__images"]) and np.array_equal(sc.masks, fx[tag + "__masks"])
+    if rgba:
+        assert np.abs(sc.depth_feats - fx["rgba__depth_feats"]).max() <= 1e-7
+    # cameras: K [R|t] written, decomposed back (load_K_Rt_from_P itself is pinned by construction only: OpenCV is absent)
+    np.testing.assert_allclose(sc.pose_all, fx["pose_all"], atol=3e-6)
+    np.testing.assert_allclose(sc.intrinsics_all[:, :3, :3], fx["intrinsics_all"][:, :3, :3], rtol=1e-5, atol=1e-4)

@@ -1,5 +1,6 @@
 """Data-parallel recipe (vdn_train/dp.py) on CPU with gloo, world_size 2: ray shards + eikonal
-numerator/denominator all-reduce + one flat gradient all-reduce == one process on the concatenated
+numerator/denominator all-reduce + the gradient all-reduced in the Trainer's three slices over its two
+communicators (dp.Collectives, the object the Trainer itself drives) == one process on the concatenated
 batch. Compute is the oracle (this is a test of the host-side DP logic, not of the kernels)."""
 import os
 import socket
@@ -47,7 +48,9 @@ def _worker(rank, port, q, wdepth):
     out = _render(nets, b)
     nd = torch.stack([out["eik_num"].detach(), out["eik_den"].detach()])
     local_num = nd[0].clone()
-    dp.global_eikonal(nd)                                   # in place: global (num, den)
+    coll = dp.Collectives(WORLD)                            # the Trainer's own collectives object (vdn_train/trainer.py:97)
+    assert coll.enabled and coll.side_group is not coll.group
+    coll.finish(coll.begin([nd]), tag="eikonal")            # in place: global (num, den)
     eik = (out["eik_num"] + (nd[0] - local_num)) / (nd[1] + 1e-5)     # gradient flows through the local numerator only
     loss = (out["color_fine"] - b[6]).abs().sum() / (B_PER_RANK + 1e-5) / WORLD + 0.1 * eik / WORLD * WORLD
     # note: the eikonal term is already the GLOBAL value; each rank differentiates only its own numerator
@@ -58,7 +61,17 @@ def _worker(rank, port, q, wdepth):
     gs = torch.autograd.grad(local, [p for _, p in named], allow_unused=True)
     flat = torch.cat([(torch.zeros_like(p) if gr is None else gr).reshape(-1) for (_, p), gr in zip(named, gs)])
     # remove the double-counted constant part: d/dtheta of (nd[0]-local_num) is zero, so nothing to fix
-    dp.allreduce_flat(flat)
+    # the gradient as the Trainer reduces it: three slices of the flat buffer - [background network] and [heads] through the
+    # side communicator, [SDF network + variance] through the main one (trainer.py: update_rest / update_sdf)
+    names = [n for n, _ in named]
+    sizes = np.cumsum([0] + [p.numel() for _, p in named])
+    sb = int(sizes[next(i for i, n in enumerate(names) if n.startswith("sdf."))])
+    se = int(sizes[names.index("variance") + 1])
+    h_nerf = coll.begin([flat[:sb]], side=True)
+    h_sdf = coll.begin([flat[sb:se]])
+    coll.finish(h_sdf, tag="grad_sdf")
+    h_heads = coll.begin([flat[se:]], side=True)
+    coll.finish(h_nerf + h_heads, tag="grad_rest")
     if rank == 0:
         q.put((flat.numpy(), float(eik)))
     dist.destroy_process_group()

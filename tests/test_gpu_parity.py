@@ -390,6 +390,39 @@ def test_on_device_ray_generator(dev):
     assert np.abs(vb[7, 5].cpu().numpy() - (pp / np.linalg.norm(pp)) @ c2w[:3, :3].T).max() < 2e-5
 
 
+def test_on_device_ray_generator_vs_reference_vectors(dev):
+    """vdn_train.rays.RaysGenerator against the REFERENCE's own RaysGenerator / near_far_from_sphere outputs (tests/golden/rays.npz,
+    written by make_golden.py::rays_fixture from poses.py:96-252 and dataset.py:111-118 run on CPU): random-pixel batches with the
+    reference's recorded torch.randint draws injected (both constructor branches, with and without VDN target features), whole-image
+    rays at three resolution levels, interpolated cameras."""
+    from vdn_train.rays import RaysGenerator
+    fx = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rays.npz")))
+    for tag, with_depth in (("rgba", True), ("rgbmask", False)):
+        gen = RaysGenerator(fx[tag + "__images"], fx[tag + "__masks"], fx["pose_all"], fx["intrinsics_all"],
+                            depth_feats=fx["rgba__depth_feats"] if with_depth else None, device=dev)
+        for idx in (1, 2):
+            k = "%s__rand_%d" % (tag, idx)
+            ref, px, py = fx[k + "__data"], fx[k + "__pixels_x"], fx[k + "__pixels_y"]
+            assert int(fx[k + "__img_idx"]) == idx
+            out, near, far = gen.gen_random_rays_at(idx, len(px), pixels=(px, py), return_near_far=True)
+            out = out.cpu().numpy()
+            assert out.shape == ref.shape                                         # [B, 10 + C]; C = 1 zero column without features
+            assert np.array_equal(out[:, 0:3], ref[:, 0:3])                       # rays_o: the pose's translation
+            assert np.abs(out[:, 3:6] - ref[:, 3:6]).max() < 2e-6                 # rays_d
+            assert np.array_equal(out[:, 6:], ref[:, 6:])                         # mask | rgb | feats: gathers
+            assert np.abs(near.cpu().numpy() - fx[k + "__near"]).max() < 1e-5 and np.abs(far.cpu().numpy() - fx[k + "__far"]).max() < 1e-5
+    for idx, l in ((0, 1), (2, 2), (1, 4)):
+        o, v = gen.gen_rays_at(idx, resolution_level=l)
+        ro, rv = fx["at_%d_l%d__rays_o" % (idx, l)], fx["at_%d_l%d__rays_v" % (idx, l)]
+        assert tuple(o.shape) == ro.shape and tuple(v.shape) == rv.shape
+        assert np.array_equal(o.cpu().numpy(), ro) and np.abs(v.cpu().numpy() - rv).max() < 2e-6
+    for k in sorted(k[:-7] for k in fx if k.startswith("between_") and k.endswith("__ratio")):
+        _, i0, i1, _, lv = k.split("_")
+        o, v = gen.gen_rays_between(float(fx[k + "__ratio"]), int(i0), int(i1), resolution_level=int(lv[1:]))
+        assert tuple(o.shape) == fx[k + "__rays_o"].shape
+        assert np.abs(o.cpu().numpy() - fx[k + "__rays_o"]).max() < 1e-5 and np.abs(v.cpu().numpy() - fx[k + "__rays_v"]).max() < 1e-5
+
+
 def test_val_img_over_a_scene_directory(tmp_path):
     """Scene files -> SceneData -> on-device rays -> batched render of one camera (Runner.val_img, dpt_runner.py:417-474),
     incl. the depth_from_sdf writer; the image equals direct render() calls on the same rays and jitter."""

@@ -59,6 +59,22 @@ def _read_png(path, unchanged=True):
     return np.concatenate([a[:, :, 2::-1], a[:, :, 3:]], axis=2) if a.shape[2] == 4 else a[:, :, ::-1]
 
 
+def composite_on_white(decoded, mask_files=None):
+    """poses.py:114-129 on decoded 0..255 arrays (what cv.imread yields): 4-channel images are composited on white with their
+    own alpha, which becomes the mask (117-122); 3-channel images with the mask files (123-127). float64 arithmetic, one cast
+    to float32 at the end, as the reference does -> (images [n,H,W,3], masks [n,H,W,1|3]), float32."""
+    images = np.asarray(decoded, dtype=np.float64) / 255.0
+    if images.shape[-1] == 4:
+        pic, a = images[..., :3], images[..., 3:]
+        images, masks = pic * a + (1 - a), a
+    else:
+        if mask_files is None:
+            raise ValueError("3-channel images need their mask files (poses.py:123-127)")
+        masks = np.asarray(mask_files, dtype=np.float64) / 255.0
+        images = images * masks + (1 - masks)
+    return images.astype(np.float32), masks.astype(np.float32)
+
+
 def normalise_depth_feats(stack, image_size):
     """poses.py:133-146: global mean / std over the whole stack -> sigmoid -> bilinear up-sampling to the image size
     (nn.Upsample(size, mode='bilinear'), align_corners=False) -> [n, H, W, C]."""
@@ -97,14 +113,9 @@ class SceneData:
         self.intrinsics_all, self.pose_all = np.stack(intr), np.stack(pose)
         self.focal = float(self.intrinsics_all[0][0, 0])
 
-        images = np.stack([_read_png(f) for f in self.images_lis]) / 255.0
-        if images.shape[-1] == 4:                                    # poses.py:117-122: RGBA, composited on white
-            pic, a = images[..., :3], images[..., 3:]
-            images, masks = pic * a + (1 - a), a
-        else:                                                        # poses.py:123-127
-            masks = np.stack([_read_png(f, unchanged=False) for f in self.masks_lis]) / 255.0
-            images = images * masks + (1 - masks)
-        self.images, self.masks = images.astype(np.float32), masks.astype(np.float32)
+        decoded = np.stack([_read_png(f) for f in self.images_lis])
+        mask_files = None if decoded.shape[-1] == 4 else np.stack([_read_png(f, unchanged=False) for f in self.masks_lis])
+        self.images, self.masks = composite_on_white(decoded, mask_files)
         self.H, self.W = self.images.shape[1:3]
         self.depth_feats = None
         if with_depth:

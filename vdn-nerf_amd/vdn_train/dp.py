@@ -13,22 +13,10 @@ Equivalence with one process on the concatenated batch:
 so each rank back-propagates its colour term scaled by 1/W and its eikonal numerator against the
 GLOBAL denominator; summing the ranks' gradients gives d loss_global / d theta.
 """
+import os
+
 import torch
 import torch.distributed as dist
-
-
-def global_eikonal(num_den, group=None):
-    """num_den: tensor [2] = local (numerator, denominator). All-reduced in place; returns gradient_error."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(num_den, group=group)
-    return num_den[0] / (num_den[1] + 1e-5)
-
-
-def allreduce_flat(flat, group=None):
-    """Sum the flat gradient buffer over ranks (colour-term scaling by 1/W is applied upstream)."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(flat, group=group)
-    return flat
 
 
 class Collectives:
@@ -48,18 +36,47 @@ class Collectives:
         self.enabled = bool(force) or world_size > 1
         if self.enabled and not dist.is_initialized():
             raise RuntimeError("data-parallel Trainer: torch.distributed is not initialised (init_process_group first)")
+        # A process group's collectives run on ONE internal stream in host issue order. The Trainer issues, per step: the
+        # background slice (side stream), the SDF slice (critical path: the next sampler waits for it), the heads' slice (side
+        # stream), the next step's 8-byte eikonal sums (critical path). In one group the critical ones would queue behind the
+        # side-stream slices and their GEMMs; the side-stream slices therefore get a communicator of their own (same ranks).
+        # Created by every rank in the same order (dist.new_group is collective). VDN_DP_SIDE_GROUP=0: one group for all.
+        self.side_group = group
+        if self.enabled and os.environ.get("VDN_DP_SIDE_GROUP", "1") != "0":
+            ranks = None if group is None else dist.get_process_group_ranks(group)
+            self.side_group = dist.new_group(ranks=ranks)
+        self.timing = False         # bench.py: HIP events around finish() -> exposed wait per tag
+        self._timed = {}
 
-    def begin(self, tensors):
-        """Start summing each tensor (contiguous views of the flat buffers) over the ranks -> handles for finish()."""
+    def begin(self, tensors, side=False):
+        """Start summing each tensor (contiguous views of the flat buffers) over the ranks -> handles for finish().
+        side: a slice that is issued and awaited on the Trainer's side stream (its own communicator)."""
         if not self.enabled:
             return []
-        return [dist.all_reduce(t, group=self.group, async_op=True) for t in tensors if t.numel()]
+        grp = self.side_group if side else self.group
+        return [dist.all_reduce(t, group=grp, async_op=True) for t in tensors if t.numel()]
 
-    @staticmethod
-    def finish(handles):
-        """Order the current stream behind the collectives started by begin()."""
+    def finish(self, handles, tag=None):
+        """Order the current stream behind the collectives started by begin(). With `timing` on, the stream's wait is bracketed
+        by two events: their distance is the EXPOSED part of the collective (what the stream could not hide behind its own
+        launches), collected per tag for exposed_ms()."""
+        if self.timing and tag is not None and handles:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for h in handles:
+                h.wait()
+            e1.record()
+            self._timed.setdefault(tag, []).append((e0, e1))
+            return
         for h in handles:
             h.wait()
+
+    def exposed_ms(self, reset=True):
+        """Mean exposed wait per finish() tag in ms over the calls since the last reset (call after a device synchronise)."""
+        out = {k: {"mean_ms": sum(a.elapsed_time(b) for a, b in v) / len(v), "calls": len(v)} for k, v in self._timed.items() if v}
+        if reset:
+            self._timed = {}
+        return out
 
     def broadcast(self, flat, src=0):
         if self.enabled:

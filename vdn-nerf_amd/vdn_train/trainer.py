@@ -197,7 +197,7 @@ class Trainer:
         if self.coll.enabled:
             # the eikonal term is a ratio of sums over the GLOBAL batch (renderer.py:313-315): its two sums were
             # on their way since the SDF kernel finished; the loss kernel and the compositor's adjoint read w["eik"]
-            self.coll.finish(self._eik_handles)
+            self.coll.finish(self._eik_handles, tag="eikonal")
             eg = self._eik_global
             eg[0:1] = eg[1:2] / (eg[2:3] + 1e-5)
             w["eik"].copy_(eg)
@@ -239,7 +239,8 @@ class Trainer:
             in front of the SDF network in the flat buffer ("nerf": the background network) / behind it ("heads")."""
             keep = {"rest": lambda b: True, "nerf": lambda b: b < sdf_begin, "heads": lambda b: b >= sdf_begin}[part]
             nets = [k for k in rest_nets if part == "rest" or (k == "nerf") == (part == "nerf")]
-            self.coll.finish(self.coll.begin([grad[b:e] for b, e in self._slices_rest if keep(b)]))
+            on_side = stream != st            # (without a side stream these slices share the caller's stream and the main group)
+            self.coll.finish(self.coll.begin([grad[b:e] for b, e in self._slices_rest if keep(b)], side=on_side), tag="grad_" + part)
             rr = [r_ for r_ in self._rest_ranges if keep(r_[0])]
             if rr:
                 adam(rr, main_step, stream)
@@ -250,7 +251,7 @@ class Trainer:
                 images.refresh_together([eng.nets[k].img for k in nets], stream, self._img_cache.setdefault(part, {}))
 
         def update_sdf(stream):
-            self.coll.finish(self.coll.begin([grad[b:e] for b, e in self._sdf_ranges]))
+            self.coll.finish(self.coll.begin([grad[b:e] for b, e in self._sdf_ranges]), tag="grad_sdf")
             adam(self._sdf_ranges, main_step, stream)
             images.refresh_together([eng.nets["sdf"].img], stream, self._img_cache.setdefault("sdf", {}))
 
