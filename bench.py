@@ -32,7 +32,17 @@ import torch
 # algorithmic FLOPs (2 per MAC, GEMM work only) - SURVEY.md 8d
 F_SDF, F_SDF1, F_GRAD, F_COL, F_VDN, F_NERF, F_NERF_DPT = 1049088, 918016, 918016, 542720, 590336, 1208320, 1232896
 PEAK = {"f32": 157.3e12, "bf16": 2.5e15}     # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
-PROFILE_ROUND = "r03"      # profiles/<round>_traffic_*.json: the PMC traffic figures quoted in `roofline.traffic`
+PROFILE_ROUND = "r04"      # profiles/<round>_traffic_*.json: the PMC traffic figures quoted in `roofline.traffic`
+
+
+def _profile_file(suffix):
+    """profiles/<round>_<suffix> of the newest round that has it (this round's counters are collected after its first bench)."""
+    n = int(PROFILE_ROUND[1:])
+    for r in range(n, 0, -1):
+        f = os.path.join(ROOT, "profiles", "r%02d_%s" % (r, suffix))
+        if os.path.exists(f):
+            return f
+    return None
 
 
 def flop_per_ray(wdepth, fg_frac=1.0, bg_frac=1.0):
@@ -72,6 +82,22 @@ def physical_cores():
     except OSError:
         pass
     return os.cpu_count() or 1
+
+
+def time_kernel_stats(fn, iters=20):
+    """Device time of fn() over `iters` launches (HIP events on the launch stream): median / mean / min / max in seconds."""
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0 = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
+    e1 = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
+    for i in range(iters):
+        e0[i].record()
+        fn()
+        e1[i].record()
+    torch.cuda.synchronize()
+    t = np.array([a.elapsed_time(b) for a, b in zip(e0, e1)]) * 1e-3
+    return {"median": float(np.median(t)), "mean": float(t.mean()), "min": float(t.min()), "max": float(t.max()), "launches": iters}
 
 
 def cpu_baseline(B, seed, wdepth=False, full=False, budget_s=75.0):
@@ -195,7 +221,25 @@ class Leg:
 
     def step(self, i):
         # one iteration of dpt_runner.py:197-259: sample -> render -> loss -> backward -> (all-reduce) -> Adam
+        self.steps_done = getattr(self, "steps_done", 0) + 1
         return self.trainer.train_step(*self.batches[i % len(self.batches)], gt_feats=self.gt_feats)
+
+    def sdf_in_situ(self, n_steps=60):
+        """The fused SDF kernel timed INSIDE `n_steps` consecutive training steps: HIP events on the launch stream right around
+        each step's own launch (TrainEngine.sdf_probe), with that step's row count. -> mean / median / min / max and mean rows."""
+        eng = self.trainer.engine
+        self.fence()
+        eng.sdf_probe = []
+        for i in range(n_steps):
+            self.step(self.steps_done)
+        self.fence()
+        probe, eng.sdf_probe = eng.sdf_probe, None
+        t = np.array([a.elapsed_time(b) for a, b, _ in probe]) * 1e-3
+        rows = np.array([eng.P if r is None else int(r.item()) for _, _, r in probe], dtype=np.float64)
+        return {"kernel_ms": float(t.mean() * 1e3), "kernel_ms_median": float(np.median(t) * 1e3), "kernel_ms_min": float(t.min() * 1e3),
+                "kernel_ms_max": float(t.max() * 1e3), "points": float(rows.mean()), "points_min": float(rows.min()),
+                "points_max": float(rows.max()), "steps": n_steps, "workgroups_mean": float(np.ceil(rows / 128.0).mean()),
+                "flops": float((F_SDF + F_GRAD) * rows.mean())}
 
     def fence(self):
         torch.cuda.synchronize()
@@ -229,6 +273,15 @@ class Leg:
             regions.append(self.region(warmup + len(regions) * steps, steps))
         med = float(np.median(regions))
         eng = self.trainer.engine
+        # mean work-list rows of the steady state: `steps` more (untimed) steps with the device-side row counters copied out per
+        # step (the kernel statistics under profiles/ quote them: roofline fractions are recomputed from rows / AverageUs)
+        counts = []
+        for i in range(steps):
+            self.step(warmup + len(regions) * steps + i)
+            counts.append((eng.w["fg_active"][1].clone(), eng.w["bg_active"][1].clone() if "bg_active" in eng.w else None))
+        self.fence()
+        rows_fg = float(np.mean([int(a.item()) for a, _ in counts]))
+        rows_bg = float(np.mean([int(b.item()) for _, b in counts])) if counts[0][1] is not None else 0.0
         fg = int(eng.w["fg_active"][1].item())
         bg = int(eng.w["bg_active"][1].item()) if "bg_active" in eng.w else 0
         rays = self.world * self.B * steps
@@ -236,20 +289,28 @@ class Leg:
         return {"value": rays / med, "ms_per_step": med / steps * 1e3,
                 "trials": {"regions": len(regions), "steps_per_region": steps, "timed_seconds": float(sum(regions)),
                            "ms_per_step_min": min(regions) / steps * 1e3, "ms_per_step_max": max(regions) / steps * 1e3},
+                "work_list_rows_mean": {"foreground": rows_fg, "background": rows_bg, "over_steps": steps},
                 "foreground_points_evaluated_last_step": fg, "foreground_points_total": eng.P,
                 "background_points_evaluated_last_step": bg, "background_points_total": eng.Q,
                 "executed_flop_per_ray": fpr, "executed_model_flops_per_s": rays / med * fpr,
                 "final_loss": float(self.last[0].item())}
 
-    def sdf_kernel_roofline(self, n_lists=6):
-        """The fused SDF-MLP kernel (north-star kernel): PE -> 9 layers -> sdf/feature + analytic gradient sweep, timed with HIP
-        events exactly as the timed training step launches it (training-mode saves, over the step's foreground work list) and
-        as render() launches it under no_grad (all 65 536 points, nothing saved). The work list differs from batch to batch
-        (and the kernel runs whole rounds of 128-point workgroups), so the training launch is timed over the lists of
-        `n_lists` different steps: achieved = their FLOPs / their time. Every rank runs the steps (they hold collectives);
-        only rank 0 times."""
+    def sdf_kernel_roofline(self, n_lists=6, one_stream=None, in_situ_steps=60):
+        """The fused SDF-MLP kernel (north-star kernel): PE -> 9 layers -> sdf/feature + analytic gradient sweep.
+        `kernel_ms` / `points` / `frac` are IN SITU: HIP events around the launch inside `in_situ_steps` consecutive timed
+        training steps - of `one_stream` (a Leg on the one-stream schedule VDN_SIDE_STREAM=0 VDN_OVERLAP=0, the schedule the
+        committed rocprofv3 kernel trace profiles/<round>_train_bf16_kernel_stats.csv is taken on: its AverageUs is this number)
+        when given, else of this leg as scheduled. Beside it: the same launch inside the steps of the default two-stream schedule
+        (`in_step_two_streams`: the background network's kernels share the chip with it), the old isolated timing (`isolated`:
+        the step's launch repeated back to back on an otherwise idle chip, over the lists of `n_lists` steps), the inference
+        launch and the training launch over all rows (medians of 20 isolated launches). Every rank runs the steps (they hold
+        collectives); only rank 0 reports."""
         eng, rend = self.trainer.engine, self.rend
         dtype = "f32" if self.precision == "fp32" else "bf16"
+        situ_two = self.sdf_in_situ(in_situ_steps)
+        situ = situ_two
+        if one_stream is not None:
+            situ = one_stream.sdf_in_situ(in_situ_steps)
         t_sum, rows_sum, per_list = 0.0, 0, []
         for j in range(n_lists):
             self.step(j)
@@ -266,56 +327,71 @@ class Leg:
             return None
         o, d = self.batches[0][0], self.batches[0][1]
         with torch.no_grad():
-            tk_inf = time_kernel(lambda: rend.sdf_network._run(1, rays=(o, d, eng.w["mid_z"])))
+            tk_inf = time_kernel_stats(lambda: rend.sdf_network._run(1, rays=(o, d, eng.w["mid_z"])))
             # SURVEY.md 8d's configuration C2 on the same 65 536 points: K1 + K3 + K5 + K6 = PE + SDF MLP + gradient sweep, colour
-            # head, NeuS alpha + compositing (NeuSRenderer._shade, renderer.py:239-315). The north star names these as ONE
-            # kernel; they are three launches here (the heads and the compositor are launches of their own: DESIGN.md 3a),
-            # timed as render() issues them, end to end
+            # head, NeuS alpha + compositing (NeuSRenderer._shade, renderer.py:239-315), timed as render() issues it, end to end
             bgc = torch.ones(3, device=self.dev)
-            tk_c2 = time_kernel(lambda: rend._shade(o, d, eng.w["dists"], eng.w["mid_z"], None, bgc, 0.5))
+            tk_c2 = time_kernel_stats(lambda: rend._shade(o, d, eng.w["dists"], eng.w["mid_z"], None, bgc, 0.5))
+            c2_launches = getattr(rend, "shade_launches", lambda: 4 if self.wdepth else 3)()
         # the training-mode launch over ALL rows (what the step launches on a scene whose samples all lie inside the relaxed
         # sphere, and in the all-samples leg): no work list
         fgc, eng._fg_compact = eng._fg_compact, False
-        tk_full = time_kernel(lambda: eng._sdf_forward(o, d), iters=4)
+        tk_full = time_kernel_stats(lambda: eng._sdf_forward(o, d))
         eng._fg_compact = fgc
         eng._sdf_forward(o, d)                    # leave the workspace as the step left it
 
         def traffic_of(tag):
-            tf = os.path.join(ROOT, "profiles", "%s_traffic_sdf_fwd_%s%s.json" % (PROFILE_ROUND, self.precision, tag))
-            if not os.path.exists(tf):
+            tf = _profile_file("traffic_sdf_fwd_%s%s.json" % (self.precision, tag))
+            if tf is None:
                 return None, None
             j = json.load(open(tf))
             return j.get("hbm_bytes_per_launch"), os.path.relpath(tf, ROOT)
         tr_train, src_train = traffic_of("_train")
         tr_inf, src_inf = traffic_of("")
         rows_mean, tk = rows_sum / float(n_lists), t_sum / n_lists
+        tr_full = tr_train
         if tr_train is not None:
-            tr_train *= rows_mean / float(eng.P)      # PMC figure is for a 65 536-point launch; bytes scale with the rows
-        fl_train, fl_inf = (F_SDF + F_GRAD) * rows_mean, (F_SDF + F_GRAD) * eng.P
+            tr_train *= situ["points"] / float(eng.P)      # PMC figure is for a 65 536-point launch; bytes scale with the rows
+        F1 = F_SDF + F_GRAD
+        pk = PEAK[dtype]
+        fl_inf = F1 * eng.P
         name = ("sdf_fwd_kernel<F32,1,4,false>" if dtype == "f32" else "sdf2::sdf_fwd2_kernel<1,true,4,3> (csrc/k_sdf_fwd2.h)")
-        return {"bound": "mfma", "kernel": name + ": fused PE + SDF MLP + gradient sweep, training-mode launch of the timed step over its "
-                                                   "foreground work list (mean over %d steps' lists)" % n_lists,
-                "achieved": fl_train / tk / 1e12, "peak": PEAK[dtype] / 1e12, "unit": "TFLOP/s", "frac": fl_train / tk / PEAK[dtype],
-                "traffic": tr_train, "traffic_source": src_train, "kernel_ms": tk * 1e3, "points": rows_mean, "per_list": per_list,
-                "inference_launch": {"kernel_ms": tk_inf * 1e3, "points": eng.P, "achieved": fl_inf / tk_inf / 1e12,
-                                     "frac": fl_inf / tk_inf / PEAK[dtype], "traffic": tr_inf, "traffic_source": src_inf},
-                "training_launch_full_rows": {"kernel_ms": tk_full * 1e3, "points": eng.P, "achieved": fl_inf / tk_full / 1e12,
-                                              "frac": fl_inf / tk_full / PEAK[dtype],
-                                              "traffic": None if tr_train is None else tr_train * float(eng.P) / rows_mean},
+        c2f = (F1 + F_COL + (F_VDN if self.wdepth else 0)) * eng.P
+        return {"bound": "mfma",
+                "kernel": name + ": fused PE + SDF MLP + gradient sweep, training-mode launch of the timed step over its foreground "
+                                 "work list, timed IN SITU: HIP events around the launch inside %d consecutive training steps (%s)"
+                                 % (in_situ_steps, "one-stream schedule, as the committed kernel trace" if one_stream is not None else "as scheduled"),
+                "achieved": situ["flops"] / (situ["kernel_ms"] * 1e-3) / 1e12, "peak": pk / 1e12, "unit": "TFLOP/s",
+                "frac": situ["flops"] / (situ["kernel_ms"] * 1e-3) / pk,
+                "traffic": tr_train, "traffic_source": src_train, "kernel_ms": situ["kernel_ms"], "points": situ["points"],
+                "in_situ": situ,
+                "in_step_two_streams": dict(situ_two, frac=situ_two["flops"] / (situ_two["kernel_ms"] * 1e-3) / pk),
+                "isolated": {"what": "the step's launch repeated 4 x back to back on an idle chip, mean over %d steps' lists (rounds 1-3 quoted "
+                                     "this as roofline.frac)" % n_lists,
+                             "kernel_ms": tk * 1e3, "points": rows_mean, "frac": F1 * rows_mean / tk / pk, "per_list": per_list},
+                "inference_launch": {"kernel_ms": tk_inf["median"] * 1e3, "kernel_ms_min": tk_inf["min"] * 1e3, "kernel_ms_max": tk_inf["max"] * 1e3,
+                                     "points": eng.P, "achieved": fl_inf / tk_inf["median"] / 1e12,
+                                     "frac": fl_inf / tk_inf["median"] / pk, "traffic": tr_inf, "traffic_source": src_inf,
+                                     "what": "median of 20 isolated launches"},
+                "training_launch_full_rows": {"kernel_ms": tk_full["median"] * 1e3, "kernel_ms_min": tk_full["min"] * 1e3,
+                                              "kernel_ms_max": tk_full["max"] * 1e3, "points": eng.P,
+                                              "achieved": fl_inf / tk_full["median"] / 1e12, "frac": fl_inf / tk_full["median"] / pk,
+                                              "traffic": tr_full, "what": "median of 20 isolated launches"},
                 "c2_forward": {"what": "SURVEY.md 8d C2: PE + SDF MLP + gradient sweep + colour%s head + NeuS alpha / compositing on %d points, "
-                                       "as render() launches them (%d launches, not one fused kernel)"
-                                       % (" + VDN" if self.wdepth else "", eng.P, 4 if self.wdepth else 3),
-                               "chain_ms": tk_c2 * 1e3, "points": eng.P, "points_per_s": eng.P / tk_c2,
-                               "achieved": (F_SDF + F_GRAD + F_COL + (F_VDN if self.wdepth else 0)) * eng.P / tk_c2 / 1e12,
-                               "frac": (F_SDF + F_GRAD + F_COL + (F_VDN if self.wdepth else 0)) * eng.P / tk_c2 / PEAK[dtype]}}
+                                       "as render() launches them (%d launch%s), median of 20"
+                                       % (" + VDN" if self.wdepth else "", eng.P, c2_launches, "" if c2_launches == 1 else "es"),
+                               "launches": c2_launches,
+                               "chain_ms": tk_c2["median"] * 1e3, "chain_ms_min": tk_c2["min"] * 1e3, "points": eng.P,
+                               "points_per_s": eng.P / tk_c2["median"],
+                               "achieved": c2f / tk_c2["median"] / 1e12, "frac": c2f / tk_c2["median"] / pk}}
 
     def dw_roofline(self):
         eng = self.trainer.engine
         dtype = "f32" if self.precision == "fp32" else "bf16"
         tdw = time_kernel(lambda: eng._launch_dw_groups())       # two launches: the SDF network's entries, then the rest
         dw_bytes, dw_flops = eng.dw_bytes(), eng.dw_flops()
-        tdwf = os.path.join(ROOT, "profiles", "%s_traffic_dw_gemm_%s.json" % (PROFILE_ROUND, dtype))
-        traffic = json.load(open(tdwf)).get("hbm_bytes_per_launch") if (os.path.exists(tdwf) and not self.wdepth) else None
+        tdwf = _profile_file("traffic_dw_gemm_%s.json" % dtype)
+        traffic = json.load(open(tdwf)).get("hbm_bytes_per_launch") if (tdwf is not None and not self.wdepth) else None
         return {"bound": "hbm", "kernel": "dw_gemm_%s_kernel (batched split-K weight-gradient GEMM, longest kernel of the step; its two launches - "
                                           "SDF entries, the rest - timed back to back)" % dtype,
                 "achieved": dw_bytes / tdw / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": dw_bytes / tdw / 8e12,
@@ -418,7 +494,23 @@ def main():
                 extras["forward_only_rays_per_s_batch_%d" % (4 * args.batch)] = world * 4 * args.batch * (nf // 2) / (time.time() - t1)
     roof = roof_dw = None
     if not args.no_roofline:
-        roof = head.sdf_kernel_roofline()           # every rank takes part (steps hold collectives); rank 0 gets the numbers
+        # the north-star kernel in situ on the one-stream schedule (what the committed rocprofv3 kernel trace shows): a second
+        # leg with the same seed, batches and step count (same work lists), built with the side stream and the overlap off
+        env1 = {"VDN_SIDE_STREAM": "0", "VDN_OVERLAP": "0"}
+        old_env = {k: os.environ.get(k) for k in env1}
+        os.environ.update(env1)
+        one = Leg(args, dev, world, rank, args.precision, wdepth, nb, crop=args.crop)
+        for k, v in old_env.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+        for i in range(head.steps_done):             # to the same training state (the work lists shrink over the first ~600 steps)
+            one.step(i)
+        one.fence()
+        roof = head.sdf_kernel_roofline(one_stream=one)   # every rank takes part (steps hold collectives); rank 0 gets the numbers
+        del one
+        torch.cuda.empty_cache()
         roof_dw = head.dw_roofline() if rank == 0 else None
 
     def other_leg(precision, wd, crop=None, roofline=True):
@@ -473,7 +565,7 @@ def main():
                        "background_points_total": res["background_points_total"],
                        "foreground_points_evaluated_last_step": res["foreground_points_evaluated_last_step"],
                        "foreground_points_total": res["foreground_points_total"]},
-            "trials": res["trials"],
+            "trials": res["trials"], "work_list_rows_mean": res["work_list_rows_mean"],
             # FLOPs of the points the step actually evaluated (not the all-samples count)
             "model_flops_per_s": res["executed_model_flops_per_s"],
             "final_loss": res["final_loss"],

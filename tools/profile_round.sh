@@ -5,7 +5,7 @@
 #   other's durations in a trace). Summaries are written under gpurun_out/<round>_*; tools/summarise_counters.py and
 #   tools/traffic_json.py turn them into the files committed under profiles/.
 #   usage: bash tools/profile_round.sh r02
-R=${1:-r03}
+R=${1:-r04}
 export VDN_SIDE_STREAM=0 VDN_OVERLAP=0
 bash tools/collect_counters.sh ${R}_sdf1 python3 tools/kernel_loop.py sdf1 65536 bf16 8
 bash tools/collect_counters.sh ${R}_sdf1t python3 tools/kernel_loop.py sdf1t 65536 bf16 8
@@ -19,11 +19,11 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 # steady-state tail (tools/steady_stats.py: the work lists shrink over the first ~600 steps; `value` is decided behind that)
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_trace -- python3 bench.py --headline-only --no-cpu-baseline --no-roofline --steps 20 > gpurun_out/${R}_trace_bench.json 2> gpurun_out/${R}_trace.log
 find gpurun_out/${R}_trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${R}_train_bf16_kernel_stats_whole_run.csv
-find gpurun_out/${R}_trace -name "*kernel_trace.csv" | head -1 | xargs -I{} python3 tools/steady_stats.py {} 0.3 > gpurun_out/${R}_train_bf16_kernel_stats.csv
+find gpurun_out/${R}_trace -name "*kernel_trace.csv" | head -1 | xargs -I{} python3 tools/steady_stats.py {} 0.3 gpurun_out/${R}_trace_bench.json > gpurun_out/${R}_train_bf16_kernel_stats.csv
 rm -rf gpurun_out/${R}_trace
 # the same with both streams in use (the default schedule): kernels overlap, their durations inflate each other
 unset VDN_SIDE_STREAM VDN_OVERLAP
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${R}_trace2 -- python3 bench.py --headline-only --no-cpu-baseline --no-roofline --steps 20 > gpurun_out/${R}_trace2_bench.json 2> gpurun_out/${R}_trace2.log
-find gpurun_out/${R}_trace2 -name "*kernel_trace.csv" | head -1 | xargs -I{} python3 tools/steady_stats.py {} 0.3 > gpurun_out/${R}_train_bf16_kernel_stats_two_streams.csv
+find gpurun_out/${R}_trace2 -name "*kernel_trace.csv" | head -1 | xargs -I{} python3 tools/steady_stats.py {} 0.3 gpurun_out/${R}_trace2_bench.json > gpurun_out/${R}_train_bf16_kernel_stats_two_streams.csv
 rm -rf gpurun_out/${R}_trace2
 echo profile_round done

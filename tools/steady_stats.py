@@ -1,7 +1,10 @@
 """Per-kernel statistics of the steady-state tail of a `rocprofv3 --kernel-trace --output-format csv` run: only dispatches that
 start in the last FRACTION of the traced time are kept (the bench's work lists shrink over its first ~600 steps; the timed regions
 that decide `value` lie behind that), so that the table reproduces the bench line without conversion.
-usage: steady_stats.py <kernel_trace.csv> [fraction=0.3] [steps_in_window: divide counts by it]   -> CSV on stdout"""
+usage: steady_stats.py <kernel_trace.csv> [fraction=0.3] [bench.json of the traced run]   -> CSV on stdout
+With the traced run's bench line the header also carries the mean work-list rows per step (work_list_rows_mean), so that a
+kernel's roofline fraction can be recomputed from the table alone: FLOP per row x rows / AverageUs / peak."""
+import json
 import csv
 import sys
 from collections import defaultdict
@@ -23,6 +26,23 @@ steps = len(by.get("vdn::composite_bwd_kernel(VdnCompositeBwdArgs)", [])) or 1
 busy = sum(sum(v) for v in by.values())
 print("# window: last %.0f %% of the trace = %.1f ms, %d training steps, kernel time %.1f us/step (sum over kernels)" % (
     100 * frac, (t1 - cut) / 1e6, steps, busy / steps))
+if len(sys.argv) > 3:
+    try:
+        line = [l for l in open(sys.argv[3]) if l.startswith("{")][-1]
+        j = json.loads(line)
+        wl = j["work_list_rows_mean"]
+        print("# mean work-list rows per step (steady state, %d steps): foreground %.0f of %d (sdf_fwd2 / rendernet / sdf_bwd kernels), "
+              "background %.0f of %d (nerf kernels); bench line of this run: %.4f ms/step" % (
+                  wl["over_steps"], wl["foreground"], j["config"]["foreground_points_total"], wl["background"],
+                  j["config"]["background_points_total"], j["ms_per_step"]))
+        fg = wl["foreground"]
+        k = [v for n, v in by.items() if "sdf_fwd2_kernel<1, true" in n]
+        if k:
+            us = sum(k[0]) / len(k[0])
+            print("# fused SDF kernel: 1 967 104 FLOP/row x %.0f rows / %.1f us = %.1f TFLOP/s = %.3f of the 2.5 PFLOP/s bf16 MFMA peak" % (
+                fg, us, 1967104.0 * fg / us / 1e6, 1967104.0 * fg / us / 1e6 / 2500.0))
+    except Exception as e:          # the table itself does not depend on it
+        print("# (no bench line: %s)" % e)
 print("Name,Calls,CallsPerStep,AverageUs,MinUs,MaxUs,UsPerStep,Percentage")
 for name, v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
     print('"%s",%d,%.2f,%.1f,%.1f,%.1f,%.1f,%.2f' % (name, len(v), len(v) / steps, sum(v) / len(v), min(v), max(v), sum(v) / steps, 100.0 * sum(v) / busy))

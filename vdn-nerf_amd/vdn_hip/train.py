@@ -668,7 +668,17 @@ class TrainEngine:
         s.H, s.V, s.PE = w["H"].data_ptr(), w["V"].data_ptr(), w["PE"].data_ptr()
         if getattr(self, "_ray_grads", False):
             s.U_pe = w["U_pe"].data_ptr()
+        probe = getattr(self, "sdf_probe", None)
+        if probe is None:
+            lib.call("vdn_sdf_mlp_fwd" + self.sfx, 1, self._fg(s), _stream())
+            return
+        # bench.py's in-situ timing of the north-star kernel: HIP events on the launch stream right around THIS step's launch,
+        # with the step's row count (read back after the run)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         lib.call("vdn_sdf_mlp_fwd" + self.sfx, 1, self._fg(s), _stream())
+        e1.record()
+        probe.append((e0, e1, w["fg_active"][1].clone() if self._fg_compact else None))
 
     def _dw_rows(self):
         """Rows each weight-gradient entry contracts over in the current step (the work lists of the last forward)."""
