@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VDN_ABI_VERSION 21
+#define VDN_ABI_VERSION 22
 
 int vdn_abi_version(void);
 
@@ -54,6 +54,8 @@ typedef struct {
     const float* tail;       /* optional: tail_n floats copied to dst + tail_off (behind the bias block, inside the chunk's   */
     int32_t tail_off;        /* stride): a small constant that rides along with every chunk's DMA - the bf16 SDF streams carry */
     int32_t tail_n;          /* row 0 of the last layer's weight there (csrc/k_sdf_fwd2.h)                                    */
+    int32_t tail_stride;     /* distance between consecutive tail floats in `tail` (0 or 1: contiguous; the colour head's "c2" */
+                             /* stream carries one COLUMN of its first layer: stride = that matrix's row length)               */
 } VdnChunkDesc;
 int vdn_build_images(const VdnChunkDesc* descs_dev, int n_chunks, void* stream);
 
@@ -272,6 +274,19 @@ typedef struct {
     float* eik_out;            /* [3]: gradient_error, numerator, denominator */
 } VdnCompositeArgs;
 int vdn_alpha_composite_fwd(const VdnCompositeArgs* args_host, void* stream);
+
+/* ---- renderer.py:239-315 in ONE launch (the north-star kernel; bf16 path, inference): render_core's SDF network + analytic
+ * gradient (fields.py:72-108), the colour head (fields.py:148-176, mode 'idr', d_out = 3) and the NeuS alpha / background blend /
+ * transmittance scan / weighted sums of vdn_alpha_composite_fwd, for rays of exactly 128 inside samples: one 128-point workgroup
+ * evaluates one ray, keeps the 256-d feature vector in registers, runs the colour head on it and composites the ray from LDS; the
+ * ray that finishes last reduces the eikonal partial sums of all rays (`ticket`: one int32 arrival counter, zero before the first
+ * call; the kernel leaves it zero). sdf: mode-1 arguments in ray form (n_per_ray = 128, P = 128 * comp.B, no work list, no saves;
+ * sdf.feat may be NULL - the feature plane is only written when given, for a VDN head launched afterwards); color_blob: the colour
+ * network's "c2" stream; comp: as for vdn_alpha_composite_fwd with comp.N = 128 - comp.sdf / normals / color are not read and
+ * comp.feat_out must be NULL (the feature channels keep their own launches). Outputs equal the three launches' up to the rounding
+ * of the colour head's first layer (the normal's z component enters as an f32 term here, as a bf16 operand there). */
+int vdn_shade_fused_bf16(const VdnSdfArgs* sdf_host, const void* color_blob, int32_t squeeze_out, const VdnCompositeArgs* comp_host,
+                         int32_t* ticket, void* stream);
 
 /* The eikonal sums of renderer.py:313-315 alone - relax_inside_sphere * (|gradient| - 1)^2 and relax_inside_sphere, summed
  * per ray and over the batch, with the compositor's own expressions (same translation unit, bit-identical to the values

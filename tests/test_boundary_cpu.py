@@ -19,11 +19,11 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) >= 10
     for name in declared:
         assert hasattr(l, name), name
-    assert l.vdn_abi_version() == int(re.search(r"#define\s+VDN_ABI_VERSION\s+(\d+)", text).group(1)) == 21
+    assert l.vdn_abi_version() == int(re.search(r"#define\s+VDN_ABI_VERSION\s+(\d+)", text).group(1)) == 22
 
 
 def test_struct_layouts_are_c_layouts():
-    assert ctypes.sizeof(lib.VdnChunkDesc) == 104 and lib.struct_dtype("VdnChunkDesc").itemsize == 104
+    assert ctypes.sizeof(lib.VdnChunkDesc) == 112 and lib.struct_dtype("VdnChunkDesc").itemsize == 112
     assert ctypes.sizeof(lib.VdnWeightNormDesc) == 40
 
 

@@ -1,0 +1,111 @@
+"""The north-star kernel of the inference path: vdn_shade_fused_bf16 (csrc/k_sdf_fwd2.h MODE 2) = renderer.py:239-315 in ONE
+launch - SDF network + gradient sweep, colour head on the feature vector in registers, the ray's NeuS alpha / background blend /
+transmittance scan / weighted sums from LDS, the eikonal sums by the last ray - against the separate launches of the same
+bf16 path (SDF kernel, colour head, compositor, eikonal reduce) and against the reference's golden vectors.
+
+What must be equal bit for bit: everything that does not pass through the colour head - the SDF kernel's arithmetic is the same
+code (sdf, `gradients`), so `cdf_fine`, `inside_sphere`, `weights`, `weight_sum`, `weight_max`, `s_val`, `z_vals` and
+`gradient_error` (same partial sums, reduced in the same order by the last ray as by eikonal_reduce_kernel). The colour differs by
+the rounding of ONE input of the colour head's first layer: the normal's z component enters as an f32 term in the fused kernel
+and as a bf16 operand in rendernet_fwd_kernel."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def g(x, dev):
+    return torch.as_tensor(np.asarray(x), dtype=torch.float32).to(dev)
+
+
+def _render(rend, batch, fused, **kw):
+    os.environ["VDN_SHADE_FUSED"] = "1" if fused else "0"
+    try:
+        with torch.no_grad():
+            return rend.render(*batch, background_rgb=torch.ones(1, 3, device=batch[0].device), cos_anneal_ratio=0.5, **kw)
+    finally:
+        del os.environ["VDN_SHADE_FUSED"]
+
+
+def _batch(B, dev, seed=0, crop=None):
+    from vdn_train import synth
+    cams = synth.make_cameras(seed)
+    o, d = synth.random_pixel_batch(seed, 3, 2, B, cams=cams, crop=crop)
+    near, far = synth.near_far_from_sphere(o, d)
+    t1, t2 = synth.jitter(seed, 3, B)
+    return (g(o, dev), g(d, dev), g(near, dev), g(far, dev)), dict(t_rand=g(t1, dev), t_rand_out=g(t2, dev))
+
+
+EXACT = ("cdf_fine", "inside_sphere", "weights", "weight_sum", "weight_max", "s_val", "z_vals", "gradients", "gradient_error")
+
+
+@pytest.mark.parametrize("B,crop", [(1, None), (3, 420), (37, None), (512, None), (512, 420), (1000, 420)])
+def test_fused_shading_equals_the_separate_launches(B, crop):
+    from vdn_train import synth, factory
+    dev = torch.device("cuda:0")
+    rend = factory.build_renderer(device=dev, states=synth.make_all_states(0, variance=0.4), precision="bf16")
+    assert rend._fused_shading(128) and rend.shade_launches() == 1
+    batch, kw = _batch(B, dev, crop=crop)
+    ref = _render(rend, batch, False, **kw)
+    out = _render(rend, batch, True, **kw)
+    again = _render(rend, batch, True, **kw)             # the arrival counter was left at zero
+    assert set(out) == set(ref)
+    for k in EXACT:
+        assert torch.equal(out[k], ref[k]), k
+        assert torch.equal(out[k], again[k]), k
+    assert out["render_feats"] is None
+    # the colour: one bf16 rounding of one input apart (measured ~1e-4; the bf16 path's own error vs fp32 is ~1e-3)
+    assert float((out["color_fine"] - ref["color_fine"]).abs().max()) < 2e-3
+    assert torch.equal(out["color_fine"], again["color_fine"])
+    assert torch.isfinite(out["color_fine"]).all()
+
+
+@pytest.mark.parametrize("name,min_psnr", [("white_v03_c0", 55.0), ("white_v065_c1", 42.0), ("black_v03", 55.0)])
+def test_fused_shading_vs_reference_golden(golden, name, min_psnr):
+    """The reference's own outputs (tests/golden, fp32) at the bf16 path's bounds (tests/test_gpu_bf16.py), through the one launch."""
+    from vdn_train import synth, factory
+    dev = torch.device("cuda:0")
+    fx = golden(name)
+    st = synth.make_all_states(int(fx["seed"]), wdepth=False, variance=float(fx["variance"]))
+    rend = factory.build_renderer(device=dev, states=st, precision="bf16")
+    os.environ["VDN_SHADE_FUSED"] = "1"
+    try:
+        with torch.no_grad():
+            bg = torch.ones(1, 3, device=dev) if name.startswith("white") else None
+            out = rend.render(g(fx["rays_o"], dev), g(fx["rays_d"], dev), g(fx["near"], dev), g(fx["far"], dev), background_rgb=bg,
+                              cos_anneal_ratio=float(fx["cos_anneal"]), t_rand=g(fx["t_rand"], dev), t_rand_out=g(fx["t_rand_out"], dev),
+                              z_vals_inject=g(fx["z_vals_inside"], dev))
+    finally:
+        del os.environ["VDN_SHADE_FUSED"]
+    mse = float(((out["color_fine"].cpu().numpy() - fx["out_color_fine"]) ** 2).mean())
+    assert 10 * np.log10(1.0 / max(mse, 1e-20)) > min_psnr
+    assert np.abs(out["weight_sum"].cpu().numpy() - fx["out_weight_sum"]).max() < 2e-2
+    assert abs(out["gradient_error"].item() - float(fx["out_gradient_error"])) < 5e-2 * max(float(fx["out_gradient_error"]), 1e-2)
+
+
+def test_fused_shading_declines_what_it_does_not_cover():
+    """VDN head, other sample counts, fp32: the separate launches run (and the entry point itself answers -10 for N != 128)."""
+    from vdn_train import synth, factory
+    from vdn_hip import lib
+    dev = torch.device("cuda:0")
+    r = factory.build_renderer(wdepth=True, device=dev, states=synth.make_all_states(0, wdepth=True), precision="bf16")
+    assert not r._fused_shading(128) and r.shade_launches() == 6
+    r = factory.build_renderer(device=dev, states=synth.make_all_states(0), precision="fp32")
+    assert not r._fused_shading(128)
+    r = factory.build_renderer(device=dev, states=synth.make_all_states(0), precision="bf16", n_importance=0)
+    assert not r._fused_shading(64)
+    batch, kw = _batch(8, dev)
+    out = _render(r, batch, True, **kw)                  # 64 samples per ray: the separate launches
+    assert torch.isfinite(out["color_fine"]).all()
+    sa, cm = lib.VdnSdfArgs(), lib.VdnCompositeArgs()
+    z = torch.zeros(8, 64, device=dev)
+    sa.blob = r.sdf_network._images().blobs["full"].data_ptr()
+    sa.rays_o, sa.rays_d, sa.z, sa.sdf, sa.normals = batch[0].data_ptr(), batch[1].data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr()
+    sa.n_per_ray, sa.z_ld, sa.sdf_ld, sa.P, sa.scale = 64, 64, 64, 8 * 64, 1.0
+    cm.B, cm.N, cm.T = 8, 64, 96
+    t = torch.zeros(1, dtype=torch.int32, device=dev)
+    assert not lib.try_call("vdn_shade_fused_bf16", sa, lib.ptr(r.color_network._images().blobs["c2"]), 1, cm, lib.ptr(t),
+                            torch.cuda.current_stream().cuda_stream)

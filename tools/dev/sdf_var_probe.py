@@ -74,3 +74,34 @@ for i in range(540):
 situ = leg.sdf_in_situ(60)
 print("one-stream leg, in situ 60 steps: mean %.1f median %.1f min %.1f max %.1f us at %.0f rows" % (
     situ["kernel_ms"] * 1e3, situ["kernel_ms_median"] * 1e3, situ["kernel_ms_min"] * 1e3, situ["kernel_ms_max"] * 1e3, situ["points"]))
+
+# cold L2 / MALL? the step's launch alone, (a) back to back, (b) with 400 MB of unrelated stores between two launches (what the
+# background network's training forward leaves in the caches in front of it in the step), (c) with a 3-MB read of the kernel's
+# own weight stream by a tiny kernel right before it (torch sum over the blob: one XCD's L2 at best)
+eng = leg.trainer.engine
+o, d = leg.batches[0][0], leg.batches[0][1]
+eng.sdf_probe = None
+step_launch = lambda: eng._sdf_forward(o, d)
+trash = torch.empty(100 << 20, dtype=torch.float32, device=dev)
+blob = eng.nets["sdf"].img.blobs["full"]
+
+
+def timed(pre, n=20):
+    ts = []
+    for i in range(n):
+        pre()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        step_launch()
+        e1.record()
+        ts.append((e0, e1))
+    torch.cuda.synchronize()
+    return np.array([a.elapsed_time(b) for a, b in ts]) * 1e3
+
+
+for i in range(100):
+    leg.step(700 + i)
+print("one-stream leg, isolated work-list launch (%d rows):" % int(eng.w["fg_active"][1].item()))
+print("   back to back:                          ", fmt(timed(lambda: None)))
+print("   400 MB of stores in front of each:     ", fmt(timed(lambda: trash.zero_())))
+print("   400 MB of stores + blob read in front: ", fmt(timed(lambda: (trash.zero_(), blob.sum()))))

@@ -24,6 +24,7 @@
 #pragma once
 #include <cstdlib>
 #include "k_ray_rows.h"
+#include "k_composite_row.h"
 #include "mlp_engine.h"
 #include "vdn_kernels.h"
 
@@ -50,18 +51,21 @@ constexpr float kVSave = kC1 / 255.0f;        // 255 sigma u -> saved V plane (1
 constexpr int kSTiles = 63;             // softplus' tiles per point block: 8 + 8 + 8 + 7 + 8 + 8 + 8 + 8
 
 // ---- compile-time program of the chunk stream -------------------------------------------------------------------
-enum { HID = 0, LAST = 1, SWEEP = 2, SWEEP_SKIP = 3, SWEEP_PE = 4 };
+// COL0 / COLH / COLOUT (MODE 2): the colour head behind the sweep (fields.py:148-176): first layer [feature (8 tiles) | points,
+// PE4(view), normal x, y (1 tile)], three hidden ReLU layers, the 3-channel sigmoid output
+enum { HID = 0, LAST = 1, SWEEP = 2, SWEEP_SKIP = 3, SWEEP_PE = 4, COL0 = 5, COLH = 6, COLOUT = 7 };
 struct LayerDesc { int kind, kt, nt, l; };
 
 template <int MODE>
 struct Prog {
-    static constexpr int NL = MODE == 0 ? 9 : 17;
+    static constexpr int NL = MODE == 0 ? 9 : (MODE == 1 ? 17 : 22);
     static constexpr LayerDesc layer(int i) {
-        constexpr LayerDesc full[17] = {
+        constexpr LayerDesc full[22] = {
             {HID, 2, 8, 0}, {HID, 8, 8, 1}, {HID, 8, 8, 2}, {HID, 8, 7, 3}, {HID, 9, 8, 4}, {HID, 8, 8, 5}, {HID, 8, 8, 6}, {HID, 8, 8, 7},
             {LAST, 8, 9, 8},
             {SWEEP, 8, 8, 6}, {SWEEP, 8, 8, 5}, {SWEEP, 8, 8, 4}, {SWEEP_SKIP, 8, 9, 3}, {SWEEP, 7, 8, 2}, {SWEEP, 8, 8, 1}, {SWEEP, 8, 8, 0},
-            {SWEEP_PE, 8, 2, -1}};
+            {SWEEP_PE, 8, 2, -1},
+            {COL0, 9, 8, 0}, {COLH, 8, 8, 1}, {COLH, 8, 8, 2}, {COLH, 8, 8, 3}, {COLOUT, 8, 1, 4}};
         LayerDesc d = full[i];
         if (MODE == 0 && i == 8) d.nt = 1;
         return d;
@@ -72,6 +76,7 @@ struct Prog {
         return c;
     }
     static constexpr int total = first_chunk(NL);
+    static constexpr int sdf_total = first_chunk(MODE == 0 ? 9 : 17);      // chunks of the SDF network's stream; the colour head's follow in a blob of their own
     static constexpr int layer_of(int c) {
         int i = 0;
         while (i + 1 < NL && first_chunk(i + 1) <= c) ++i;
@@ -79,7 +84,7 @@ struct Prog {
     }
     static constexpr int tile_of(int c) { return c - first_chunk(layer_of(c)); }
     static constexpr int kt_of(int c) { return (c >= 0 && c < total) ? layer(layer_of(c)).kt : 0; }
-    static constexpr bool bias_of(int c) { return c >= 0 && c < total && layer(layer_of(c)).kind <= LAST; }
+    static constexpr bool bias_of(int c) { return c >= 0 && c < total && (layer(layer_of(c)).kind <= LAST || layer(layer_of(c)).kind >= COL0); }
     // first softplus' tile of hidden layer l
     static constexpr int s_tile0(int l) { return l <= 3 ? 8 * l : 8 * l - 1; }
 };
@@ -92,11 +97,12 @@ constexpr int tile_stores(int c) {
     if (c < 0 || c >= PG::total) return 0;
     const LayerDesc d = PG::layer(PG::layer_of(c));
     const int t = PG::tile_of(c);
+    constexpr bool TS = SAVE && MODE == 1;       // the training saves (MODE 2: SAVE = the feature plane is written, for the VDN head)
     switch (d.kind) {      // (two 16-byte stores per plane tile: BF16::kTileOps)
-        case HID: return SAVE ? 2 : 0;                                           // H plane tile
-        case LAST: return (MODE == 1 && t < 8) ? (SAVE ? 4 : 2) : 0;             // feature tile (+ V[7] tile)
-        case SWEEP: return SAVE ? 2 : 0;                                         // V[l]
-        case SWEEP_SKIP: return (SAVE && t < 7) ? 2 : 0;
+        case HID: return TS ? 2 : 0;                                             // H plane tile
+        case LAST: return t < 8 ? (MODE == 1 ? (SAVE ? 4 : 2) : (MODE == 2 && SAVE ? 2 : 0)) : 0;   // feature tile (+ V[7] tile)
+        case SWEEP: return TS ? 2 : 0;                                           // V[l]
+        case SWEEP_SKIP: return (TS && t < 7) ? 2 : 0;
         default: return 0;
     }
 }
@@ -136,9 +142,10 @@ VDN_DEV void glds16_saddr(const char* base_uniform, unsigned lane_off, char* lds
 }
 
 // ---- pipeline state ---------------------------------------------------------------------------------------------
-template <int NSLOT>
+template <int NSLOT, int SPLIT = (1 << 30)>
 struct Pipe {
     const char* g;      // weight stream (wave-uniform)
+    const char* g2;     // chunks from SPLIT on: a second stream (MODE 2: the colour head's)
     char* lds;          // ring base
     int wave, lane;
     unsigned lane16;    // lane * 16
@@ -151,7 +158,8 @@ struct Pipe {
     VDN_DEV void issue_piece() {
 #if !(VDN_SDF2_ABL & 4)
         const int piece = wave + I * kWaves;
-        glds16_saddr(g + ((long)C * kStride + piece * 1024), lane16, slot<C>() + piece * 1024);
+        if constexpr (C >= SPLIT) glds16_saddr(g2 + ((long)(C - SPLIT) * kStride + piece * 1024), lane16, slot<C>() + piece * 1024);
+        else glds16_saddr(g + ((long)C * kStride + piece * 1024), lane16, slot<C>() + piece * 1024);
 #endif
     }
     template <int C>
@@ -177,8 +185,8 @@ struct Pipe {
 // One chunk step: acc = (bias) + W[chunk C] . X over KT input tiles. group(gi, NG) = the VALU work assigned to MFMA
 // group gi of NG (kGroup MFMAs per group). Group 0 certifies chunk C+1; the DMA pieces of chunk C+DEPTH follow one per
 // group; the tail reads the opening fragments of chunk C+1.
-template <int MODE, bool SAVE, int NSLOT, int DEPTH, int C, class ActT, class Group>
-VDN_DEV f32x16 chunk_step(Pipe<NSLOT>& pp, const ActT& X, Group&& group) {
+template <int MODE, bool SAVE, int NSLOT, int DEPTH, int C, class PipeT, class ActT, class Group>
+VDN_DEV f32x16 chunk_step(PipeT& pp, const ActT& X, Group&& group) {
     using PG = Prog<MODE>;
     constexpr int KT = PG::kt_of(C);
     constexpr bool BIAS = PG::bias_of(C);
@@ -342,20 +350,34 @@ constexpr int pair_begin(int gi, int GA) { return gi >= GA ? 8 : gi * 8 / GA; }
 // UPS (MODE 0, ray form with 64 samples per ray): the first up-sampling round (renderer.py:147-191 on the coarse samples)
 // behind the pass - a 128-point workgroup is two rays, whose z / sdf rows go through LDS to upsample_row (k_ray_rows.h),
 // vdn_upsample_round's work without its launch.
+// MODE 2 (the north-star kernel of the inference path, reference renderer.py:239-315 in one launch): MODE 1 with the feature
+// vector kept in registers, then the colour head on the same 32 points per wave, then - a 128-point workgroup being exactly one
+// ray of 128 samples - the ray's NeuS alpha, background blend, transmittance scan and weighted sums (k_composite_row.h) by wave 0
+// on the samples handed over in LDS, and the eikonal sums of all rays by the ray that finishes last.
+struct ShadeExtra {
+    const char* color_blob;     // the colour head's chunk stream ("c2", vdn_hip/images.py), same chunk format and stride
+    int* ticket;                // [1] arrival counter, zero before the first launch (the last ray leaves it zero)
+    int squeeze_out;            // fields.py:170-171
+    CompositeArgs cm;           // sdf / normals / color are not read (the samples come through LDS)
+};
+
 template <int MODE, bool SAVE, int NSLOT, int DEPTH, int VID = 0, bool UPS = false>
-__global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kernel(SdfArgs a, UpsampleArgs up) {
+__global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kernel(SdfArgs a, UpsampleArgs up, ShadeExtra ex) {
     static_assert(!UPS || MODE == 0, "the up-sampling round follows the sdf-only pass");
     using PG = Prog<MODE>;
+    constexpr bool TS = SAVE && MODE == 1;          // training saves (H, V, PE planes)
+    constexpr bool FEAT = MODE == 1 || (MODE == 2 && SAVE);     // the feature plane goes to HBM
     using P = BF16;
     using ST = unsigned short;
     static_assert(NSLOT >= DEPTH + 1, "ring: the chunk being read, the one being opened and DEPTH-1 in flight");
     constexpr int kRing = NSLOT * kStride;
     constexpr int kW8 = 0;                             // (W8 row 0 rides in every chunk's tail: kTail)
-    constexpr int kLdsTotal = MODE == 1 ? 160 * 1024 : kRing + kW8;
-    constexpr int NLDS = MODE == 1 ? ((kLdsTotal - kRing - kW8) / (kWaves * 1024) < kSTiles ? (kLdsTotal - kRing - kW8) / (kWaves * 1024) : kSTiles) : 0;
+    constexpr int kLdsTotal = MODE >= 1 ? 160 * 1024 : kRing + kW8;
+    constexpr int NLDS = MODE >= 1 ? ((kLdsTotal - kRing - kW8) / (kWaves * 1024) < kSTiles ? (kLdsTotal - kRing - kW8) / (kWaves * 1024) : kSTiles) : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    Pipe<NSLOT> pp;
+    Pipe<NSLOT, MODE == 2 ? PG::sdf_total : (1 << 30)> pp;
     pp.g = a.blob;
+    pp.g2 = ex.color_blob;
     pp.lds = smem;
     pp.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     pp.lane = threadIdx.x & 63;
@@ -371,6 +393,7 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
     const long p = wr.row, pd = wr.point;
 
     float xin[3];
+    float px[3] = {0.0f, 0.0f, 0.0f}, dir[3] = {0.0f, 0.0f, 0.0f};     // MODE 2: the point and the view direction (the colour head's inputs)
     long sdf_idx = pd;
     float z_keep = 0.0f, sdf_keep = 0.0f;           // UPS: this point's depth and sdf for the up-sampling round
     if (a.pts != nullptr) {
@@ -384,6 +407,13 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
         sdf_idx = r * a.sdf_ld + sidx;
 #pragma unroll
         for (int d = 0; d < 3; ++d) xin[d] = (a.rays_o[r * 3 + d] + a.rays_d[r * 3 + d] * z) * a.scale;
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                dir[d] = a.rays_d[r * 3 + d];
+                px[d] = a.rays_o[r * 3 + d] + a.rays_d[r * 3 + d] * z;          // renderer.py:233
+            }
+        }
     }
     ST* Hs = reinterpret_cast<ST*>(a.H);
     ST* Vs = reinterpret_cast<ST*>(a.V);
@@ -394,6 +424,9 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ordinary loads above: nothing but DMA and stores from here on
 
     typename P::template Act<9> X, Y;
+    typename P::template Act<9> F;          // MODE 2: the feature vector as the colour head's input fragments (tiles 0..7) + its small tile (8)
+    float nz = 0.0f;                        // MODE 2: the normal's z component, the 33rd small input (an f32 rank-1 term in COL0's epilogue)
+    float col[3] = {0.0f, 0.0f, 0.0f};      // MODE 2: the sampled colour of this lane's point
     SStore<NLDS> SS;
     SS.lds = smem + kRing + kW8 + pp.wave * (NLDS * 1024) + lane * 16;
 
@@ -413,7 +446,7 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
         for (int i = 0; i < 25; ++i) pe[39 + i] = fmaf(pe39[i], kC1, -bf16_lo(pack_bf16x2(pe[i], 0.0f)));      // (the residue of the exact product)
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) X.set(kt, vals_tile<64>(pe, h, kt));
-        if constexpr (SAVE) {       // saved in the same scaled units as H and V (include/vdn_render.h: VdnSdfArgs); the residue
+        if constexpr (TS) {         // saved in the same scaled units as H and V (include/vdn_render.h: VdnSdfArgs); the residue
             if (a.PE != nullptr) {  // slots are saved as zeros (the weight-gradient GEMM contracts over the 39 encoded values)
 #pragma unroll
                 for (int i = 39; i < 64; ++i) pe[i] = 0.0f;
@@ -487,7 +520,7 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
                     u32x4 cur = __builtin_bit_cast(u32x4, D.r[T * 2 + (pr >> 2)]);
                     cur[pr & 3] = pk;
                     D.r[T * 2 + (pr >> 2)] = __builtin_bit_cast(bf16x8, cur);
-                    if constexpr (MODE == 1) {
+                    if constexpr (MODE >= 1) {
                         if constexpr ((pr & 1) == 0) {
                             hold0 = __builtin_bit_cast(unsigned, sp0.e);
                             hold1 = __builtin_bit_cast(unsigned, sp1.e);
@@ -496,15 +529,15 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
                             unsigned w = sigma255_pack(__builtin_bit_cast(float, hold0), __builtin_bit_cast(float, hold1), sp0.e, sp1.e);
                             asm volatile("" : "+v"(w));      // materialise here: otherwise the chain sinks to the tile's end
                             sq_prev[pr >> 1] = w;
-                            if constexpr (SAVE && (pr & 3) == 3)        // H plane piece k = pr >> 2 = this k-step's whole B fragment
+                            if constexpr (TS && (pr & 3) == 3)          // H plane piece k = pr >> 2 = this k-step's whole B fragment
                                 plane_store16(Hs + L.l * PS + prow + T * 1024 + 512 * (pr >> 2), cur);
                             if constexpr (pr == 7) SS.template put<PG::s_tile0(L.l) + T>(sq_prev);
                         }
                     }
                 });
             } else if constexpr (L.kind == LAST) {
-                if constexpr (MODE == 1 && T < 8) {
-                    // feature tile T to HBM; v7 tile T = (W8 row 0 / scale) (.) 255 sigma_7 -> Y (free while layer 8 reads X)
+                if constexpr (MODE >= 1 && T < 8) {
+                    // feature tile T to HBM (MODE 2: into F, the colour head's input fragments; to HBM only for a VDN head); v7 tile T = (W8 row 0 / scale) (.) 255 sigma_7 -> Y (free while layer 8 reads X)
                     static_for<PE_ - PB>([&](auto i_c) VDN_INL {
                         constexpr int pr = PB + decltype(i_c)::value;
                         if constexpr ((pr & 1) == 1) {
@@ -519,7 +552,8 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
                                 o[1] = fhold1;
                                 o[2] = pack_bf16x2(acc_prev[4 * q], acc_prev[4 * q + 1]);
                                 o[3] = pack_bf16x2(acc_prev[4 * q + 2], acc_prev[4 * q + 3]);
-                                plane_store16(feat + prow + T * 1024 + 512 * (q >> 1), o);
+                                if constexpr (FEAT) plane_store16(feat + prow + T * 1024 + 512 * (q >> 1), o);
+                                if constexpr (MODE == 2) F.r[T * 2 + (q >> 1)] = __builtin_bit_cast(bf16x8, o);      // (the piece IS the B fragment)
                             }
                             const f32x4 w = *(reinterpret_cast<const f32x4*>(pp.template slot<CP + 1>() + kTail) + (8 * T + 2 * q + h));
                             if constexpr (q == 0) sq_v7 = SS.template get<PG::s_tile0(7) + T>();
@@ -532,7 +566,7 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
                             cur[2 * (q & 1)] = k0;
                             cur[2 * (q & 1) + 1] = k1;
                             Y.r[T * 2 + (q >> 1)] = __builtin_bit_cast(bf16x8, cur);
-                            if constexpr (SAVE) {
+                            if constexpr (TS) {
                                 if constexpr ((q & 1) == 0) {
                                     vhold0 = pack_bf16x2(v0 * kVSave, v1 * kVSave);
                                     vhold1 = pack_bf16x2(v2 * kVSave, v3 * kVSave);
@@ -560,7 +594,7 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
                     u32x4 cur = __builtin_bit_cast(u32x4, D.r[T * 2 + (pr >> 2)]);
                     cur[pr & 3] = pk;
                     D.r[T * 2 + (pr >> 2)] = __builtin_bit_cast(bf16x8, cur);
-                    if constexpr (SAVE) {
+                    if constexpr (TS) {
                         // the V plane holds 100 log2(e) v, v = u (.) sigma: the units of H and PE
                         unsigned pv = pack_bf16x2(v0 * kVSave, v1 * kVSave);
                         if constexpr ((pr & 3) == 0) {
@@ -582,6 +616,29 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
                         }
                     }
                 });
+            } else if constexpr (L.kind == COL0 || L.kind == COLH) {
+                // colour head, hidden layers: ReLU, packed as the next layer's input fragments. COL0 adds the 33rd small input, the
+                // normal's z component, as an f32 rank-1 term: its weight column rides in every colour chunk's tail (f32 x 256)
+                static_for<PE_ - PB>([&](auto i_c) VDN_INL {
+                    constexpr int pr = PB + decltype(i_c)::value;
+                    float a0 = acc_prev[2 * pr], a1 = acc_prev[2 * pr + 1];
+                    if constexpr (L.kind == COL0) {
+                        if constexpr ((pr & 1) == 0) w8hold = *(reinterpret_cast<const f32x4*>(pp.template slot<CP + 1>() + kTail) + (8 * T + 2 * (pr >> 1) + h));
+                        a0 = fmaf(w8hold[2 * (pr & 1)], nz, a0);
+                        a1 = fmaf(w8hold[2 * (pr & 1) + 1], nz, a1);
+                    }
+                    unsigned pk = pack_bf16x2(relu0(a0), relu0(a1));
+                    asm volatile("" : "+v"(pk));
+                    u32x4 cur = __builtin_bit_cast(u32x4, D.r[T * 2 + (pr >> 2)]);
+                    cur[pr & 3] = pk;
+                    D.r[T * 2 + (pr >> 2)] = __builtin_bit_cast(bf16x8, cur);
+                });
+            } else if constexpr (L.kind == COLOUT) {
+                // rows 0..2 of the output tile = registers 0..2 of the h = 0 lanes (fields.py:166-171)
+                if constexpr (PB == 0) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) col[j] = ex.squeeze_out ? sigmoidf_(acc_prev[j]) : relu0(acc_prev[j]);
+                }
             }
         }
     };
@@ -603,7 +660,7 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
             // the MFMA group that reads the pending tile (k-steps 2 T', 2 T' + 1 of this layer's input)
             constexpr bool boundary = CP >= 0 && PG::layer_of(CPs) != LI;
             constexpr int KP = PG::layer(PG::layer_of(CPs)).kind;
-            constexpr bool prev_writes_input = boundary && (KP == HID || KP == SWEEP);
+            constexpr bool prev_writes_input = boundary && (KP == HID || KP == SWEEP || KP == COL0 || KP == COLH);
             constexpr int GA = prev_writes_input ? ((2 * PG::tile_of(CPs)) / kGroup < NG ? (2 * PG::tile_of(CPs)) / kGroup : NG) : NG;
             static_assert(GA >= 1, "a pending tile needs at least one MFMA group before its reader");
             if constexpr (L.kind == HID && L.l == 4 && T == 0) { X.r[14] = pe7[0]; X.r[15] = pe7[1]; }
@@ -611,7 +668,7 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
             constexpr bool sweep_tile = L.kind == SWEEP || (L.kind == SWEEP_SKIP && T < 7);
             u32x4 sq_next;
             if constexpr (sweep_tile) sq_next = SS.template get<PG::s_tile0(L.l) + T>();
-            const auto& Xin = (LI & 1) ? Y : X;
+            const auto& Xin = L.kind == COL0 ? F : ((LI & 1) ? Y : X);
             const f32x16 acc_cur = chunk_step<MODE, SAVE, NSLOT, DEPTH, C>(pp, Xin, [&](auto g_c, auto) VDN_INL {
                 constexpr int gi = decltype(g_c)::value;
                 epilogue(std::integral_constant<int, CP>{}, std::integral_constant<int, pair_begin(gi, GA)>{},
@@ -630,16 +687,84 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
             acc_prev = acc_cur;
             if constexpr (sweep_tile) sq_prev = sq_next;
             if constexpr ((L.kind == SWEEP_SKIP && T == 8) || (L.kind == SWEEP_PE && T == 1)) pe_backward(L.kind == SWEEP_SKIP);
+            if constexpr (MODE == 2 && L.kind == SWEEP_PE && T == 1) {
+                // the normal is complete: the colour head's small input tile [points (3), PE4(view) (27), normal x, y] (fields.py:154;
+                // k order of the "c2" stream), z component kept in f32
+                float small[32], pe[27];
+                posenc<3, 4, P::kAccurateTrig>(dir, pe);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) small[d] = px[d];
+#pragma unroll
+                for (int i = 0; i < 27; ++i) small[3 + i] = pe[i];
+                small[30] = n[0] * a.scale;
+                small[31] = n[1] * a.scale;
+                nz = n[2] * a.scale;
+                F.set(8, vals_tile<32>(small, h, 0));
+            }
         } else {
             // drain: the last chunk's tile (MODE 0: nothing is pending, the sdf row was stored above)
             epilogue(std::integral_constant<int, CP>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
         }
         __builtin_amdgcn_sched_barrier(0);
     });
-    if constexpr (MODE == 1) {
+    if constexpr (MODE >= 1) {
         if (ok && h == 0) {
 #pragma unroll
             for (int d = 0; d < 3; ++d) a.normals[pd * 3 + d] = n[d] * a.scale;
+        }
+    }
+    if constexpr (MODE == 2) {
+        // this workgroup's 128 points are the 128 samples of ray blockIdx.x: hand them to wave 0 through LDS (the weight ring is
+        // free behind the barrier) and composite there; rows = [7][128] floats: sdf | normal x, y, z | colour r, g, b
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        float* rows = reinterpret_cast<float*>(smem);
+        if (h == 0) {
+            const int i = pp.wave * 32 + c;
+            rows[i] = sdf_keep;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                rows[(1 + d) * 128 + i] = n[d] * a.scale;
+                rows[(4 + d) * 128 + i] = col[d];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (pp.wave != 0) return;
+        const int ray = blockIdx.x;
+        CompositeArgs cm = ex.cm;
+        float* eik_partial = cm.eik_partial;
+        cm.eik_partial = nullptr;                   // (stored below, write-through, ahead of the arrival count)
+        const EikPair ep = composite_row(cm, ray, lane, CompositeLdsSrc{rows, 128}, rows + 7 * 128, rows + 7 * 128 + kMaxT);
+        // gradient_error = sum(num) / (sum(den) + 1e-5) over ALL rays (renderer.py:313-315) without a launch of its own: every ray
+        // publishes its partial sums (one 8-byte write-through store, drained) and then counts itself in; the ray whose count comes
+        // back last reads all partials (sc1 loads: served by L2 / memory, never by this CU's L1) and reduces them exactly as
+        // eikonal_reduce_kernel does (lane-strided double sums, then the wave sum): the same bits as the separate launch.
+        int old = 0;
+        if (lane == 0) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 pv = {ep.num, ep.den};
+            asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" ::"v"(eik_partial + 2 * ray), "v"(pv) : "memory");
+            old = __hip_atomic_fetch_add(ex.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old == cm.B - 1) {
+            double sn = 0.0, sd = 0.0;
+            for (int i = lane; i < cm.B; i += 64) {
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                f32x2 v;
+                asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(eik_partial + 2 * i) : "memory");
+                sn += (double)v[0];
+                sd += (double)v[1];
+            }
+            sn = wave_sum(sn);
+            sd = wave_sum(sd);
+            if (lane == 0) {
+                cm.eik_out[0] = (float)sn / ((float)sd + 1e-5f);
+                cm.eik_out[1] = (float)sn;
+                cm.eik_out[2] = (float)sd;
+                __hip_atomic_store(ex.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
     if constexpr (UPS) {
@@ -666,8 +791,8 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
 }
 
 template <int MODE, bool SAVE, int NSLOT, int DEPTH, int VID = 0, bool UPS = false>
-int launch(const VdnSdfArgs* args, hipStream_t stream, const VdnUpsampleArgs* up = nullptr) {
-    constexpr size_t lds_min = MODE == 1 ? 160 * 1024 : NSLOT * kStride;
+int launch(const VdnSdfArgs* args, hipStream_t stream, const VdnUpsampleArgs* up = nullptr, const ShadeExtra* ex = nullptr) {
+    constexpr size_t lds_min = MODE >= 1 ? 160 * 1024 : NSLOT * kStride;
     constexpr size_t lds_solo = 96 * 1024;          // more than half a CU's LDS: one workgroup per CU
     static bool once = (allow_big_lds(sdf_fwd2_kernel<MODE, SAVE, NSLOT, DEPTH, VID, UPS>, lds_min > lds_solo ? lds_min : lds_solo), true);
     (void)once;
@@ -679,7 +804,7 @@ int launch(const VdnSdfArgs* args, hipStream_t stream, const VdnUpsampleArgs* up
     static const bool solo = [] { const char* e = getenv("VDN_SDF0_SOLO"); return e != nullptr && e[0] == '1'; }();
     const size_t lds = (MODE == 0 && solo && grid <= 256) ? lds_solo : lds_min;
     hipLaunchKernelGGL((sdf_fwd2_kernel<MODE, SAVE, NSLOT, DEPTH, VID, UPS>), dim3(grid), dim3(kWaves * 64), lds, stream, *args,
-                       up != nullptr ? *up : VdnUpsampleArgs{});
+                       up != nullptr ? *up : VdnUpsampleArgs{}, ex != nullptr ? *ex : ShadeExtra{});
     return (int)hipGetLastError();
 }
 

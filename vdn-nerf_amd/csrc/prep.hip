@@ -96,7 +96,8 @@ __global__ void build_images_kernel(const ChunkDesc* descs) {
     }
     if (d.tail != nullptr && d.write_bias) {
         float* t = reinterpret_cast<float*>(d.dst + d.tail_off);
-        for (int i = threadIdx.x; i < d.tail_n; i += blockDim.x) t[i] = d.tail[i];
+        const long ts = d.tail_stride > 1 ? d.tail_stride : 1;
+        for (int i = threadIdx.x; i < d.tail_n; i += blockDim.x) t[i] = d.tail[i * ts];
     }
 }
 

@@ -10,6 +10,8 @@ Extra, optional keyword arguments (not in the reference): `t_rand` [B,1] and `t_
 [B,n_outside] inject the two uniform draws of renderer.py:348,355; `z_vals_inject` [B,N] skips the
 hierarchical sampler. They exist for parity tests (hard part 6).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -336,12 +338,14 @@ class NeuSRenderer:
         bg_density, bg_rgb, bg_feat, bg_dists, bg_mid = bg if bg is not None else (None,) * 5
         O = 0 if bg is None else bg_dists.shape[1] - N
         T = N + O
-        sdf, feat, normals = self.sdf_network._run(1, rays=(rays_o, rays_d, mid_z))          # renderer.py:239-243
+        fused = self._fused_shading(N, depth_before_color)
         sampled_feat = None
-        if self.depth_network is not None:                                       # renderer.py:245-249
-            sampled_feat = self.depth_network._run(normals, feat, rays=(rays_o, rays_d, mid_z))
-        sampled_color = self.color_network._run(normals, feat, rays=(rays_o, rays_d, mid_z),        # renderer.py:247-251
-                                                extra=sampled_feat if depth_before_color else None)
+        if not fused:
+            sdf, feat, normals = self.sdf_network._run(1, rays=(rays_o, rays_d, mid_z))          # renderer.py:239-243
+            if self.depth_network is not None:                                       # renderer.py:245-249
+                sampled_feat = self.depth_network._run(normals, feat, rays=(rays_o, rays_d, mid_z))
+            sampled_color = self.color_network._run(normals, feat, rays=(rays_o, rays_d, mid_z),        # renderer.py:247-251
+                                                    extra=sampled_feat if depth_before_color else None)
 
         a = lib.VdnCompositeArgs()
         f32 = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
@@ -349,8 +353,10 @@ class NeuSRenderer:
         color, wsum, wmax, s_val = f32(B, 3), f32(B, 1), f32(B, 1), f32(B, 1)
         eik_partial, eik = f32(B, 2), f32(3)
         feat_out = f32(B, 96) if sampled_feat is not None else None
-        a.rays_o, a.rays_d, a.sdf, a.normals = rays_o.data_ptr(), rays_d.data_ptr(), sdf.data_ptr(), normals.data_ptr()
-        a.dists, a.mid_z, a.color = dists.data_ptr(), mid_z.data_ptr(), sampled_color.data_ptr()
+        a.rays_o, a.rays_d = rays_o.data_ptr(), rays_d.data_ptr()
+        a.dists, a.mid_z = dists.data_ptr(), mid_z.data_ptr()
+        if not fused:
+            a.sdf, a.normals, a.color = sdf.data_ptr(), normals.data_ptr(), sampled_color.data_ptr()
         a.variance = self.deviation_network.variance.data_ptr()
         if sampled_feat is not None:
             a.feat, a.feat_out, a.feat_ch = sampled_feat.data_ptr(), feat_out.data_ptr(), 96
@@ -371,7 +377,24 @@ class NeuSRenderer:
         a.weights, a.alpha_out, a.cdf, a.inside_sphere = weights.data_ptr(), alpha.data_ptr(), cdf.data_ptr(), inside.data_ptr()
         a.color_out, a.weight_sum, a.weight_max, a.s_val = color.data_ptr(), wsum.data_ptr(), wmax.data_ptr(), s_val.data_ptr()
         a.eik_partial, a.eik_out = eik_partial.data_ptr(), eik.data_ptr()
-        lib.call("vdn_alpha_composite_fwd", a, st)
+        if fused:
+            # renderer.py:239-315 in one launch (csrc/k_sdf_fwd2.h MODE 2): a 128-point workgroup is one ray - SDF network +
+            # gradient sweep, the colour head on the feature vector in registers, the ray's compositing from LDS, the eikonal sums
+            # by the last ray
+            sn = self.sdf_network
+            sa = lib.VdnSdfArgs()
+            sa.blob = sn._images().blobs["full"].data_ptr()
+            sa.rays_o, sa.rays_d, sa.z = rays_o.data_ptr(), rays_d.data_ptr(), mid_z.data_ptr()
+            sa.n_per_ray, sa.z_ld, sa.sdf_ld, sa.P, sa.scale = N, mid_z.stride(0), N, B * N, float(sn.scale)
+            sdf, normals = f32(B * N), f32(B * N, 3)
+            sa.sdf, sa.normals = sdf.data_ptr(), normals.data_ptr()
+            ticket = self.__dict__.get("_shade_ticket")
+            if ticket is None or ticket.device != dev:
+                ticket = self.__dict__["_shade_ticket"] = torch.zeros(1, dtype=torch.int32, device=dev)
+            cn = self.color_network
+            lib.call("vdn_shade_fused_bf16", sa, lib.ptr(cn._images().blobs["c2"]), int(cn.squeeze_out), a, lib.ptr(ticket), st)
+        else:
+            lib.call("vdn_alpha_composite_fwd", a, st)
 
         self.last_eikonal_terms = eik[1:3]      # (numerator, denominator) for the data-parallel reduction
         return {
@@ -387,6 +410,21 @@ class NeuSRenderer:
             "gradient_error": eik[0],
             "inside_sphere": inside,
         }
+
+    def _fused_shading(self, N, depth_before_color=False):
+        """True where vdn_shade_fused_bf16 covers the configuration: bf16 kernels, rays of exactly 128 inside samples (one
+        workgroup per ray), the shipped 'idr' colour head (d_feature 256, d_out 3), no VDN head (its 96 channels keep their own
+        launches). VDN_SHADE_FUSED=0 forces the separate launches (SDF / colour / compositor / eikonal reduce)."""
+        cn, sn = self.color_network, self.sdf_network
+        return (os.environ.get("VDN_SHADE_FUSED", "1") != "0" and N == 128 and self.depth_network is None and not depth_before_color
+                and sn.precision == "bf16" and cn.precision == "bf16" and cn.conf.get("mode") == "idr"
+                and cn.conf.get("d_feature") == 256 and cn.conf.get("d_out") == 3)
+
+    def shade_launches(self):
+        """Launches of _shade (renderer.py:239-315) on the current configuration, for the bench's C2 leg."""
+        if self._fused_shading(self.n_samples + self.n_importance):
+            return 1
+        return 4 + (2 if self.depth_network is not None else 0)      # SDF, colour, compositor, eikonal reduce (+ VDN head, its compositor)
 
     def plan(self, batch, **render_kwargs):
         """A replayable whole-batch render() for `batch` rays with fixed keyword arguments -> RenderPlan."""

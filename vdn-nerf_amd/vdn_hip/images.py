@@ -28,7 +28,7 @@ def chunk_stride(kt_max, fmt=FMT_F32):
 
 
 # largest contraction width (in 32-wide tiles) each kernel's stream is laid out for (must match the kernels)
-STREAM_KT_MAX = {"sdf": 9, "full": 9, "fbar": 9}
+STREAM_KT_MAX = {"sdf": 9, "full": 9, "fbar": 9, "c2": 9}
 
 
 def _pad32(n):
@@ -54,7 +54,9 @@ class Layer:
         self.scale = float(scale)
         self.bias_scale = float(bias_scale)
         self.transposed = transposed
-        self.tail = tail            # (matrix name, byte offset inside the chunk, floats): leading floats of that effective weight
+        # (matrix name, byte offset inside the chunk, floats[, first element, stride]): floats of that effective weight - by
+        # default its leading ones (row 0); with (first, stride) every stride-th from `first` on (stride = row length: a column)
+        self.tail = tail
 
     @property
     def kt(self):
@@ -119,7 +121,7 @@ class NetImages:
         maps, map_off = [], 0
         chunk_rows = []
         for sname, layers in streams.items():
-            if sname.startswith("_"):
+            if sname.startswith("_") or (sname == "c2" and fmt != FMT_BF16):     # ("c2" is the bf16 fused kernel's format)
                 continue
             kt_max = max(L.kt for L in layers)
             kt_max = max(kt_max, STREAM_KT_MAX.get(sname, 0))
@@ -178,8 +180,10 @@ class NetImages:
             ch[i]["scale"] = L.scale
             ch[i]["bias_scale"] = L.bias_scale
             if L.tail is not None:
-                tname, toff, tn = L.tail
-                ch[i]["tail"], ch[i]["tail_off"], ch[i]["tail_n"] = self.weff.data_ptr() + 4 * self.w_off[tname], toff, tn
+                tname, toff, tn = L.tail[:3]
+                first, tstride = (L.tail[3], L.tail[4]) if len(L.tail) > 3 else (0, 1)
+                ch[i]["tail"], ch[i]["tail_off"], ch[i]["tail_n"] = self.weff.data_ptr() + 4 * (self.w_off[tname] + first), toff, tn
+                ch[i]["tail_stride"] = tstride
             ch[i]["fmt"] = self.fmt
             ch[i]["kt_begin"], ch[i]["kt_count"], ch[i]["write_bias"] = kt0, ktc, int(first)
         self.wn_table = torch.from_numpy(wn.view(np.uint8)).to(self.device)
@@ -342,7 +346,20 @@ def rendering_streams(d_feature, mode, d_in, d_out, d_hidden, n_layers, multires
     bwd = [transposed_layer("lin4", ident_map(256), nm4)]
     bwd += [transposed_layer("lin%d" % l, ident_map(256), ident_map(256)) for l in (3, 2, 1)]
     bwd.append(transposed_layer("lin0", km0, ident_map(256)))
-    return {"fwd": layers, "bwd": bwd}
+    st = {"fwd": layers, "bwd": bwd}
+    if d_feature == 256 and mode == "idr" and 1 <= d_out <= 4:
+        # "c2": the colour head behind the fused SDF kernel (csrc/k_sdf_fwd2.h MODE 2), in that kernel's chunk format (9 k-tiles,
+        # 20-KiB stride): the first layer contracts [feature (256) | points, PE(view), normal x, y (32)]; the 33rd small input - the
+        # normal's z component - is an f32 rank-1 term in the kernel's epilogue, its weight column (source column 32 of lin0) rides
+        # in every chunk's tail like row 0 of W8 does in the SDF streams
+        c2 = [dense_layer("lin0", np.concatenate([km0[:256], km0[256:288]]), ident_map(256))]
+        c2 += [dense_layer("lin%d" % l, ident_map(256), ident_map(256)) for l in (1, 2, 3)]
+        c2.append(dense_layer("lin4", ident_map(256), nm4))
+        n_in = 33 + 256                       # row length of lin0's effective weight
+        for L in c2:
+            L.tail = ("lin0", SDF_TAIL_OFF, 256, int(km0[288]), n_in)
+        st["c2"] = c2
+    return st
 
 
 def nerf_streams(D, W, d_in, d_in_view, multires, multires_view, skips, rgb_dims, gen_depth_feats, dpt_dim):
