@@ -24,11 +24,13 @@ ap.add_argument("--checkpoints", type=int, default=10)
 ap.add_argument("--cross", action="store_true")
 ap.add_argument("--out", default=None)
 ap.add_argument("--grid", type=int, default=64)
+ap.add_argument("--seed", type=int, default=0, help="initial weights (torch.manual_seed) and pixel stream")
+ap.add_argument("--quiet", action="store_true", help="only the summary line")
 args = ap.parse_args()
 steps, prec = args.steps, args.precision
 dev = torch.device("cuda:0")
-torch.manual_seed(0)
-B, seed = 512, 0
+torch.manual_seed(args.seed)
+B, seed = 512, args.seed
 # geometric init exactly as the reference constructs it (fields.py:45-63); no synthetic perturbation
 rend = factory.build_renderer(device=dev, precision=prec)
 # shortened schedule so that a few thousand steps cover warm-up and annealing
@@ -98,12 +100,13 @@ for it in range(steps):
             rec["val_psnr_sd_on_%s_kernels" % oprec] = float(np.std(po))
         log.append(rec)
         line = json.dumps(rec)
-        print(line, flush=True)
+        if not args.quiet:
+            print(line, flush=True)
         if out_f:
             out_f.write(line + "\n")
             out_f.flush()
 last = [r["val_psnr_mean"] for r in log[-3:]]
-summary = {"precision": prec, "steps": steps, "views": HELD, "final_val_psnr_mean": log[-1]["val_psnr_mean"], "final_val_psnr_sd": log[-1]["val_psnr_sd"],
+summary = {"precision": prec, "steps": steps, "seed": args.seed, "views": HELD, "final_val_psnr_mean": log[-1]["val_psnr_mean"], "final_val_psnr_sd": log[-1]["val_psnr_sd"],
            "mean_of_last_3_checkpoints": float(np.mean(last)), "final_train_psnr": log[-1]["train_psnr"], "wall_s": time.time() - t0}
 print(json.dumps(summary))
 if out_f:
