@@ -101,12 +101,21 @@ typedef struct {
      * normal = scale * J_PE(x)^T u (fields.py:97-108) - what the ray adjoint needs for the explicit x-dependence of
      * J_PE (learnable poses, poses.py:198-208). Rows follow the saves (compact with a work list). */
     float* U_pe;               /* [P,39] or NULL */
+    /* optional (bf16 entry points, mode 1 with a work list): the TAIL of the list. The 128-row kernel runs whole rounds of 256
+     * workgroups (one per CU); when the list ends within tail_max_rows rows behind tail_row0 (a multiple of 128, normally one
+     * full round = 32 768), vdn_sdf_mlp_fwd_bf16 leaves the rows from tail_row0 on alone and vdn_sdf_fwd_tail_bf16 - called with
+     * the SAME struct - evaluates them with 32-row workgroups (csrc/k_sdf_fwd1_split.h): same planes, same values, bit for bit.
+     * Both decide on the device-side row count, so both launches are always made. tail_max_rows = 0: off. */
+    int32_t tail_row0, tail_max_rows;
 } VdnSdfArgs;
 int vdn_sdf_mlp_fwd_f32(int mode, const VdnSdfArgs* args_host, void* stream);
 /* bf16-MFMA variant (csrc/k_sdf_fwd2.h): blob holds bf16 chunks (fmt 1) of the SCALED streams (vdn_hip/images.py:
  * sdf_streams(scaled=True): hidden biases x 100 log2 e, last layer's weights / (100 log2 e), sweep weights / 255);
  * feat / H / V / PE are bf16 arrays in the tile-blocked layout of csrc/mlp_engine.h; sdf / normals stay f32. */
 int vdn_sdf_mlp_fwd_bf16(int mode, const VdnSdfArgs* args_host, void* stream);
+/* mode 1 (+ training saves when H is given) on rows [tail_row0, n) of the work list - see VdnSdfArgs.tail_row0; with
+ * tail_row0 = 0 and tail_max_rows >= P it evaluates every row (tests). U_pe must be NULL (-10). */
+int vdn_sdf_fwd_tail_bf16(const VdnSdfArgs* args_host, void* stream);
 
 /* ---- RenderingNetwork (colour head / 96-channel VDN head): fields.py:148-176, mode 'idr' ------
  * points are regenerated as rays_o[r] + rays_d[r]*z[p] (renderer.py:233), r = p / n_per_ray. */

@@ -335,6 +335,53 @@ def test_determinism(env, dev, golden):
         assert torch.equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("B,row0,crop", [(512, 32768, None), (512, 16384, None), (300, 4096, None), (64, 0, 420), (512, 32768, 420)])
+def test_sdf_tail_kernel_equals_the_large_kernel_bit_for_bit(monkeypatch, B, row0, crop):
+    """bf16 training forward: the rows behind `row0` of the foreground work list evaluated by the 32-row feature-split kernel
+    (vdn_sdf_fwd_tail_bf16, csrc/k_sdf_fwd1_split.h) instead of by the 128-row kernel - sdf, normals, the feature plane and every
+    saved plane (H, V, PE) of every listed row, bit for bit; full batches, a ragged one, a list that ends in front of row0 (no tail),
+    a crop whose list is the whole batch (the tail would be longer than its limit: the large kernel keeps every row)."""
+    from vdn_train import synth, factory
+    from vdn_hip.train import TrainEngine
+    from vdn_hip import layout
+    dev = torch.device("cuda:0")
+    seed = 21
+    st = synth.make_all_states(seed)
+    cams = synth.make_cameras(seed)
+    o, d = synth.random_pixel_batch(seed, 0, 5, B, cams=cams, crop=crop)
+    near, far = synth.near_far_from_sphere(o, d)
+    t1, t2 = synth.jitter(seed, 0, B)
+    o, d, near, far, t1, t2 = (torch.tensor(x).to(dev) for x in (o, d, near, far, t1, t2))
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("VDN_SDF_TAIL", mode)
+        monkeypatch.setenv("VDN_SDF_TAIL_ROW0", str(row0))
+        monkeypatch.setenv("VDN_SDF_TAIL_MAX", "40000" if row0 != 32768 else "8192")
+        rend = factory.build_renderer(device=dev, states=st, precision="bf16")
+        eng = TrainEngine(rend, B, dev)
+        with torch.no_grad():
+            z, z_out = rend._sample(o, d, near.reshape(B), far.reshape(B), 1.0, t1, t2, None)
+        for k in ("H", "V", "PE", "feat"):
+            eng.w[k].zero_()
+        eng.forward(o, d, z.contiguous(), z_out, torch.ones(3, device=dev), 0.3, skip_far=True)
+        torch.cuda.synchronize()
+        n = int(eng.w["fg_active"][1].item())
+        idx = eng.w["fg_active"][0][:n].long()
+        planes = {"sdf": eng.w["sdf"][idx].clone(), "normals": eng.w["normals"][idx].clone(),
+                  "feat": layout.from_pt32(eng.w["feat"], eng.Pp, 256)[:n], "PE": layout.from_pt32(eng.w["PE"], eng.Pp, 64)[:n]}
+        for l in range(8):
+            planes["H%d" % l] = layout.from_pt32(eng.w["H"][l], eng.Pp, 256)[:n]
+            planes["V%d" % l] = layout.from_pt32(eng.w["V"][l], eng.Pp, 256)[:n]
+        res[mode] = (n, planes, {k: eng.w[k].clone() for k in ("color", "weights")})
+    (n0, p0, o0), (n1, p1, o1) = res["0"], res["1"]
+    assert n0 == n1 and n0 > 0
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), (k, n0, (p0[k].float() - p1[k].float()).abs().max().item())
+        assert torch.isfinite(p0[k]).all()
+    for k in o0:
+        assert torch.equal(o0[k], o1[k]), k
+
+
 def test_on_device_ray_generator(dev):
     """vdn_train.rays.RaysGenerator against the formulas of poses.py:168-212 / dataset.py:111-118 (numpy, float64)."""
     from vdn_train import synth

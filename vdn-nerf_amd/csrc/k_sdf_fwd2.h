@@ -405,6 +405,13 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
     const int lane = pp.lane, c = lane & 31, h = lane >> 5;
     const WorkRow wr = work_row(a.active_idx, a.n_active, a.P, kWaves, pp.wave, c);
     if (wr.none) return;
+    if constexpr (MODE == 1) {
+        // the list's tail is vdn_sdf_fwd_tail_bf16's (k_sdf_fwd1_split.h) when it ends within tail_max_rows behind tail_row0
+        if (a.tail_max_rows > 0) {
+            const long n_rows = a.active_idx != nullptr ? (long)*a.n_active : (long)a.P;
+            if (n_rows > a.tail_row0 && n_rows - a.tail_row0 <= a.tail_max_rows && (long)blockIdx.x * (kWaves * 32) >= a.tail_row0) return;
+        }
+    }
 #ifdef VDN_SDF2_STAMP      // development harness: shader-clock and 100-MHz stamps of the workgroup, into the (otherwise unused) PE buffer
     const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long stamp_p1 = 0, stamp_p2 = 0;     // end of the hidden layers / of the last layer

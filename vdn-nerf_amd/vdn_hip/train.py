@@ -668,15 +668,31 @@ class TrainEngine:
         s.H, s.V, s.PE = w["H"].data_ptr(), w["V"].data_ptr(), w["PE"].data_ptr()
         if getattr(self, "_ray_grads", False):
             s.U_pe = w["U_pe"].data_ptr()
+        # The tail of the work list (bf16): the 128-row kernel runs whole rounds of one workgroup per CU, so ~37 K rows cost two
+        # rounds; when the list ends within VDN_SDF_TAIL_MAX rows behind the last full round, those rows go to the 32-row
+        # feature-split kernel instead (csrc/k_sdf_fwd1_split.h: same planes, bit for bit; both launches decide on the device-side
+        # row count). VDN_SDF_TAIL=0: off. (Not with ray gradients: the tail kernel does not write U_pe.)
+        tail = (self.precision == "bf16" and self._fg_compact and os.environ.get("VDN_SDF_TAIL", "1") != "0"
+                and not getattr(self, "_ray_grads", False))
+        if tail:
+            row0 = int(os.environ.get("VDN_SDF_TAIL_ROW0", str(128 * torch.cuda.get_device_properties(self.dev).multi_processor_count)))
+            tail = self.P > row0
+            if tail:
+                s.tail_row0, s.tail_max_rows = row0, int(os.environ.get("VDN_SDF_TAIL_MAX", "8192"))
+
+        def launch():
+            lib.call("vdn_sdf_mlp_fwd" + self.sfx, 1, self._fg(s), _stream())
+            if tail:
+                lib.call("vdn_sdf_fwd_tail_bf16", s, _stream())
         probe = getattr(self, "sdf_probe", None)
         if probe is None:
-            lib.call("vdn_sdf_mlp_fwd" + self.sfx, 1, self._fg(s), _stream())
+            launch()
             return
         # bench.py's in-situ timing of the north-star kernel: HIP events on the launch stream right around THIS step's launch,
         # with the step's row count (read back after the run)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        lib.call("vdn_sdf_mlp_fwd" + self.sfx, 1, self._fg(s), _stream())
+        launch()
         e1.record()
         probe.append((e0, e1, w["fg_active"][1].clone() if self._fg_compact else None))
 
