@@ -102,3 +102,35 @@ def test_stream_plans_are_consistent():
     assert [len(L.chunks) for L in n] == [8, 8, 8, 8, 8, 8, 8, 8, 9, 4, 4]
     r = images.rendering_streams(256, "idr", 9, 96, 256, 4, 4)["fwd"]
     assert [L.kt for L in r] == [10, 8, 8, 8, 8] and len(r[-1].chunks) == 3
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_chunk_tables_cover_every_chunk_once(precision):
+    """The descriptor tables of vdn_build_images, built on the host (no GPU needed): every chunk of every stream gets its
+    bias / pad block from exactly ONE descriptor, its k-tiles from descriptors that tile the contraction width without
+    overlap, and the streams that carry a tail (row 0 of W8 in the scaled SDF streams, the normal-z column in the colour
+    head's "c2" stream) carry it in every chunk."""
+    rend = factory.build_renderer(wdepth=True, device="cpu", states=synth.make_all_states(2, wdepth=True), precision=precision)
+    fmt = images.FMT_F32 if precision == "fp32" else images.FMT_BF16
+    for net in (rend.sdf_network, rend.color_network, rend.depth_network, rend.nerf):
+        im = images.NetImages(net._matrices(), net._streams(), torch.device("cpu"), fmt)
+        im._build_tables()
+        ch = np.frombuffer(im.chunk_table.numpy().tobytes(), dtype=lib.struct_dtype("VdnChunkDesc"))
+        by_dst = {}
+        for d in ch:
+            by_dst.setdefault(int(d["dst"]), []).append(d)
+        for dst, ds in by_dst.items():
+            assert sum(int(d["write_bias"]) for d in ds) == 1, (type(net).__name__, precision)
+            kt = int(ds[0]["k_pad"]) // 32
+            cover = sorted((int(d["kt_begin"]), int(d["kt_count"]) or kt) for d in ds)
+            assert cover[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(cover, cover[1:])) and cover[-1][0] + cover[-1][1] == kt
+        if precision == "bf16" and net is rend.sdf_network:
+            assert all(int(d["tail"]) != 0 and int(d["tail_n"]) == 256 and int(d["tail_stride"]) == 1 for d in ch if int(d["fmt"]) == 1 and
+                       any(int(d["dst"]) >= b.data_ptr() and int(d["dst"]) < b.data_ptr() + b.numel() for k, b in im.blobs.items() if k in ("sdf", "full")))
+        if precision == "bf16" and net is rend.color_network:
+            c2 = im.blobs["c2"]
+            mine = [d for d in ch if c2.data_ptr() <= int(d["dst"]) < c2.data_ptr() + c2.numel()]
+            assert len(mine) == 33 and all(int(d["tail_stride"]) == 289 and int(d["tail_n"]) == 256 for d in mine)
+            assert all(int(d["tail"]) == im.weff.data_ptr() + 4 * (im.w_off["lin0"] + 32) for d in mine)
+        if precision == "fp32":
+            assert "c2" not in im.blobs

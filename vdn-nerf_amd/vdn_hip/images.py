@@ -181,8 +181,8 @@ class NetImages:
             ch[i]["bias_scale"] = L.bias_scale
             if L.tail is not None:
                 tname, toff, tn = L.tail[:3]
-                first, tstride = (L.tail[3], L.tail[4]) if len(L.tail) > 3 else (0, 1)
-                ch[i]["tail"], ch[i]["tail_off"], ch[i]["tail_n"] = self.weff.data_ptr() + 4 * (self.w_off[tname] + first), toff, tn
+                tfirst, tstride = (L.tail[3], L.tail[4]) if len(L.tail) > 3 else (0, 1)
+                ch[i]["tail"], ch[i]["tail_off"], ch[i]["tail_n"] = self.weff.data_ptr() + 4 * (self.w_off[tname] + tfirst), toff, tn
                 ch[i]["tail_stride"] = tstride
             ch[i]["fmt"] = self.fmt
             ch[i]["kt_begin"], ch[i]["kt_count"], ch[i]["write_bias"] = kt0, ktc, int(first)
