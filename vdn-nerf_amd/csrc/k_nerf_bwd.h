@@ -18,6 +18,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void nerf_bwd_ke
     // p = row in the (possibly compacted) work list = row of the saves and deltas; pd = dense point id of the upstream grads
     const long n_rows = a.active_idx != nullptr ? (long)*a.n_active : (long)a.P;
     if ((long)blockIdx.x * P::kWaves * 32 >= n_rows) return;
+    ws.warm((n_rows + P::kWaves * 32 - 1) / (P::kWaves * 32), 256 * P::kMinWavesPerEU);
     const long p_raw = ((long)blockIdx.x * P::kWaves + ws.wave) * 32 + c;
     const bool ok = p_raw < n_rows;
     const long p = ok ? p_raw : n_rows - 1;

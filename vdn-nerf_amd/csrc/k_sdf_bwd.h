@@ -29,6 +29,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_rbar_ke
     const int lane = ws.lane, c = lane & 31, h = lane >> 5;
     const WorkRow wr = work_row(a.active_idx, a.n_active, a.P, P::kWaves, ws.wave, c);
     if (wr.none) return;
+    ws.warm(wr.n_wg, 256 * P::kMinWavesPerEU);
     const bool ok = wr.ok;
     const long p = wr.row, pd = wr.point;          // p: row of the saves / adjoint planes; pd: dense point id
     const long Pn = P::rows(a.P), PS = Pn * 256;
@@ -142,6 +143,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void sdf_fbar_ke
     const int lane = ws.lane, c = lane & 31, h = lane >> 5;
     const WorkRow wr = work_row(a.active_idx, a.n_active, a.P, P::kWaves, ws.wave, c);
     if (wr.none) return;
+    ws.warm(wr.n_wg, 256 * P::kMinWavesPerEU);
     const bool ok = wr.ok;
     const long p = wr.row, pd = wr.point;          // p: row of the saves / adjoint planes; pd: dense point id
     const long Pn = P::rows(a.P), PS = Pn * 256;

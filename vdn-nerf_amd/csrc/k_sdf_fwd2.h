@@ -358,28 +358,9 @@ struct ShadeExtra {
     const char* color_blob;     // the colour head's chunk stream ("c2", vdn_hip/images.py), same chunk format and stride
     int* ticket;                // [1] arrival counter, zero before the first launch (the last ray leaves it zero)
     int squeeze_out;            // fields.py:170-171
-    int warm_bytes, warm_bytes2;    // all modes: bytes of the weight stream(s) the first round of workgroups pulls into L2 up front (0 = off)
+    int warm_bytes, warm_bytes2;    // all modes: bytes of the weight stream(s) the first round of workgroups pulls into L2 up front (0 = off; mlp_engine.h: warm_l2)
     CompositeArgs cm;           // sdf / normals / color are not read (the samples come through LDS)
 };
-
-// L2 warm-up. Inside a training step the kernel starts on caches full of other kernels' planes: every chunk of the weight stream
-// is then an HBM miss for the first workgroup of each XCD that asks for it, and since all workgroups walk the stream in lockstep
-// each of the ~140 chunk steps waits that miss out - the step's launch takes 196 us where the same launch repeated back to back
-// (stream L2-resident) takes 144 (tools/dev/sdf_var_probe.py; 400 MB of unrelated stores in front of it reproduce the 196).
-// So the first round of workgroups reads the whole stream once, up front and in parallel: blocks b, b + 8, b + 16 .. share an XCD
-// (round-robin dispatch: a placement assumed for SPEED only), the j-th of them reads slice j of 32 (88 KB, 22 loads per lane, all
-// in flight together); 8 L2s x 2.8 MB = 22 MB from HBM, a few microseconds instead of 140 exposed misses.
-VDN_DEV void warm_l2(const char* blob, int bytes) {
-    if (bytes <= 0 || blockIdx.x >= 256) return;
-    const int j = blockIdx.x >> 3;
-    const int slice = ((bytes + 31) / 32 + 4095) & ~4095;
-    const int begin = j * slice, end = begin + slice < bytes ? begin + slice : bytes;
-    typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
-    u32x4w sink = {0u, 0u, 0u, 0u};
-    for (int off = begin + (int)threadIdx.x * 16; off < end; off += kWaves * 64 * 16)
-        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(blob + off) : "memory");
-    asm volatile("" ::"v"(sink));
-}
 
 template <int MODE, bool SAVE, int NSLOT, int DEPTH, int VID = 0, bool UPS = false>
 __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kernel(SdfArgs a, UpsampleArgs up, ShadeExtra ex) {
@@ -448,8 +429,8 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
     const long PS = P::plane(a.P, 256);
     const long prow = (p >> 5) * (32L * 256) + h * 256 + (p & 31) * 8;       // PT32 offset of this lane's 16-byte pieces (mlp_engine.h)
     const float inv_scale = 1.0f / a.scale;
-    warm_l2(a.blob, ex.warm_bytes);
-    if constexpr (MODE == 2) warm_l2(ex.color_blob, ex.warm_bytes2);
+    warm_l2(a.blob, ex.warm_bytes, wr.n_wg, MODE == 0 ? 512 : 256);
+    if constexpr (MODE == 2) warm_l2(ex.color_blob, ex.warm_bytes2, wr.n_wg, 256);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ordinary loads above: nothing but DMA and stores from here on
 
     typename P::template Act<9> X, Y;
@@ -835,8 +816,8 @@ int launch(const VdnSdfArgs* args, hipStream_t stream, const VdnUpsampleArgs* up
     // VDN_SDF2_WARM=0: no L2 warm-up (A/B); by default every launch that fills the chip at least once warms the stream it walks
     static const bool warm = [] { const char* e = getenv("VDN_SDF2_WARM"); return e == nullptr || e[0] != '0'; }();
     ShadeExtra exv = ex != nullptr ? *ex : ShadeExtra{};
-    exv.warm_bytes = (warm && grid >= 256) ? Prog<MODE>::sdf_total * kStride : 0;
-    exv.warm_bytes2 = (warm && grid >= 256 && MODE == 2) ? (Prog<MODE>::total - Prog<MODE>::sdf_total) * kStride : 0;
+    exv.warm_bytes = warm ? Prog<MODE>::sdf_total * kStride : 0;
+    exv.warm_bytes2 = (warm && MODE == 2) ? (Prog<MODE>::total - Prog<MODE>::sdf_total) * kStride : 0;
     hipLaunchKernelGGL((sdf_fwd2_kernel<MODE, SAVE, NSLOT, DEPTH, VID, UPS>), dim3(grid), dim3(kWaves * 64), lds, stream, *args,
                        up != nullptr ? *up : VdnUpsampleArgs{}, exv);
     return (int)hipGetLastError();

@@ -30,6 +30,36 @@ VDN_DEV unsigned pack_bf16x2(float a, float b) {
 VDN_DEV float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
 VDN_DEV float bf16_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
 
+// L2 warm-up of a kernel's weight stream. Inside a training step every MLP kernel starts on caches full of other kernels'
+// planes: each chunk of its weight stream is then an HBM miss for the first workgroup of each XCD that asks for it, and as the
+// workgroups of a launch walk the stream in lockstep, every one of its ~40-140 chunk steps waits that miss out (measured on the fused
+// SDF kernel: 196 us in the step, 144 us repeated back to back with the stream L2-resident; 400 MB of unrelated stores in front
+// of the back-to-back launch reproduce the 196: tools/dev/sdf_var_probe.py). So the FIRST ROUND of workgroups reads the whole
+// stream once, up front and in parallel: blocks b, b + 8, b + 16 .. share an XCD (round-robin dispatch - a placement assumed for
+// SPEED only), the j-th of them reads slice j; 8 L2s x 1-3 MB from HBM take a few microseconds instead of ~100 exposed misses.
+//   n_wg: workgroups of this launch that have rows; resident: workgroups the chip holds at once (256 CUs x workgroups per CU).
+#ifndef VDN_WARM_L2
+#define VDN_WARM_L2 1
+#endif
+VDN_DEV void warm_l2(const char* blob, int bytes, long n_wg, int resident) {
+#if VDN_WARM_L2
+    const int first = n_wg < resident ? (int)n_wg : resident;          // workgroups of the first round
+    if (bytes <= 0 || first < 128 || (int)blockIdx.x >= first) return;  // (a small launch's few workgroups would each read MBs)
+    const int slices = first >> 3;
+    const int j = blockIdx.x >> 3;
+    if (j >= slices) return;
+    const int slice = ((bytes + slices - 1) / slices + 255) & ~255;
+    const int begin = j * slice, end = begin + slice < bytes ? begin + slice : bytes;
+    typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+    u32x4w sink = {0u, 0u, 0u, 0u};
+    for (int off = begin + (int)threadIdx.x * 16; off < end; off += (int)blockDim.x * 16)
+        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(blob + off) : "memory");
+    // the loads write `sink` whenever they return: it must stay allocated until they have (the compiler does not know these are
+    // loads and would hand the registers to the next values while data is still on its way into them)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink)::"memory");
+#endif
+}
+
 // Weight stream: a ring of NSLOT LDS slots, each chunk fetched DEPTH = NSLOT-1 chunk steps before it is used
 // (measured: with a depth of 1 every step waited ~0.9 us for its chunk - the L2 -> LDS latency - which put a
 // 58 us floor under a 63-step forward chain whose MFMAs take 31 us). All chunks of a stream sit at one uniform
@@ -58,6 +88,8 @@ struct WStream {
         lane = threadIdx.x & 63;
         all_issue = false;
     }
+    // L2 warm-up of the whole stream by the launch's first round of workgroups (warm_l2 above); before start()
+    VDN_DEV void warm(long n_wg, int resident) const { warm_l2(g, total * STRIDE, n_wg, resident); }
     VDN_DEV void issue_next() {
         char* dst = lds + (issued % NSLOT) * STRIDE;
 #pragma unroll
@@ -117,6 +149,7 @@ VDN_DEV float sprime(float raw, int from_h) {
 struct WorkRow {
     long row, point;
     bool ok, none;
+    long n_wg;          // workgroups of the launch that have rows
 };
 VDN_DEV WorkRow work_row(const int32_t* active_idx, const int32_t* n_active, long P, int waves, int wave, int c) {
     WorkRow w;
@@ -126,6 +159,7 @@ VDN_DEV WorkRow work_row(const int32_t* active_idx, const int32_t* n_active, lon
     w.ok = raw < n_rows;
     w.row = w.ok ? raw : (n_rows > 0 ? n_rows - 1 : 0);
     w.point = active_idx != nullptr ? (long)active_idx[w.row] : w.row;
+    w.n_wg = (n_rows + waves * 32 - 1) / (waves * 32);
     return w;
 }
 

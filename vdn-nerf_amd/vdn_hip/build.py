@@ -13,10 +13,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 CSRC = os.path.join(PKG, "csrc")
 INCLUDE = os.path.join(os.path.dirname(PKG), "include")
-OBJDIR = os.path.join(HERE, "_build")
-LIB = os.path.join(HERE, "libvdn_render.so")
+# VDN_BUILD_VARIANT="name:-DFLAG=..": a side copy of the whole library built with extra flags (objects in _build_<name>,
+# libvdn_render_<name>.so) for same-box A/B runs of compile-time switches through VDN_LIB (development only)
+_VARIANT = os.environ.get("VDN_BUILD_VARIANT", "")
+_VNAME, _VFLAGS = (_VARIANT.split(":", 1) + [""])[:2] if _VARIANT else ("", "")
+OBJDIR = os.path.join(HERE, "_build" + ("_" + _VNAME if _VNAME else ""))
+LIB = os.path.join(HERE, "libvdn_render%s.so" % ("_" + _VNAME if _VNAME else ""))
 ARCH = "gfx950"
-BASE_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC]
+BASE_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC] + _VFLAGS.split()
 PER_FILE_FLAGS = {"rays.hip": ["-ffp-contract=off"], "train_rays.hip": ["-ffp-contract=off"],
                   # k_sdf_fwd2.h: no SLP packing of the epilogue into v_pk_*_f32, MFMA accumulators in arch VGPRs
                   "sdf_bf16.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1"],
