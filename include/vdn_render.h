@@ -107,6 +107,10 @@ typedef struct {
      * the SAME struct - evaluates them with 32-row workgroups (csrc/k_sdf_fwd1_split.h): same planes, same values, bit for bit.
      * Both decide on the device-side row count, so both launches are always made. tail_max_rows = 0: off. */
     int32_t tail_row0, tail_max_rows;
+    /* != 0: the launch is part of a training step, where every kernel starts on caches full of other kernels' planes: its first
+     * round of workgroups then reads the weight stream into L2 up front (csrc/mlp_engine.h: warm_l2). The launches that save
+     * activations do so on their own; a render() loop keeps its weights cached and leaves this 0. */
+    int32_t cold_start;
 } VdnSdfArgs;
 int vdn_sdf_mlp_fwd_f32(int mode, const VdnSdfArgs* args_host, void* stream);
 /* bf16-MFMA variant (csrc/k_sdf_fwd2.h): blob holds bf16 chunks (fmt 1) of the SCALED streams (vdn_hip/images.py:

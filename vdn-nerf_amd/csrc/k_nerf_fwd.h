@@ -20,7 +20,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void nerf_fwd_ke
     // q = row of this lane in the (possibly compacted) work list = row of its training saves; p = its dense point id
     const long n_rows = a.active_idx != nullptr ? (long)*a.n_active : (long)a.P;
     if ((long)blockIdx.x * P::kWaves * 32 >= n_rows) return;          // whole workgroup beyond the active list
-    ws.warm((n_rows + P::kWaves * 32 - 1) / (P::kWaves * 32), 256 * P::kMinWavesPerEU);
+    if (a.save_h != nullptr) ws.warm((n_rows + P::kWaves * 32 - 1) / (P::kWaves * 32), 256 * P::kMinWavesPerEU);
     const long q_raw = ((long)blockIdx.x * P::kWaves + ws.wave) * 32 + c;
     const bool ok = q_raw < n_rows;
     const long q = ok ? q_raw : n_rows - 1;

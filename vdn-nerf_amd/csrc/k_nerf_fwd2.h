@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256, 2) void nerf_fwd2_kernel(NerfArgs a) {
     // q = row of this lane in the (possibly compacted) work list = row of its training saves; p = its dense point id
     const long n_rows = a.active_idx != nullptr ? (long)*a.n_active : (long)a.P;
     if ((long)blockIdx.x * 4 * 32 >= n_rows) return;          // whole workgroup beyond the active list
-    warm_l2(a.blob, PG::total * kSlot, (n_rows + 127) / 128, 512);          // (mlp_engine.h: cold weight stream inside a training step)
+    if constexpr (SAVE) warm_l2(a.blob, PG::total * kSlot, (n_rows + 127) / 128, 512);      // (mlp_engine.h: cold weight stream inside a training step)
     const long q_raw = ((long)blockIdx.x * 4 + pp.wave) * 32 + c;
     const bool ok = q_raw < n_rows;
     const long q = ok ? q_raw : n_rows - 1;                   // out-of-range lanes repeat the last row (their plane stores are duplicates)

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_b
     const int lane = ws.lane, c = lane & 31, h = lane >> 5;
     const WorkRow wr = work_row(a.active_idx, a.n_active, a.P, P::kWaves, ws.wave, c);
     if (wr.none) return;
-    ws.warm(wr.n_wg, P::kWaves == 4 ? 256 * P::kMinWavesPerEU : 256);
+    ws.warm(wr.n_wg, 256 * P::kMinWavesPerEU);
     const bool ok = wr.ok;
     const long p = wr.row, pd = wr.point;          // p: row of saves / deltas / d_feat; pd: dense point id
     const long PS = P::plane(a.P, 256);

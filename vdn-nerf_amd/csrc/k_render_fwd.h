@@ -21,7 +21,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_f
     const int lane = ws.lane, c = lane & 31, h = lane >> 5;
     const WorkRow wr = work_row(a.active_idx, a.n_active, a.P, P::kWaves, ws.wave, c);
     if (wr.none) return;
-    ws.warm(wr.n_wg, P::kWaves == 4 ? 256 * P::kMinWavesPerEU : 256);
+    if (a.save_h != nullptr) ws.warm(wr.n_wg, 256 * P::kMinWavesPerEU);      // training step: the stream is cold (mlp_engine.h)
     const bool ok = wr.ok;
     const long p = wr.row, pd = wr.point;          // p: row of feat and of the saves; pd: dense point id
     const long r = pd / a.n_per_ray;

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(Sdf
     const int lane = ws.lane, c = lane & 31, h = lane >> 5;
     const WorkRow wr = work_row(a.active_idx, a.n_active, a.P, NW, ws.wave, c);
     if (wr.none) return;
-    ws.warm(wr.n_wg, 256 * P::kMinWavesPerEU);
+    if (a.H != nullptr || a.cold_start) ws.warm(wr.n_wg, 256 * P::kMinWavesPerEU);
     const bool ok = wr.ok;
     const long p = wr.row, pd = wr.point;          // p: row of the saves (and of feat); pd: dense point id
     ws.all_issue = __any(ok);

@@ -816,8 +816,11 @@ int launch(const VdnSdfArgs* args, hipStream_t stream, const VdnUpsampleArgs* up
     // VDN_SDF2_WARM=0: no L2 warm-up (A/B); by default every launch that fills the chip at least once warms the stream it walks
     static const bool warm = [] { const char* e = getenv("VDN_SDF2_WARM"); return e == nullptr || e[0] != '0'; }();
     ShadeExtra exv = ex != nullptr ? *ex : ShadeExtra{};
-    exv.warm_bytes = warm ? Prog<MODE>::sdf_total * kStride : 0;
-    exv.warm_bytes2 = (warm && MODE == 2) ? (Prog<MODE>::total - Prog<MODE>::sdf_total) * kStride : 0;
+    // (a training step's launches find the stream cold: the saving launch always, the others when the caller says so; a render()
+    // loop keeps its few MB of weights in L2 / MALL, where the warm-up would only cost its 3-5 us)
+    const bool cold = (SAVE && MODE == 1) || args->cold_start != 0;
+    exv.warm_bytes = (warm && cold) ? Prog<MODE>::sdf_total * kStride : 0;
+    exv.warm_bytes2 = (warm && cold && MODE == 2) ? (Prog<MODE>::total - Prog<MODE>::sdf_total) * kStride : 0;
     hipLaunchKernelGGL((sdf_fwd2_kernel<MODE, SAVE, NSLOT, DEPTH, VID, UPS>), dim3(grid), dim3(kWaves * 64), lds, stream, *args,
                        up != nullptr ? *up : VdnUpsampleArgs{}, exv);
     return (int)hipGetLastError();

@@ -158,6 +158,7 @@ class SDFNetwork(_HipNet):
         a = lib.VdnSdfArgs()
         a.rays_o, a.rays_d, a.z, a.n_per_ray, a.z_ld = rays_o.data_ptr(), rays_d.data_ptr(), z.data_ptr(), 64, z.stride(0)
         a.P, a.scale, a.sdf, a.sdf_ld = z.shape[0] * 64, float(self.scale), sdf_out.data_ptr(), sdf_out.stride(0)
+        a.cold_start = int(self.__dict__.get("_cold_start", False))      # (a Trainer's renderer: the step's first SDF pass finds the stream cold)
         a.w8row = img.weff_view("lin8").data_ptr()
         a.blob = img.blobs["sdf"].data_ptr()
         return lib.try_call("vdn_sdf_upsample_bf16", a, upsample, _stream())

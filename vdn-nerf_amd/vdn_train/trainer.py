@@ -114,6 +114,9 @@ class Trainer:
         for m in (renderer.nerf, renderer.color_network, renderer.depth_network):
             if m is not None:
                 m.__dict__["_stream_join"] = self.join
+        # the sampler's first SDF pass of a step starts on caches full of the previous step's planes: it warms its weight stream
+        # (VdnSdfArgs.cold_start; the kernels that save activations do so on their own)
+        renderer.sdf_network.__dict__["_cold_start"] = True
         self._eik_global = torch.zeros(3, dtype=torch.float32, device=self.dev)
         self._eik_partial = torch.zeros(batch_size, 2, dtype=torch.float32, device=self.dev)
         self._eik_handles = []
