@@ -672,7 +672,11 @@ class TrainEngine:
         # rounds; when the list ends within VDN_SDF_TAIL_MAX rows behind the last full round, those rows go to the 32-row
         # feature-split kernel instead (csrc/k_sdf_fwd1_split.h: same planes, bit for bit; both launches decide on the device-side
         # row count). VDN_SDF_TAIL=0: off. (Not with ray gradients: the tail kernel does not write U_pe.)
-        tail = (self.precision == "bf16" and self._fg_compact and os.environ.get("VDN_SDF_TAIL", "1") != "0"
+        # Default: only on the one-stream schedule. The tail kernel buys latency with CU time (32 rows per 45 us against 128 per
+        # 80): it shortens the launch when the second round's CUs would idle (-37 us per step on one stream), but on the default
+        # two-stream schedule those CUs run the background network and the extra CU time costs +7 .. +20 us (same-box A/B).
+        tail_default = "1" if self._side is None else "0"
+        tail = (self.precision == "bf16" and self._fg_compact and os.environ.get("VDN_SDF_TAIL", tail_default) != "0"
                 and not getattr(self, "_ray_grads", False))
         if tail:
             row0 = int(os.environ.get("VDN_SDF_TAIL_ROW0", str(128 * torch.cuda.get_device_properties(self.dev).multi_processor_count)))
