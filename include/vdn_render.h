@@ -287,6 +287,9 @@ typedef struct {
     float* eik_out;            /* [3]: gradient_error, numerator, denominator */
 } VdnCompositeArgs;
 int vdn_alpha_composite_fwd(const VdnCompositeArgs* args_host, void* stream);
+/* d_feats = sum_i w_i * feature_i (renderer.py:306-308) alone, from the `weights` / `inside_sphere` a compositor launch has
+ * written: the second launch of vdn_alpha_composite_fwd, for callers whose compositor ran inside vdn_shade_fused_bf16. */
+int vdn_feat_composite(const VdnCompositeArgs* args_host, void* stream);
 
 /* ---- renderer.py:239-315 in ONE launch (the north-star kernel; bf16 path, inference): render_core's SDF network + analytic
  * gradient (fields.py:72-108), the colour head (fields.py:148-176, mode 'idr', d_out = 3) and the NeuS alpha / background blend /

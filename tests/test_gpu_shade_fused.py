@@ -86,13 +86,32 @@ def test_fused_shading_vs_reference_golden(golden, name, min_psnr):
     assert abs(out["gradient_error"].item() - float(fx["out_gradient_error"])) < 5e-2 * max(float(fx["out_gradient_error"]), 1e-2)
 
 
+@pytest.mark.parametrize("B", [5, 512])
+def test_fused_shading_with_a_vdn_head(B):
+    """womsk_white_wdepth (BASELINE.json configs[4]): the fused launch also writes the feature plane, the VDN head and the weighted
+    sums of its 96 channels follow as two launches (3 instead of 6). `render_feats` depends on the colour head only through
+    nothing at all - weights and VDN features are the same bits as the separate launches'."""
+    from vdn_train import synth, factory
+    dev = torch.device("cuda:0")
+    rend = factory.build_renderer(wdepth=True, device=dev, states=synth.make_all_states(3, wdepth=True, variance=0.4), precision="bf16")
+    assert rend._fused_shading(128) and rend.shade_launches() == 3
+    batch, kw = _batch(B, dev, seed=3)
+    ref = _render(rend, batch, False, **kw)
+    out = _render(rend, batch, True, **kw)
+    for k in EXACT + ("render_feats",):
+        assert torch.equal(out[k], ref[k]), k
+    assert out["render_feats"].shape == (B, 96) and float(out["render_feats"].abs().max()) > 0
+    assert float((out["color_fine"] - ref["color_fine"]).abs().max()) < 2e-3
+
+
 def test_fused_shading_declines_what_it_does_not_cover():
-    """VDN head, other sample counts, fp32: the separate launches run (and the entry point itself answers -10 for N != 128)."""
+    """depth_before_color, other sample counts, fp32: the separate launches run (and the entry point itself answers -10 for N != 128)."""
     from vdn_train import synth, factory
     from vdn_hip import lib
     dev = torch.device("cuda:0")
-    r = factory.build_renderer(wdepth=True, device=dev, states=synth.make_all_states(0, wdepth=True), precision="bf16")
-    assert not r._fused_shading(128) and r.shade_launches() == 6
+    r = factory.build_renderer(wdepth=True, device=dev, states=synth.make_all_states(0, wdepth=True, depth_before_color=True),
+                               precision="bf16", depth_before_color=True)
+    assert not r._fused_shading(128, depth_before_color=True)       # the colour head would read the VDN head's output
     r = factory.build_renderer(device=dev, states=synth.make_all_states(0), precision="fp32")
     assert not r._fused_shading(128)
     r = factory.build_renderer(device=dev, states=synth.make_all_states(0), precision="bf16", n_importance=0)

@@ -429,9 +429,11 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
     const long PS = P::plane(a.P, 256);
     const long prow = (p >> 5) * (32L * 256) + h * 256 + (p & 31) * 8;       // PT32 offset of this lane's 16-byte pieces (mlp_engine.h)
     const float inv_scale = 1.0f / a.scale;
-    warm_l2(a.blob, ex.warm_bytes, wr.n_wg, MODE == 0 ? 512 : 256);
-    if constexpr (MODE == 2) warm_l2(ex.color_blob, ex.warm_bytes2, wr.n_wg, 256);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ordinary loads above: nothing but DMA and stores from here on
+    // the input loads above have to be back first: the compiler waits for them with vmcnt(0), which would also wait for younger
+    // warm-up loads; behind this wait the stream arrives in L2 while the encoding below is computed from registers
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    warm_sink_t warm_a = warm_l2_begin(a.blob, ex.warm_bytes, wr.n_wg, MODE == 0 ? 512 : 256);
+    warm_sink_t warm_b = warm_l2_begin(MODE == 2 ? ex.color_blob : nullptr, MODE == 2 ? ex.warm_bytes2 : 0, wr.n_wg, 256);
 
     typename P::template Act<9> X, Y;
     typename P::template Act<9> F;          // MODE 2: the feature vector as the colour head's input fragments (tiles 0..7) + its small tile (8)
@@ -467,6 +469,9 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
         pe7[0] = X.r[0]; pe7[1] = X.r[1];
         X.r[16] = X.r[2]; X.r[17] = X.r[3];
     }
+    warm_l2_end(warm_a);
+    warm_l2_end(warm_b);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ordinary loads and stores above: nothing but DMA and counted stores from here on
     // ring start (behind the PE stores, so that nothing but counted operations is younger than a DMA): W8 row 0 into its
     // fixed place (wave 0), chunks 0 .. DEPTH-1 in flight, chunk 0 certified, its opening fragments read
     static_for<DEPTH>([&](auto i_c) VDN_INL { pp.template issue<decltype(i_c)::value>(); });

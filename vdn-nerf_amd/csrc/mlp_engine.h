@@ -41,23 +41,35 @@ VDN_DEV float bf16_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
 #ifndef VDN_WARM_L2
 #define VDN_WARM_L2 1
 #endif
-VDN_DEV void warm_l2(const char* blob, int bytes, long n_wg, int resident) {
+// Two halves, so that a kernel can do its own prologue (input loads, encodings) while the stream arrives: warm_l2_begin issues the
+// loads and hands back the registers they land in, warm_l2_end waits for them. The loads write that register quadruple whenever
+// they return, so it must stay allocated until they have: the compiler does not know these asm statements are loads and would hand
+// the registers to the next values while data is still on its way into them (which is why _end takes it as an in-out operand).
+// Un-counted vector-memory operations in flight only make a counted or compiler-placed s_waitcnt vmcnt(N) return later.
+typedef unsigned warm_sink_t __attribute__((ext_vector_type(4)));
+VDN_DEV warm_sink_t warm_l2_begin(const char* blob, int bytes, long n_wg, int resident) {
+    warm_sink_t sink = {0u, 0u, 0u, 0u};
 #if VDN_WARM_L2
     const int first = n_wg < resident ? (int)n_wg : resident;          // workgroups of the first round
-    if (bytes <= 0 || first < 128 || (int)blockIdx.x >= first) return;  // (a small launch's few workgroups would each read MBs)
+    if (bytes <= 0 || first < 128 || (int)blockIdx.x >= first) return sink;     // (a small launch's few workgroups would each read MBs)
     const int slices = first >> 3;
     const int j = blockIdx.x >> 3;
-    if (j >= slices) return;
+    if (j >= slices) return sink;
     const int slice = ((bytes + slices - 1) / slices + 255) & ~255;
     const int begin = j * slice, end = begin + slice < bytes ? begin + slice : bytes;
-    typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
-    u32x4w sink = {0u, 0u, 0u, 0u};
     for (int off = begin + (int)threadIdx.x * 16; off < end; off += (int)blockDim.x * 16)
         asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(blob + off) : "memory");
-    // the loads write `sink` whenever they return: it must stay allocated until they have (the compiler does not know these are
-    // loads and would hand the registers to the next values while data is still on its way into them)
+#endif
+    return sink;
+}
+VDN_DEV void warm_l2_end(warm_sink_t& sink) {
+#if VDN_WARM_L2
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink)::"memory");
 #endif
+}
+VDN_DEV void warm_l2(const char* blob, int bytes, long n_wg, int resident) {
+    warm_sink_t sink = warm_l2_begin(blob, bytes, n_wg, resident);
+    warm_l2_end(sink);
 }
 
 // Weight stream: a ring of NSLOT LDS slots, each chunk fetched DEPTH = NSLOT-1 chunk steps before it is used
@@ -90,6 +102,7 @@ struct WStream {
     }
     // L2 warm-up of the whole stream by the launch's first round of workgroups (warm_l2 above); before start()
     VDN_DEV void warm(long n_wg, int resident) const { warm_l2(g, total * STRIDE, n_wg, resident); }
+    VDN_DEV warm_sink_t warm_begin(long n_wg, int resident) const { return warm_l2_begin(g, total * STRIDE, n_wg, resident); }
     VDN_DEV void issue_next() {
         char* dst = lds + (issued % NSLOT) * STRIDE;
 #pragma unroll

@@ -488,6 +488,14 @@ extern "C" int vdn_eikonal_terms(const VdnEikonalArgs* a, void* stream) {
     return (int)hipGetLastError();
 }
 
+extern "C" int vdn_feat_composite(const VdnCompositeArgs* a, void* stream) {
+    if (!a || a->B <= 0 || a->N <= 0 || a->T < a->N || a->T > kMaxT) return -1;
+    if (!a->feat || !a->feat_out || a->feat_ch <= 0 || !a->weights || !a->inside_sphere) return -2;
+    if (a->T > a->N && (!a->bg_density || !a->bg_feat)) return -3;
+    hipLaunchKernelGGL(feat_composite_kernel, dim3(a->B), dim3(256), 0, (hipStream_t)stream, *a);
+    return (int)hipGetLastError();
+}
+
 extern "C" int vdn_alpha_composite_fwd(const VdnCompositeArgs* a, void* stream) {
     if (!a || a->B <= 0 || a->N <= 0 || a->T < a->N || a->T > kMaxT) return -1;
     if (!a->rays_o || !a->rays_d || !a->sdf || !a->normals || !a->dists || !a->mid_z || !a->color || !a->variance) return -2;

@@ -388,11 +388,26 @@ class NeuSRenderer:
             sa.n_per_ray, sa.z_ld, sa.sdf_ld, sa.P, sa.scale = N, mid_z.stride(0), N, B * N, float(sn.scale)
             sdf, normals = f32(B * N), f32(B * N, 3)
             sa.sdf, sa.normals = sdf.data_ptr(), normals.data_ptr()
+            feat = None
+            if self.depth_network is not None:       # the VDN head reads the feature plane: the fused kernel also writes it out
+                feat = torch.empty(B * N, 256, dtype=torch.bfloat16, device=dev)
+                sa.feat = feat.data_ptr()
             ticket = self.__dict__.get("_shade_ticket")
             if ticket is None or ticket.device != dev:
                 ticket = self.__dict__["_shade_ticket"] = torch.zeros(1, dtype=torch.int32, device=dev)
             cn = self.color_network
             lib.call("vdn_shade_fused_bf16", sa, lib.ptr(cn._images().blobs["c2"]), int(cn.squeeze_out), a, lib.ptr(ticket), st)
+            if self.depth_network is not None:
+                # renderer.py:245-249, 306-308: the 96 VDN channels keep their own launches - the head on the feature plane and the
+                # normals the fused kernel wrote, then their weighted sums with the weights it composited
+                if bg is not None and bg_feat is None:
+                    raise ValueError("depth_network is set but the NeRF was built with gen_depth_feats=False")
+                sampled_feat = self.depth_network._run(normals, feat, rays=(rays_o, rays_d, mid_z))
+                feat_out = f32(B, 96)
+                a.feat, a.feat_out, a.feat_ch = sampled_feat.data_ptr(), feat_out.data_ptr(), 96
+                if O > 0:
+                    a.bg_feat = bg_feat.data_ptr()
+                lib.call("vdn_feat_composite", a, st)
         else:
             lib.call("vdn_alpha_composite_fwd", a, st)
 
@@ -413,18 +428,19 @@ class NeuSRenderer:
 
     def _fused_shading(self, N, depth_before_color=False):
         """True where vdn_shade_fused_bf16 covers the configuration: bf16 kernels, rays of exactly 128 inside samples (one
-        workgroup per ray), the shipped 'idr' colour head (d_feature 256, d_out 3), no VDN head (its 96 channels keep their own
-        launches). VDN_SHADE_FUSED=0 forces the separate launches (SDF / colour / compositor / eikonal reduce)."""
+        workgroup per ray), the shipped 'idr' colour head (d_feature 256, d_out 3); a VDN head's 96 channels keep their own two
+        launches behind it. VDN_SHADE_FUSED=0 forces the separate launches (SDF / colour / compositor / eikonal reduce)."""
         cn, sn = self.color_network, self.sdf_network
-        return (os.environ.get("VDN_SHADE_FUSED", "1") != "0" and N == 128 and self.depth_network is None and not depth_before_color
+        return (os.environ.get("VDN_SHADE_FUSED", "1") != "0" and N == 128 and not depth_before_color
                 and sn.precision == "bf16" and cn.precision == "bf16" and cn.conf.get("mode") == "idr"
                 and cn.conf.get("d_feature") == 256 and cn.conf.get("d_out") == 3)
 
     def shade_launches(self):
         """Launches of _shade (renderer.py:239-315) on the current configuration, for the bench's C2 leg."""
+        vdn = 2 if self.depth_network is not None else 0               # the VDN head and the weighted sums of its 96 channels
         if self._fused_shading(self.n_samples + self.n_importance):
-            return 1
-        return 4 + (2 if self.depth_network is not None else 0)      # SDF, colour, compositor, eikonal reduce (+ VDN head, its compositor)
+            return 1 + vdn
+        return 4 + vdn      # SDF, colour, compositor, eikonal reduce
 
     def plan(self, batch, **render_kwargs):
         """A replayable whole-batch render() for `batch` rays with fixed keyword arguments -> RenderPlan."""
