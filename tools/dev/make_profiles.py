@@ -1,13 +1,14 @@
 """profiles/<round>_* from what tools/profile_round.sh left under gpurun_out/ (dev; run from the repo root):
 python tools/dev/make_profiles.py r03"""
 import json, os, shutil, subprocess, sys
-R = sys.argv[1] if len(sys.argv) > 1 else "r03"
+R = sys.argv[1] if len(sys.argv) > 1 else "r04"
 G, P = "gpurun_out", "profiles"
 line = open("%s/%s_bench_train_bf16.json" % (G, R)).read().strip().splitlines()[-1]
 json.loads(line)
 open("%s/%s_bench_train_bf16.json" % (P, R), "w").write(line + "\n")
-for f in ("train_bf16_kernel_stats.csv", "train_bf16_kernel_stats_two_streams.csv", "train_bf16_kernel_stats_whole_run.csv", "step_timeline_two_streams.txt"):
-    shutil.copy("%s/%s_%s" % (G, R, f), "%s/%s_%s" % (P, R, f))
+for f in ("train_bf16_kernel_stats_whole_run.csv", "step_timeline_two_streams.txt"):
+    if os.path.exists("%s/%s_%s" % (G, R, f)):          # (the two steady-state tables are copied by hand: their headers are edited)
+        shutil.copy("%s/%s_%s" % (G, R, f), "%s/%s_%s" % (P, R, f))
 summ = {t: json.load(open("%s/%s_%s/summary.json" % (G, R, t))) for t in ("sdf1", "sdf1t", "step")}
 
 def pick(d, key):
