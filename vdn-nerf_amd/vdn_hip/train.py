@@ -585,10 +585,22 @@ class TrainEngine:
                 w["bg_active"][1].fill_(self.Q)           # the dW GEMM's device-side row count
             # the NeRF++ background is independent of the SDF / colour path until compositing: it may run on a side stream
             # (81 920 background points = 1.25 rounds of the CUs; the tail round could overlap the SDF kernels)
-            self._fork()
+            # VDN_SDF_FIRST=1 (A/B): submit the fused SDF kernel - the critical path: colour head, compositor, loss follow it -
+            # BEFORE the background network's launch, which has slack until the compositor (the fork event is still taken in
+            # front of both): the SDF kernel's first round then gets the whole chip and the background network fills in behind it
+            sdf_first = self._side is not None and os.environ.get("VDN_SDF_FIRST", "0") == "1"
+            if sdf_first:
+                self._ev_fork.record(torch.cuda.current_stream())
+                self._sdf_forward(rays_o, rays_d)
+                self._side.wait_event(self._ev_fork)
+            else:
+                self._fork()
             lib.call("vdn_nerf_mlp_fwd" + self.sfx, n, self._side_handle(st))
             self._side_done()
-        self._sdf_forward(rays_o, rays_d)
+            if not sdf_first:
+                self._sdf_forward(rays_o, rays_d)
+        else:
+            self._sdf_forward(rays_o, rays_d)
         if after_sdf is not None:       # (the data-parallel Trainer reduces the eikonal sums over the ranks from here on)
             after_sdf(self)
 
@@ -841,6 +853,7 @@ class TrainEngine:
         lib.call("vdn_alpha_composite_bwd", c, st)
         if g_gradients is not None:              # `gradients` is the SDF normal itself: its adjoint joins the alpha / eikonal parts
             w["d_normals"].add_(g_gradients.reshape(self.P, 3))
+        nerf_late = False
         if r.n_outside > 0:                      # NeRF backward on the side stream, beside the heads' and the SDF backward
             nb = lib.VdnNerfBwdArgs()
             nb.blob = self.nets["nerf"].img.blobs["bwd"].data_ptr()
@@ -857,9 +870,15 @@ class TrainEngine:
                 w["d_bg_dirs"].zero_()
                 nb.rays_o, nb.rays_d, nb.z, nb.n_per_ray = rays_o.data_ptr(), rays_d.data_ptr(), w["bg_mid"].data_ptr(), self.T
                 nb.d_pts, nb.d_dirs = w["d_bg_pts"].data_ptr(), w["d_bg_dirs"].data_ptr()
-            self._fork()
-            lib.call("vdn_nerf_mlp_bwd" + self.sfx, nb, self._side_handle(st))
-            self._side_done()
+            # VDN_BWD_MAIN_FIRST=1 (A/B): the background network's backward is submitted behind the colour head's backward instead
+            # of in front of it (see nerf_late below)
+            nerf_late = self._side is not None and os.environ.get("VDN_BWD_MAIN_FIRST", "0") == "1"
+            if nerf_late:
+                self._ev_fork.record(torch.cuda.current_stream())
+            else:
+                self._fork()
+                lib.call("vdn_nerf_mlp_bwd" + self.sfx, nb, self._side_handle(st))
+                self._side_done()
 
         def rnet_bwd(net, g_out, out, save_h, dout, dh, d_out, module, accumulate):
             b = lib.VdnRenderNetBwdArgs()
@@ -881,6 +900,10 @@ class TrainEngine:
         # (accumulate flag covers both d_feat and d_normals; d_normals must always accumulate)
         if self.wdepth:
             rnet_bwd("vdn", w["d_vdn"], w["vdn_out"], w["vdn_h"], w["vdn_dout"], w["vdn_dh"], 96, r.depth_network, True)
+        if r.n_outside > 0 and nerf_late:
+            self._side.wait_event(self._ev_fork)
+            lib.call("vdn_nerf_mlp_bwd" + self.sfx, nb, self._side.cuda_stream)
+            self._side_done()
         if defer_rest and self._side is not None:
             self._ev_heads.record(torch.cuda.current_stream())      # the heads' deltas (operands of the rest group) are complete
 
