@@ -21,7 +21,8 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_f
     const int lane = ws.lane, c = lane & 31, h = lane >> 5;
     const WorkRow wr = work_row(a.active_idx, a.n_active, a.P, P::kWaves, ws.wave, c);
     if (wr.none) return;
-    if (a.save_h != nullptr) ws.warm(wr.n_wg, 256 * P::kMinWavesPerEU);      // training step: the stream is cold (mlp_engine.h)
+    // training step: the stream is cold (mlp_engine.h); it arrives in L2 underneath the input assembly below
+    warm_sink_t wsink = a.save_h != nullptr ? ws.warm_begin(wr.n_wg, 256 * P::kMinWavesPerEU) : warm_sink_t{0u, 0u, 0u, 0u};
     const bool ok = wr.ok;
     const long p = wr.row, pd = wr.point;          // p: row of feat and of the saves; pd: dense point id
     const long r = pd / a.n_per_ray;
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_f
     };
     const int est = save_h != nullptr ? P::kTileOps : 0;
     ws.all_issue = __any(ok);
+    warm_l2_end(wsink);
     ws.start();
     dense<P, 10 + EX, 8, true>(ws, X, 0, NoPre{}, relu_into(Y, 0), est);
     dense<P, 8, 8, true>(ws, Y, 0, NoPre{}, relu_into(X, 1), est);
