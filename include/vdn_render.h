@@ -605,6 +605,19 @@ typedef struct {
 } VdnCompositeBwdArgs;
 int vdn_alpha_composite_bwd(const VdnCompositeBwdArgs* args_host, void* stream);
 
+/* Training step, plain configuration (no mask loss, no depth-feature loss, one rank): vdn_alpha_composite_fwd, the colour term's
+ * gradient of vdn_loss_fwd_bwd (g_color = sign(color - true_rgb) / (B + 1e-5) * grad_scale, dpt_runner.py:228-229 with mask = 1;
+ * written to g_color [B,3] too) and vdn_alpha_composite_bwd in ONE launch, one wavefront per ray. fwd / bwd: the two calls' own
+ * argument blocks (bwd.alpha / bwd.weights must be fwd.alpha_out / fwd.weights; bwd.g_color / g_eik / eik are not read); fg_count:
+ * device scalar = the eikonal term's global denominator = the number of inside samples within the relaxed sphere (n_active of
+ * vdn_foreground_active); igr_weight = d loss / d gradient_error. fwd.eik_out is NOT written: the loss scalars are left to
+ * vdn_eikonal_reduce + vdn_loss_fwd_bwd, which may run later on any stream. Adjoints are bit-identical to the three calls'.
+ * -10: a configuration it does not cover (feature channels, g_weights, g_cdf, ray adjoints). */
+int vdn_composite_train(const VdnCompositeArgs* fwd_host, const VdnCompositeBwdArgs* bwd_host, const float* true_rgb, float* g_color,
+                        const int32_t* fg_count, float igr_weight, float grad_scale, void* stream);
+/* gradient_error = sum(num) / (sum(den) + 1e-5) from the per-ray partial sums [B,2] -> eik_out [3] (ratio, num, den). */
+int vdn_eikonal_reduce(const float* eik_partial, int32_t B, float* eik_out, void* stream);
+
 /* ---- adjoint of the ray geometry of render_core / render_core_outside (renderer.py:107-115, 228-237): collects the
  * per-point input adjoints of the networks and the section-length adjoints of the compositor into
  * d loss / d rays_o, d rays_d and d loss / d z (inside samples) / d z_out (outside samples), for learnable poses

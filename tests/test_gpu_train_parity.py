@@ -82,3 +82,43 @@ def test_overlapped_schedule_is_bit_identical_to_the_in_order_one():
     assert torch.equal(trs[0].param_flat, trs[1].param_flat)
     assert torch.equal(trs[0].exp_avg, trs[1].exp_avg) and torch.equal(trs[0].exp_avg_sq, trs[1].exp_avg_sq)
     assert trs[0]._depth_adam_steps == trs[1]._depth_adam_steps > 0
+
+
+@pytest.mark.parametrize("crop", [None, 420])
+def test_fused_compositor_launch_is_bit_identical_to_the_four_launches(monkeypatch, crop):
+    """Plain configuration (womsk_white: no mask loss, no VDN head, one rank): vdn_composite_train - the compositor, the colour
+    term's gradient and the compositor's adjoint of one ray in one launch, the eikonal denominator taken from the foreground work
+    list's length, the loss scalars reduced on a stream of their own - against vdn_alpha_composite_fwd + eikonal reduce +
+    vdn_loss_fwd_bwd + vdn_alpha_composite_bwd (VDN_FUSED_COMPOSITE=0): the reported scalars, the gradients, the parameters and
+    the Adam moments of every step, bit for bit (full-frame pixels: the list is a strict subset; object-centric crop: all rows)."""
+    import torch
+    from vdn_train import synth, factory
+    from vdn_train.trainer import Trainer
+    dev = torch.device("cuda:0")
+    B, seed = 512, 5
+    cams = synth.make_cameras(seed)
+    gg = lambda x: torch.tensor(x).to(dev)
+    conf = dict(warm_up_end=10, end_iter=300, anneal_end=40)
+    trs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("VDN_FUSED_COMPOSITE", fused)
+        torch.manual_seed(0)
+        tr = Trainer(factory.build_renderer(device=dev, precision="bf16"), B, dev, conf=conf)
+        trs.append(tr)
+    for it in range(16):
+        o, d = synth.random_pixel_batch(seed, it, it % 40, B, cams=cams, crop=crop)
+        near, far = synth.near_far_from_sphere(o, d)
+        t1, t2 = synth.jitter(seed, it, B)
+        args = [gg(o), gg(d), gg(near), gg(far), gg(synth.target_colors(o, d, 0.5))]
+        sc = []
+        for fused, tr in zip(("1", "0"), trs):
+            monkeypatch.setenv("VDN_FUSED_COMPOSITE", fused)
+            sc.append(tr.train_step(*args, t_rand=gg(t1), t_rand_out=gg(t2)).clone())
+            assert bool(tr.engine._fused_keep is not None) if fused == "1" else True
+        assert torch.equal(sc[0], sc[1]), (it, sc[0].tolist(), sc[1].tolist())
+        if it % 4 == 3:
+            assert torch.equal(trs[0].engine.grad_flat, trs[1].engine.grad_flat), it
+            assert torch.equal(trs[0].g_color, trs[1].g_color)
+    assert torch.equal(trs[0].param_flat, trs[1].param_flat)
+    assert torch.equal(trs[0].exp_avg, trs[1].exp_avg) and torch.equal(trs[0].exp_avg_sq, trs[1].exp_avg_sq)
+    assert torch.isfinite(trs[0].param_flat).all()

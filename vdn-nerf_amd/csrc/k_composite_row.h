@@ -28,12 +28,15 @@ struct CompositeLdsSrc {
     VDN_DEV float color(long, int i, int k) const { return rows[(4 + k) * n + i]; }
 };
 
-struct EikPair { float num, den; };      // the ray's eikonal partial sums (what eik_partial[2r], [2r+1] receive)
+// what a caller may need in registers: the ray's eikonal partial sums (what eik_partial[2r], [2r+1] receive) and its composited
+// colour incl. the background term (what color_out[3r ..] receives); uniform over the wave
+struct RowOut { float num, den, c[3]; };
+typedef RowOut EikPair;
 
 // s_w / s_in: kMaxT floats of LDS scratch each (this wave's): the ray's weights and inside flags for the feature channels.
 // eik_partial may be NULL (the fused kernel publishes the returned pair itself).
 template <class Src>
-VDN_DEV EikPair composite_row(const CompositeArgs& a, int r, int lane, const Src& src, float* s_w, float* s_in) {
+VDN_DEV RowOut composite_row(const CompositeArgs& a, int r, int lane, const Src& src, float* s_w, float* s_in) {
 #pragma clang fp contract(off)
     const int N = a.N, T = a.T;
     const bool has_bg = a.bg_density != nullptr;
@@ -190,7 +193,7 @@ VDN_DEV EikPair composite_row(const CompositeArgs& a, int r, int lane, const Src
             if (v1) a.feat_out[(long)r * C + ch1] = (float)acc1;
         }
     }
-    return EikPair{(float)eik_num, (float)eik_den};
+    return RowOut{(float)eik_num, (float)eik_den, {cr, cg, cb}};
 }
 
 }  // namespace vdn

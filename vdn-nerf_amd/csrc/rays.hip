@@ -488,6 +488,12 @@ extern "C" int vdn_eikonal_terms(const VdnEikonalArgs* a, void* stream) {
     return (int)hipGetLastError();
 }
 
+extern "C" int vdn_eikonal_reduce(const float* eik_partial, int32_t B, float* eik_out, void* stream) {
+    if (!eik_partial || !eik_out || B <= 0) return -1;
+    hipLaunchKernelGGL(eikonal_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, eik_partial, B, eik_out);
+    return (int)hipGetLastError();
+}
+
 extern "C" int vdn_feat_composite(const VdnCompositeArgs* a, void* stream) {
     if (!a || a->B <= 0 || a->N <= 0 || a->T < a->N || a->T > kMaxT) return -1;
     if (!a->feat || !a->feat_out || a->feat_ch <= 0 || !a->weights || !a->inside_sphere) return -2;

@@ -5,6 +5,7 @@
 // alpha (renderer.py:124) and the eikonal term (renderer.py:313-315). Built with -ffp-contract=off.
 #include "vdn_common.h"
 #include "vdn_kernels.h"
+#include "k_composite_row.h"
 
 namespace vdn {
 
@@ -80,10 +81,15 @@ __global__ __launch_bounds__(256) void feat_outer_kernel(CompositeBwdArgs a) {
     }
 }
 
-__global__ __launch_bounds__(kRW * 64) void composite_bwd_kernel(CompositeBwdArgs a) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int r = blockIdx.x * kRW + wave;
-    if (r >= a.B) return;
+// upstream gradients the caller already holds in registers (the fused forward + loss + backward launch below): the colour
+// term's gradient of this ray, d loss / d gradient_error and the eikonal term's GLOBAL denominator
+struct CompositeBwdOvr {
+    bool on;
+    float gc[3], g_eik, eik_den;
+};
+
+// the adjoint of one ray (one wavefront); `wave` = this ray's slot in the workgroup's LDS arrays
+VDN_DEV void composite_bwd_row(const CompositeBwdArgs& a, int r, int wave, int lane, const CompositeBwdOvr& ov) {
     const int N = a.N, T = a.T, C = a.feat_ch;
     const bool has_bg = a.bg_density != nullptr;
     const bool has_feat = a.d_feat != nullptr && a.g_feat != nullptr;
@@ -92,15 +98,16 @@ __global__ __launch_bounds__(kRW * 64) void composite_bwd_kernel(CompositeBwdArg
     for (int k = 0; k < 3; ++k) {
         o[k] = a.rays_o[r * 3 + k];
         d[k] = a.rays_d[r * 3 + k];
-        if (a.g_color != nullptr) gc[k] = a.g_color[r * 3 + k];
+        if (ov.on) gc[k] = ov.gc[k];
+        else if (a.g_color != nullptr) gc[k] = a.g_color[r * 3 + k];
     }
     const float var = a.variance[0];
     const float inv_s_raw = expf(var * 10.0f);
     const float inv_s = fminf(fmaxf(inv_s_raw, 1e-6f), 1e6f);
     const bool s_unclipped = inv_s_raw >= 1e-6f && inv_s_raw <= 1e6f;
     const float car = a.cos_anneal_ratio;
-    const float g_eik = a.g_eik != nullptr ? a.g_eik[0] : 0.0f;
-    const float eik_den = a.eik[2] + 1e-5f;
+    const float g_eik = ov.on ? ov.g_eik : (a.g_eik != nullptr ? a.g_eik[0] : 0.0f);
+    const float eik_den = ov.on ? ov.eik_den : a.eik[2] + 1e-5f;
     float bgc[3] = {0.0f, 0.0f, 0.0f};
     if (a.background_rgb != nullptr) {
         bgc[0] = a.background_rgb[0]; bgc[1] = a.background_rgb[1]; bgc[2] = a.background_rgb[2];
@@ -343,6 +350,45 @@ __global__ __launch_bounds__(kRW * 64) void composite_bwd_kernel(CompositeBwdArg
     }
 }
 
+__global__ __launch_bounds__(kRW * 64) void composite_bwd_kernel(CompositeBwdArgs a) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * kRW + wave;
+    if (r >= a.B) return;
+    CompositeBwdOvr ov;
+    ov.on = false;
+    composite_bwd_row(a, r, wave, lane, ov);
+}
+
+// renderer.py:262-315 forward, the colour term's gradient (dpt_runner.py:228-229, mask = 1) and the adjoint of the compositor
+// for one ray in ONE launch: the training step's plain configuration (no mask loss, no depth-feature loss, one rank) needs no
+// global quantity between the three but the eikonal term's denominator - the number of inside samples within the relaxed
+// sphere, which is exactly the length of the foreground work list (vdn_foreground_active uses the compositor's own norm
+// expression). The loss SCALARS (logging) are reduced afterwards by the usual kernels, off the critical path. Same device
+// functions as composite_kernel / composite_bwd_kernel and loss_kernel's expressions: bit-identical adjoints.
+__global__ __launch_bounds__(kRW * 64) void composite_train_kernel(CompositeArgs fa, CompositeBwdArgs ba, const float* true_rgb, float* g_color,
+                                                                   const int32_t* fg_count, float igr_weight, float grad_scale) {
+    __shared__ float s_w[kRW][kMaxTB], s_in[kRW][kMaxTB];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * kRW + wave;
+    if (r >= fa.B) return;
+    const RowOut ro = composite_row(fa, r, lane, CompositeGlobalSrc{fa.sdf, fa.normals, fa.color}, s_w[wave], s_in[wave]);
+    CompositeBwdOvr ov;
+    ov.on = true;
+    const float mask_sum = (float)fa.B + 1e-5f;                       // dpt_runner.py:213 with mask = ones
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float m = 1.0f;
+        const float diff = ro.c[k] - true_rgb[r * 3 + k];
+        const float e = diff * m;
+        const float sgn = e > 0.0f ? 1.0f : (e < 0.0f ? -1.0f : 0.0f);
+        ov.gc[k] = sgn * m / mask_sum * grad_scale;
+        if (lane == 0) g_color[r * 3 + k] = ov.gc[k];
+    }
+    ov.g_eik = igr_weight;
+    ov.eik_den = (float)(*fg_count) + 1e-5f;
+    composite_bwd_row(ba, r, wave, lane, ov);
+}
+
 // Adjoint of the ray geometry (include/vdn_render.h: VdnRayAdjointArgs), one wave per ray, sample i = kE * lane + e.
 //   d o = sum_i d pts_i;  d d = sum_i (d pts_i mid_i + d dirs_i) + d dir_cos;  d mid_i = d pts_i . d
 //   mid_i = (z_i + z_{i+1}) / 2 and dists_i = z_{i+1} - z_i for i < n-1;  mid_{n-1} = z_{n-1} + sample_dist / 2, dists_{n-1} const
@@ -427,6 +473,24 @@ extern "C" int vdn_alpha_composite_bwd(const VdnCompositeBwdArgs* a, void* strea
     if (ext_feat) hipLaunchKernelGGL(feat_outer_kernel, dim3(row_blocks), dim3(256), 0, (hipStream_t)stream, *a);
     if (a->d_variance != nullptr)
         hipLaunchKernelGGL(variance_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a->d_var_partial, a->B, a->d_variance);
+    return (int)hipGetLastError();
+}
+
+extern "C" int vdn_composite_train(const VdnCompositeArgs* f, const VdnCompositeBwdArgs* b, const float* true_rgb, float* g_color,
+                                   const int32_t* fg_count, float igr_weight, float grad_scale, void* stream) {
+    using namespace vdn;
+    if (!f || !b || !true_rgb || !g_color || !fg_count) return -1;
+    if (f->B <= 0 || f->N <= 0 || f->T < f->N || f->T > kMaxTB || b->B != f->B || b->N != f->N || b->T != f->T) return -1;
+    if (!f->rays_o || !f->rays_d || !f->sdf || !f->normals || !f->dists || !f->mid_z || !f->color || !f->variance) return -2;
+    if (!f->weights || !f->alpha_out || !f->cdf || !f->inside_sphere || !f->color_out || !f->weight_sum || !f->weight_max || !f->eik_partial) return -3;
+    if (f->T > f->N && (!f->bg_density || !f->bg_rgb || !f->bg_dists || !b->d_bg_density || !b->d_bg_rgb)) return -4;
+    // the plain configuration only: no feature channels, no extra upstream gradients, no ray adjoints
+    if (f->feat_out || b->d_feat || b->g_feat || b->g_weights || b->g_cdf || b->d_dists || b->d_dir_cos) return -10;
+    if (b->alpha != f->alpha_out || b->weights != f->weights || !b->d_sdf || !b->d_normals || !b->d_color || !b->d_var_partial) return -3;
+    hipLaunchKernelGGL(composite_train_kernel, dim3((f->B + kRW - 1) / kRW), dim3(kRW * 64), 0, (hipStream_t)stream, *f, *b, true_rgb,
+                       g_color, fg_count, igr_weight, grad_scale);
+    if (b->d_variance != nullptr)
+        hipLaunchKernelGGL(variance_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, b->d_var_partial, b->B, b->d_variance);
     return (int)hipGetLastError();
 }
 

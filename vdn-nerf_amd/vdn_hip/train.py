@@ -96,6 +96,7 @@ class TrainEngine:
         self._ev_join2 = torch.cuda.Event() if self._side2 is not None else None
         self._ev_heads = torch.cuda.Event() if use_side else None
         self._pending = False
+        self._fused_keep = None
         self._fg_compact = self._bg_compact = False
         precs = {m.precision for m in (renderer.nerf, renderer.sdf_network, renderer.color_network, renderer.depth_network) if m is not None}
         if len(precs) != 1:
@@ -503,12 +504,15 @@ class TrainEngine:
         return w
 
     def forward(self, rays_o, rays_d, z, z_out, background_rgb, cos_anneal_ratio, skip_far=False, ray_grads=False, pending_merge=None,
-                after_sdf=None):
+                after_sdf=None, fuse_loss=None):
         """Differentiable part of render() at detached z [B,N] (+ z_out [B,O]); returns the output tensors.
         skip_far (the Trainer's hot loop): inside samples beyond the relaxed sphere (|p| >= 1.2: inside_sphere = 0 and
         relax_inside_sphere = 0, renderer.py:284-286) enter the loss only through exact zeros, so the SDF / colour / VDN
         networks skip them; `normals` / `sdf` are then only valid at the listed points (render() never sets it: it returns
-        `gradients` for every sample)."""
+        `gradients` for every sample).
+        fuse_loss (the Trainer's plain configuration): dict(true_rgb, g_color, igr_weight, grad_scale) - the compositor, the
+        colour term's gradient and the compositor's adjoint run as ONE launch (vdn_composite_train); backward() then starts at
+        the heads. Needs skip_far (the eikonal denominator is the foreground list's length)."""
         r, w, B, N, T = self.r, self.w, self.B, self.N, self.T
         st = _stream()
         if ray_grads and skip_far:
@@ -634,8 +638,16 @@ class TrainEngine:
         if self.wdepth:
             c.feat_out = w["feat_out"].data_ptr()
         self._join()
-        lib.call("vdn_alpha_composite_fwd", c, st)
         self._ctx = (rays_o, rays_d, background_rgb, cos_anneal_ratio, z)
+        self._composite_bwd_done = False
+        if fuse_loss is not None and self._fg_compact and not self.wdepth and not ray_grads:
+            cb = self._composite_bwd_args(None, None, None, None, None)
+            self._fused_keep = (c, cb, fuse_loss)
+            lib.call("vdn_composite_train", c, cb, lib.ptr(fuse_loss["true_rgb"]), lib.ptr(fuse_loss["g_color"]), lib.ptr(w["fg_active"][1]),
+                     float(fuse_loss["igr_weight"]), float(fuse_loss["grad_scale"]), st)
+            self._composite_bwd_done = True
+        else:
+            lib.call("vdn_alpha_composite_fwd", c, st)
         self.generation = getattr(self, "generation", 0) + 1
         return w
 
@@ -811,28 +823,18 @@ class TrainEngine:
         c.B, c.N, c.T = self.B, self.N, self.T
         return c
 
-    # ------------------------------------------------------------------------------------------
-    def backward(self, g_color, g_feat, g_weights, g_eik, g_cdf=None, g_gradients=None, defer_rest=False, gemm_event=None):
-        """Upstream grads (any may be None) -> list of parameter grads (clones) per network. g_cdf [B,N] / g_gradients
-        [B,N,3]: adjoints of the `cdf_fine` / `gradients` outputs (the reference returns them attached, renderer.py:426-439).
-        defer_rest (the Trainer's hot loop): only the SDF network's and the variance's gradients are complete on return (on the
-        caller's stream); the caller finishes the others with rest_weight_grads() - on the side stream, behind the background
-        network's backward - so that they overlap whatever follows on the main stream."""
-        r, w, st = self.r, self.w, _stream()
+    def _composite_bwd_args(self, g_color, g_feat, g_weights, g_eik, g_cdf):
+        """Argument block of the compositor's adjoint (vdn_alpha_composite_bwd / vdn_composite_train) for the last forward."""
+        r, w = self.r, self.w
         rays_o, rays_d, background_rgb, car, z = self._ctx
         c = self._composite_common(lib.VdnCompositeBwdArgs(), rays_o, rays_d, background_rgb, car)
         c.alpha, c.weights, c.eik = w["alpha"].data_ptr(), w["weights"].data_ptr(), w["eik"].data_ptr()
-        keep = [t.contiguous() if t is not None else None for t in (g_color, g_feat, g_weights, g_eik, g_cdf, g_gradients)]
-        g_color, g_feat, g_weights, g_eik, g_cdf, g_gradients = keep
-        if (g_cdf is not None or g_gradients is not None) and self._fg_compact:
-            raise ValueError("adjoints of cdf_fine / gradients need every inside sample evaluated (skip_far=False)")
         c.g_cdf = g_cdf.data_ptr() if g_cdf is not None else None
         c.g_color = g_color.data_ptr() if g_color is not None else None
         c.g_feat = g_feat.data_ptr() if (g_feat is not None and self.wdepth) else None
         c.g_weights = g_weights.data_ptr() if g_weights is not None else None
         c.g_eik = g_eik.data_ptr() if g_eik is not None else None
         c.d_sdf, c.d_normals, c.d_color = w["d_sdf"].data_ptr(), w["d_normals"].data_ptr(), w["d_color"].data_ptr()
-        use_vdn = self.wdepth and g_feat is not None
         if self.wdepth:
             c.d_feat = w["d_vdn"].data_ptr()
             c.feat_scratch = w["feat_scratch"].data_ptr()
@@ -845,12 +847,33 @@ class TrainEngine:
                 if g_feat is None:
                     w["d_bg_feat"].zero_()
         c.d_var_partial = w["d_var_partial"].data_ptr()       # summed into the variance's gradient by the finalize launch (_build_dw_plan)
-        rg = getattr(self, "_ray_grads", False)
-        if rg:
+        if getattr(self, "_ray_grads", False):
             c.d_dists, c.d_dir_cos = w["d_dists"].data_ptr(), w["d_dir_cos"].data_ptr()
             if r.n_outside > 0:
                 c.d_bg_dists = w["d_bg_dists"].data_ptr()
-        lib.call("vdn_alpha_composite_bwd", c, st)
+        self._bwd_args_keep = (g_color, g_feat, g_weights, g_eik, g_cdf)
+        return c
+
+    # ------------------------------------------------------------------------------------------
+    def backward(self, g_color, g_feat, g_weights, g_eik, g_cdf=None, g_gradients=None, defer_rest=False, gemm_event=None):
+        """Upstream grads (any may be None) -> list of parameter grads (clones) per network. g_cdf [B,N] / g_gradients
+        [B,N,3]: adjoints of the `cdf_fine` / `gradients` outputs (the reference returns them attached, renderer.py:426-439).
+        defer_rest (the Trainer's hot loop): only the SDF network's and the variance's gradients are complete on return (on the
+        caller's stream); the caller finishes the others with rest_weight_grads() - on the side stream, behind the background
+        network's backward - so that they overlap whatever follows on the main stream."""
+        r, w, st = self.r, self.w, _stream()
+        rays_o, rays_d, background_rgb, car, z = self._ctx
+        keep = [t.contiguous() if t is not None else None for t in (g_color, g_feat, g_weights, g_eik, g_cdf, g_gradients)]
+        g_color, g_feat, g_weights, g_eik, g_cdf, g_gradients = keep
+        if (g_cdf is not None or g_gradients is not None) and self._fg_compact:
+            raise ValueError("adjoints of cdf_fine / gradients need every inside sample evaluated (skip_far=False)")
+        use_vdn = self.wdepth and g_feat is not None
+        rg = getattr(self, "_ray_grads", False)
+        if getattr(self, "_composite_bwd_done", False):
+            self._composite_bwd_done = False          # (forward(fuse_loss=...) ran the compositor's adjoint already)
+        else:
+            c = self._composite_bwd_args(g_color, g_feat, g_weights, g_eik, g_cdf)
+            lib.call("vdn_alpha_composite_bwd", c, st)
         if g_gradients is not None:              # `gradients` is the SDF normal itself: its adjoint joins the alpha / eikonal parts
             w["d_normals"].add_(g_gradients.reshape(self.P, 3))
         nerf_late = False

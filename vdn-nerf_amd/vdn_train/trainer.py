@@ -101,6 +101,7 @@ class Trainer:
         self.engine = TrainEngine(renderer, batch_size, self.dev)
         self.overlap = (os.environ.get("VDN_OVERLAP", "1") != "0") if overlap is None else bool(overlap)
         self._ev_gemm, self._ev_rest, self._ev_tail = (torch.cuda.Event() for _ in range(3))
+        self._ev_comp, self._ev_log, self._log_stream = torch.cuda.Event(), torch.cuda.Event(), None
         self._rest_pending = False
         self._jitter, self._jitter_next = None, 0
         self._main = None
@@ -195,8 +196,18 @@ class Trainer:
                                  defer_last_merge=True)
         self.join()
         after_sdf = self._eikonal_begin if self.coll.enabled else None
+        depth_on = self.conf["extract_depth"] and self.iter_step > self.conf["depth_start_iter"] and gt_feats is not None
+        # Plain configuration (one rank, no mask, no mask loss, no VDN head): compositor, colour-term gradient and the compositor's
+        # adjoint are ONE launch (vdn_composite_train) - nothing global sits between them but the eikonal denominator, which is
+        # the foreground list's length - and the loss SCALARS (logging only) are reduced on a stream of their own, off the
+        # critical path: 4 launches of 5 - 15 us each (compositor, eikonal reduce, loss, adjoint) become one. Same device
+        # functions, same expressions: gradients bit-identical (tests/test_gpu_train_parity.py). VDN_FUSED_COMPOSITE=0: off.
+        fuse = (not self.coll.enabled and mask is None and self.conf["mask_weight"] == 0.0 and not eng.wdepth
+                and os.environ.get("VDN_FUSED_COMPOSITE", "1") != "0")
+        fl = dict(true_rgb=true_rgb, g_color=self.g_color, igr_weight=self.conf["igr_weight"], grad_scale=1.0 / self.world) if fuse else None
         w = eng.forward(rays_o, rays_d, z.contiguous(), z_out, self.bg, self.cos_anneal_ratio(), skip_far=True,
-                        pending_merge=r._pending_merge, after_sdf=after_sdf)
+                        pending_merge=r._pending_merge, after_sdf=after_sdf, fuse_loss=fl)
+        fused = bool(getattr(eng, "_composite_bwd_done", False))
         if self.coll.enabled:
             # the eikonal term is a ratio of sums over the GLOBAL batch (renderer.py:313-315): its two sums were
             # on their way since the SDF kernel finished; the loss kernel and the compositor's adjoint read w["eik"]
@@ -204,7 +215,6 @@ class Trainer:
             eg = self._eik_global
             eg[0:1] = eg[1:2] / (eg[2:3] + 1e-5)
             w["eik"].copy_(eg)
-        depth_on = self.conf["extract_depth"] and self.iter_step > self.conf["depth_start_iter"] and gt_feats is not None
         a = lib.VdnLossArgs()
         a.color, a.true_rgb, a.weights, a.eik = w["color"].data_ptr(), true_rgb.data_ptr(), w["weights"].data_ptr(), w["eik"].data_ptr()
         a.mask = mask.data_ptr() if mask is not None else None
@@ -218,7 +228,17 @@ class Trainer:
             a.feats, a.gt_feats, a.g_feats = w["feat_out"].data_ptr(), gt_feats.data_ptr(), self.g_feats.data_ptr()
             a.depth_weight = self.depth_iter_weight()
             self.depth_iter += 1
-        lib.call("vdn_loss_fwd_bwd", a, st)
+        if fused:
+            if self._log_stream is None:
+                self._log_stream = torch.cuda.Stream(device=self.dev)
+            ls = self._log_stream
+            self._ev_comp.record(torch.cuda.current_stream())
+            ls.wait_event(self._ev_comp)
+            lib.call("vdn_eikonal_reduce", lib.ptr(w["eik_partial"]), B, lib.ptr(w["eik"]), ls.cuda_stream)
+            lib.call("vdn_loss_fwd_bwd", a, ls.cuda_stream)      # the scalars (it rewrites g_color / g_eik with the values already used)
+            self._ev_log.record(ls)
+        else:
+            lib.call("vdn_loss_fwd_bwd", a, st)
         g_feats = self.g_feats if depth_on else None
         g_weights = self.g_weights if self.conf["mask_weight"] != 0.0 else None
         lr, main_step = self.learning_rate(), self.iter_step + 1 - self._step0()
@@ -298,6 +318,8 @@ class Trainer:
                         update_rest(side.cuda_stream)
                         self._ev_rest.record(side)
                     self._rest_pending = True
+        if fused:
+            torch.cuda.current_stream().wait_event(self._ev_log)      # the scalars (long done) are ordered in front of what follows
         self.iter_step += 1
         return self.scalars        # device tensor [loss, color_loss, psnr, eikonal, depth_loss, mask_loss]; no host sync here
 
