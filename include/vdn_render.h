@@ -556,24 +556,6 @@ typedef struct {
 } VdnDwFinalizeDesc;
 int vdn_dw_finalize(const VdnDwFinalizeDesc* descs_dev, int n_desc, int max_M, int phase, void* stream);
 
-/* vdn_weightnorm_bwd + vdn_adam_step + vdn_weightnorm_materialize for a group of layers in ONE launch (one wave per matrix row;
- * the three are row-local): per descriptor, dg / dv from dw_eff (written to the gradient buffer as vdn_weightnorm_bwd does), Adam on
- * g, v and bias with the moments at the parameters' offsets in the flat buffers (param_base / grad_base / exp_avg / exp_avg_sq:
- * the bias gradient is read at the bias's offset in grad_base), then w_eff and inv_norm of the updated row. g == NULL: a plain
- * parameter block of rows x cols (Adam only, gradient read from grad_base). Same results as the three calls, bit for bit. */
-typedef struct {
-    float* g;                /* [rows] weight_g, or NULL */
-    float* v;                /* [rows,cols] weight_v (or the plain parameter) */
-    float* bias;             /* [rows] or NULL */
-    const float* dw_eff;     /* [rows,cols] d loss / d W_eff (vdn_dw_finalize's target) */
-    float* dg; float* dv;    /* gradient buffer views of g and v */
-    float* inv_norm;         /* [rows] in: 1/||v_r|| of the forward; out: of the updated row */
-    float* w_eff;            /* [rows,cols] out */
-    int32_t rows, cols;
-} VdnWnUpdateDesc;
-int vdn_wn_update(const VdnWnUpdateDesc* descs_dev, int n_desc, int max_rows, const float* param_base, const float* grad_base,
-                  float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2, float eps, int32_t step, void* stream);
-
 /* weight-norm backward: dg_r = <dW_r, v_r>/||v_r||;  dv_r = g_r/||v_r|| * (dW_r - <dW_r,v_r>/||v_r||^2 * v_r) */
 typedef struct {
     const float* g; const float* v; const float* inv_norm; const float* dw_eff;

@@ -122,37 +122,3 @@ def test_fused_compositor_launch_is_bit_identical_to_the_four_launches(monkeypat
     assert torch.equal(trs[0].param_flat, trs[1].param_flat)
     assert torch.equal(trs[0].exp_avg, trs[1].exp_avg) and torch.equal(trs[0].exp_avg_sq, trs[1].exp_avg_sq)
     assert torch.isfinite(trs[0].param_flat).all()
-
-
-def test_fused_sdf_update_launch_is_bit_identical_to_the_three_launches(monkeypatch):
-    """vdn_wn_update (weight-norm backward + Adam + weight norm of the SDF network and the variance, one wave per matrix row, one
-    launch) against vdn_weightnorm_bwd + vdn_adam_step_ranges + vdn_weightnorm_materialize (VDN_FUSED_UPDATE=0): scalars, gradients
-    (incl. dg / dv), parameters, Adam moments and - through the next steps' losses - the rebuilt weight images, bit for bit."""
-    import torch
-    from vdn_train import synth, factory
-    from vdn_train.trainer import Trainer
-    dev = torch.device("cuda:0")
-    B, seed = 256, 9
-    cams = synth.make_cameras(seed)
-    gg = lambda x: torch.tensor(x).to(dev)
-    conf = dict(warm_up_end=10, end_iter=300, anneal_end=40)
-    trs = []
-    for fused in ("1", "0"):
-        monkeypatch.setenv("VDN_FUSED_UPDATE", fused)
-        torch.manual_seed(0)
-        trs.append(Trainer(factory.build_renderer(device=dev, precision="bf16"), B, dev, conf=conf))
-    assert trs[0]._fused_sdf_update and not trs[1]._fused_sdf_update
-    for it in range(12):
-        o, d = synth.random_pixel_batch(seed, it, it % 40, B, cams=cams, crop=420)
-        near, far = synth.near_far_from_sphere(o, d)
-        t1, t2 = synth.jitter(seed, it, B)
-        args = [gg(o), gg(d), gg(near), gg(far), gg(synth.target_colors(o, d, 0.5))]
-        sc = [tr.train_step(*args, t_rand=gg(t1), t_rand_out=gg(t2)).clone() for tr in trs]
-        assert torch.equal(sc[0], sc[1]), (it, sc[0].tolist(), sc[1].tolist())
-        assert torch.equal(trs[0].engine.grad_flat, trs[1].engine.grad_flat), it
-        assert torch.equal(trs[0].param_flat, trs[1].param_flat), it
-    assert torch.equal(trs[0].exp_avg, trs[1].exp_avg) and torch.equal(trs[0].exp_avg_sq, trs[1].exp_avg_sq)
-    a, b = (tr.engine.nets["sdf"].img for tr in trs)
-    assert torch.equal(a.weff, b.weff) and torch.equal(a.inv_norm, b.inv_norm)
-    for k in a.blobs:
-        assert torch.equal(a.blobs[k], b.blobs[k]), k

@@ -105,75 +105,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
-// The update of a group of weight-normed layers in ONE launch, one wave per matrix row: weight-norm backward (dg, dv from d W_eff:
-// weightnorm_bwd_kernel's expressions), Adam on that row's g, v and bias (adam_kernel's expressions, moments at the parameters' offsets
-// in the flat buffers), then the row of the new effective weight and its 1 / ||v|| (weightnorm_kernel's expressions). Everything is
-// row-local, so the three launches (5 - 6 us each, in front of the weight-image build on the path into the next step's sampler) need
-// not be three. A descriptor without g is a plain parameter row (Adam only; the variance).
-__global__ void wn_update_kernel(const VdnWnUpdateDesc* descs, const float* param_base, const float* grad_base, float* exp_avg, float* exp_avg_sq,
-                                 float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
-    const VdnWnUpdateDesc d = descs[blockIdx.x];
-    const int row = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (row >= d.rows) return;
-    const float step_size = lr / bc1;
-    auto adam = [&](float* p, float gi) {
-        const long i = p - param_base;
-        const float mi = exp_avg[i] + (gi - exp_avg[i]) * (1.0f - b1);
-        const float vi = exp_avg_sq[i] * b2 + gi * gi * (1.0f - b2);
-        exp_avg[i] = mi;
-        exp_avg_sq[i] = vi;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        *p = *p - step_size * (mi / denom);
-    };
-    float* v = d.v + (long)row * d.cols;
-    if (d.g == nullptr) {                       // plain rows: the gradient already sits in the flat buffer
-        for (int c = lane; c < d.cols; c += 64) adam(v + c, grad_base[(v + c) - param_base]);
-        return;
-    }
-    const float* dw = d.dw_eff + (long)row * d.cols;
-    float dot = 0.0f;
-    for (int c = lane; c < d.cols; c += 64) dot += dw[c] * v[c];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
-    const float inv_old = d.inv_norm[row], g_old = d.g[row];
-    float* dv = d.dv + (long)row * d.cols;
-    const float k1 = g_old * inv_old, k2 = dot * inv_old * inv_old;
-    float ss = 0.0f;
-    for (int c = lane; c < d.cols; c += 64) {
-        const float gv = k1 * (dw[c] - k2 * v[c]);
-        dv[c] = gv;
-        adam(v + c, gv);
-        const float vn = v[c];
-        ss += vn * vn;
-    }
-    const float dgv = dot * inv_old;
-    if (lane == 0) {
-        d.dg[row] = dgv;
-        adam(d.g + row, dgv);
-        if (d.bias != nullptr) adam(d.bias + row, grad_base[(d.bias + row) - param_base]);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
-    const float inv = 1.0f / sqrtf(ss);
-    const float g_new = __shfl(d.g[row], 0);      // (lane 0 has just written it; every lane reads its own copy of lane 0's value)
-    const float sc = g_new * inv;
-    float* w = d.w_eff + (long)row * d.cols;
-    for (int c = lane; c < d.cols; c += 64) w[c] = v[c] * sc;
-    if (lane == 0) d.inv_norm[row] = inv;
-}
-
 }  // namespace vdn
-
-extern "C" int vdn_wn_update(const VdnWnUpdateDesc* descs_dev, int n_desc, int max_rows, const float* param_base, const float* grad_base,
-                             float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2, float eps, int32_t step, void* stream) {
-    if (!descs_dev || n_desc <= 0 || max_rows <= 0 || !param_base || !grad_base || !exp_avg || !exp_avg_sq || step < 1) return -1;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    hipLaunchKernelGGL(vdn::wn_update_kernel, dim3(n_desc, (max_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, descs_dev, param_base,
-                       grad_base, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2));
-    return (int)hipGetLastError();
-}
 
 extern "C" int vdn_loss_fwd_bwd(const VdnLossArgs* a, void* stream) {
     if (!a || a->B <= 0 || !a->color || !a->true_rgb || !a->eik || !a->g_color || !a->g_eik || !a->out_scalars) return -1;

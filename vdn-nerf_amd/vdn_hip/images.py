@@ -216,7 +216,7 @@ class NetImages:
         return True
 
 
-def refresh_together(images, stream, cache, materialize=True):
+def refresh_together(images, stream, cache):
     """Rebuild the weight images of several networks with ONE weight-norm launch and ONE image-build launch (the
     descriptor tables are self-contained, so they concatenate). Used after the fused Adam step, which changes every
     network at once: 2 launches instead of 2 per network. `cache` (a dict) keeps the concatenated tables."""
@@ -229,8 +229,7 @@ def refresh_together(images, stream, cache, materialize=True):
         cache["ch"] = torch.cat([im.chunk_table for im in images])
         cache["n_wn"], cache["n_ch"] = sum(im._n_wn for im in images), sum(im._n_ch for im in images)
         cache["max_rows"] = max(im.max_rows for im in images)
-    if materialize:          # (False: vdn_wn_update has just written W_eff and 1 / ||v|| of these networks)
-        lib.call("vdn_weightnorm_materialize", lib.ptr(cache["wn"]), cache["n_wn"], cache["max_rows"], stream)
+    lib.call("vdn_weightnorm_materialize", lib.ptr(cache["wn"]), cache["n_wn"], cache["max_rows"], stream)
     lib.call("vdn_build_images", lib.ptr(cache["ch"]), cache["n_ch"], stream)
     for im in images:
         im._key = tuple(t._version for t in im._params())

@@ -386,26 +386,6 @@ class TrainEngine:
                 self.wn_groups[k] = (torch.from_numpy(wn[idx].view(np.uint8).copy()).to(dev), len(idx), max(rows[i][1].shape[0] for i in idx))
         if "sdf" in self.wn_groups:
             self.wn_groups["sdf_pipe"] = self.wn_groups["sdf"]
-        # vdn_wn_update tables (weight-norm backward + Adam + weight norm of a group in one launch): the SDF network + the variance
-        self.wn_update = {}
-        self.skip_wn_bwd = set()          # groups whose weight-norm backward rides in vdn_wn_update (set by the Trainer)
-        sdf = self.nets["sdf"]
-        urows = []
-        for name, (g, v, b) in sdf.img.matrices.items():
-            if g is None:
-                continue
-            urows.append(dict(g=g.data_ptr(), v=v.data_ptr(), bias=0 if b is None else b.data_ptr(), dw_eff=sdf.dweff_view(name).data_ptr(),
-                              dg=sdf.grads[id(g)].data_ptr(), dv=sdf.grads[id(v)].data_ptr(),
-                              inv_norm=sdf.img.inv_norm.data_ptr() + 4 * sdf.img.r_off[name], w_eff=sdf.img.weff_view(name).data_ptr(),
-                              rows=v.shape[0], cols=v.shape[1]))
-        var = self.r.deviation_network.variance
-        urows.append(dict(g=0, v=var.data_ptr(), bias=0, dw_eff=0, dg=0, dv=0, inv_norm=0, w_eff=0, rows=1, cols=1))
-        if len(urows) == len(sdf.img.matrices) + 1:          # (every SDF layer weight-normed: the shipped configuration)
-            ud = np.zeros(len(urows), dtype=lib.struct_dtype("VdnWnUpdateDesc"))
-            for i, u in enumerate(urows):
-                for k, val in u.items():
-                    ud[i][k] = val
-            self.wn_update["sdf"] = (torch.from_numpy(ud.view(np.uint8).copy()).to(dev), len(urows), max(u["rows"] for u in urows))
         self._param_ptrs = self._ptr_key()
 
     @property
@@ -822,7 +802,7 @@ class TrainEngine:
             lib.call("vdn_dw_finalize", lib.ptr(tab), n, max_m, 0, stream)
             if phase1:
                 lib.call("vdn_dw_finalize", lib.ptr(tab), n, max_m, 1, stream)
-        if group in self.wn_groups and group not in self.skip_wn_bwd:
+        if group in self.wn_groups:
             tab, n, max_rows = self.wn_groups[group]
             lib.call("vdn_weightnorm_bwd", lib.ptr(tab), n, max_rows, stream)
 

@@ -108,9 +108,6 @@ class Trainer:
         if self.overlap and self.engine._side is not None and os.environ.get("VDN_MAIN_PRIORITY", "0") == "1":
             self._main = torch.cuda.Stream(device=self.dev, priority=-1)
         self.engine.join_hook = self.join
-        self._fused_sdf_update = (not self.coll.enabled and "sdf" in self.engine.wn_update and os.environ.get("VDN_FUSED_UPDATE", "1") != "0")
-        if self._fused_sdf_update:
-            self.engine.skip_wn_bwd.add("sdf")
         # the networks this Trainer updates on its side stream wait for that update whenever their weight images are used
         # (dpt_models/fields.py::_HipNet._images): rendering with the renderer right after train_step needs no explicit join().
         # The SDF network and the variance are updated on the caller's stream and need none (the next step's sampler runs on
@@ -277,15 +274,6 @@ class Trainer:
                 images.refresh_together([eng.nets[k].img for k in nets], stream, self._img_cache.setdefault(part, {}))
 
         def update_sdf(stream):
-            if self._fused_sdf_update:
-                # one rank: weight-norm backward, Adam and the weight norm of the SDF network (+ the variance) in one launch
-                # (vdn_wn_update: all three are row-local) instead of three, in front of the weight-image build on the path into
-                # the next step's sampler; same bits (tests/test_gpu_train_parity.py). VDN_FUSED_UPDATE=0: the three launches
-                tab, n, max_rows = eng.wn_update["sdf"]
-                lib.call("vdn_wn_update", lib.ptr(tab), n, max_rows, lib.ptr(self._param_flat), lib.ptr(grad), lib.ptr(self._exp_avg),
-                         lib.ptr(self._exp_avg_sq), lr, 0.9, 0.999, 1e-8, main_step, stream)
-                images.refresh_together([eng.nets["sdf"].img], stream, self._img_cache.setdefault("sdf", {}), materialize=False)
-                return
             self.coll.finish(self.coll.begin([grad[b:e] for b, e in self._sdf_ranges]), tag="grad_sdf")
             adam(self._sdf_ranges, main_step, stream)
             images.refresh_together([eng.nets["sdf"].img], stream, self._img_cache.setdefault("sdf", {}))
