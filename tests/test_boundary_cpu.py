@@ -134,3 +134,36 @@ def test_chunk_tables_cover_every_chunk_once(precision):
             assert all(int(d["tail"]) == im.weff.data_ptr() + 4 * (im.w_off["lin0"] + 32) for d in mine)
         if precision == "fp32":
             assert "c2" not in im.blobs
+
+
+def test_code_warm_up_sizes_stay_inside_their_kernels(tmp_path):
+    """csrc/vdn_common.h warm_code_begin: the first workgroups of a training-step kernel read kWarmCode* bytes of their own code from
+    the warm-up site on, so that every XCD's L2 holds it before the other workgroups arrive. A constant larger than the kernel
+    would read past the end of the loaded code object: each constant + 4 KiB (the warm-up site sits within the first KiB's of the
+    kernel) must fit the smallest symbol its `// symbol:` note names, in the library that ships."""
+    import os
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(llvm, "llvm-objdump")):
+        pytest.skip("no llvm-objdump")
+    from vdn_hip import build
+    shutil.copy(build.LIB, tmp_path / "lib.so")
+    subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", str(tmp_path / "lib.so")], check=True, capture_output=True)
+    sizes = {}
+    for f in os.listdir(tmp_path):
+        if "amdgcn" not in f:
+            continue
+        out = subprocess.run([os.path.join(llvm, "llvm-readelf"), "-s", "-W", str(tmp_path / f)], check=True, capture_output=True, text=True).stdout
+        for line in out.splitlines():
+            p = line.split()
+            if len(p) >= 8 and p[3] == "FUNC":
+                sizes[p[7]] = int(p[2], 0)
+    assert sizes
+    src = open(os.path.join(os.path.dirname(build.__file__), "..", "csrc", "vdn_common.h")).read()
+    notes = re.findall(r"constexpr int (kWarmCode\w+) = (\d+) \* 1024;\s*// symbol: (\S+)", src)
+    assert len(notes) >= 8
+    for name, kib, sub in notes:
+        match = [s for n, s in sizes.items() if re.search(sub, n)]
+        assert match, (name, sub)
+        assert int(kib) * 1024 + 4096 <= min(match), (name, kib, min(match))

@@ -3,6 +3,7 @@
 // transposed layer yields d loss / d [feature | points, PE(view), normals]. Per-layer deltas go to
 // HBM row-major for the weight-gradient GEMM. Adjoint of fields.py:148-176.
 #pragma once
+#include <type_traits>
 #include "mlp_engine.h"
 #include "vdn_kernels.h"
 
@@ -19,6 +20,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_b
     const WorkRow wr = work_row(a.active_idx, a.n_active, a.P, P::kWaves, ws.wave, c);
     if (wr.none) return;
     warm_sink_t wsink = ws.warm_begin(wr.n_wg, 256 * P::kMinWavesPerEU);      // (mlp_engine.h; ends before the ring starts)
+    warm_sink_t wcode = warm_code_begin((std::is_same<P, BF16>::value) ? kWarmCodeRenderBwd : 0, wr.n_wg, 256 * P::kMinWavesPerEU);      // (the kernel's own code: vdn_common.h)
     const bool ok = wr.ok;
     const long p = wr.row, pd = wr.point;          // p: row of saves / deltas / d_feat; pd: dense point id
     const long PS = P::plane(a.P, 256);
@@ -66,6 +68,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_b
     };
     ws.all_issue = __any(ok);
     warm_l2_end(wsink);
+    warm_l2_end(wcode);
     ws.start();
     dense<P, NT_OUT, 8, false, kBwdPrefetch>(ws, X, 0, ldH(3), mask_store(Y, 3), P::kTileOps, P::kTileOps);   // W4^T
     dense<P, 8, 8, false, kBwdPrefetch>(ws, Y, 0, ldH(2), mask_store(X, 2), P::kTileOps, P::kTileOps);        // W3^T

@@ -149,6 +149,7 @@ __global__ __launch_bounds__(kWaves * 64, 1) void sdf_bwd_split_kernel(SdfRbarAr
     if (wr.none) return;
     warm_l2(ra.blob, 63 * kStride, wr.n_wg, 256);       // (mlp_engine.h: both weight streams are cold inside a training step)
     warm_l2(fa.blob, 67 * kStride, wr.n_wg, 256);
+    { warm_sink_t wcode = warm_code_begin(kWarmCodeSdfBwdSplit, wr.n_wg, 256); warm_l2_end(wcode); }
     const bool ok = wr.ok;
     const long p = wr.row, pd = wr.point;
     const long Pn = P::rows(ra.P), PS = Pn * 256;

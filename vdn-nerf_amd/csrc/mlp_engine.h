@@ -30,47 +30,6 @@ VDN_DEV unsigned pack_bf16x2(float a, float b) {
 VDN_DEV float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
 VDN_DEV float bf16_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
 
-// L2 warm-up of a kernel's weight stream. Inside a training step every MLP kernel starts on caches full of other kernels'
-// planes: each chunk of its weight stream is then an HBM miss for the first workgroup of each XCD that asks for it, and as the
-// workgroups of a launch walk the stream in lockstep, every one of its ~40-140 chunk steps waits that miss out (measured on the fused
-// SDF kernel: 196 us in the step, 144 us repeated back to back with the stream L2-resident; 400 MB of unrelated stores in front
-// of the back-to-back launch reproduce the 196: tools/dev/sdf_var_probe.py). So the FIRST ROUND of workgroups reads the whole
-// stream once, up front and in parallel: blocks b, b + 8, b + 16 .. share an XCD (round-robin dispatch - a placement assumed for
-// SPEED only), the j-th of them reads slice j; 8 L2s x 1-3 MB from HBM take a few microseconds instead of ~100 exposed misses.
-//   n_wg: workgroups of this launch that have rows; resident: workgroups the chip holds at once (256 CUs x workgroups per CU).
-#ifndef VDN_WARM_L2
-#define VDN_WARM_L2 1
-#endif
-// Two halves, so that a kernel can do its own prologue (input loads, encodings) while the stream arrives: warm_l2_begin issues the
-// loads and hands back the registers they land in, warm_l2_end waits for them. The loads write that register quadruple whenever
-// they return, so it must stay allocated until they have: the compiler does not know these asm statements are loads and would hand
-// the registers to the next values while data is still on its way into them (which is why _end takes it as an in-out operand).
-// Un-counted vector-memory operations in flight only make a counted or compiler-placed s_waitcnt vmcnt(N) return later.
-typedef unsigned warm_sink_t __attribute__((ext_vector_type(4)));
-VDN_DEV warm_sink_t warm_l2_begin(const char* blob, int bytes, long n_wg, int resident) {
-    warm_sink_t sink = {0u, 0u, 0u, 0u};
-#if VDN_WARM_L2
-    const int first = n_wg < resident ? (int)n_wg : resident;          // workgroups of the first round
-    if (bytes <= 0 || first < 128 || (int)blockIdx.x >= first) return sink;     // (a small launch's few workgroups would each read MBs)
-    const int slices = first >> 3;
-    const int j = blockIdx.x >> 3;
-    if (j >= slices) return sink;
-    const int slice = ((bytes + slices - 1) / slices + 255) & ~255;
-    const int begin = j * slice, end = begin + slice < bytes ? begin + slice : bytes;
-    for (int off = begin + (int)threadIdx.x * 16; off < end; off += (int)blockDim.x * 16)
-        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(blob + off) : "memory");
-#endif
-    return sink;
-}
-VDN_DEV void warm_l2_end(warm_sink_t& sink) {
-#if VDN_WARM_L2
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink)::"memory");
-#endif
-}
-VDN_DEV void warm_l2(const char* blob, int bytes, long n_wg, int resident) {
-    warm_sink_t sink = warm_l2_begin(blob, bytes, n_wg, resident);
-    warm_l2_end(sink);
-}
 
 // Weight stream: a ring of NSLOT LDS slots, each chunk fetched DEPTH = NSLOT-1 chunk steps before it is used
 // (measured: with a depth of 1 every step waited ~0.9 us for its chunk - the L2 -> LDS latency - which put a

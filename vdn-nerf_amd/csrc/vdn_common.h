@@ -39,6 +39,74 @@ VDN_DEV void static_for(F&& f) {
 
 VDN_DEV int rho(int t, int h) { return (t & 3) + 8 * (t >> 2) + 4 * h; }
 
+// L2 warm-up of a kernel's weight stream. Inside a training step every MLP kernel starts on caches full of other kernels'
+// planes: each chunk of its weight stream is then an HBM miss for the first workgroup of each XCD that asks for it, and as the
+// workgroups of a launch walk the stream in lockstep, every one of its ~40-140 chunk steps waits that miss out (measured on the fused
+// SDF kernel: 196 us in the step, 144 us repeated back to back with the stream L2-resident; 400 MB of unrelated stores in front
+// of the back-to-back launch reproduce the 196: tools/dev/sdf_var_probe.py). So the FIRST ROUND of workgroups reads the whole
+// stream once, up front and in parallel: blocks b, b + 8, b + 16 .. share an XCD (round-robin dispatch - a placement assumed for
+// SPEED only), the j-th of them reads slice j; 8 L2s x 1-3 MB from HBM take a few microseconds instead of ~100 exposed misses.
+//   n_wg: workgroups of this launch that have rows; resident: workgroups the chip holds at once (256 CUs x workgroups per CU).
+#ifndef VDN_WARM_L2
+#define VDN_WARM_L2 1
+#endif
+// Two halves, so that a kernel can do its own prologue (input loads, encodings) while the stream arrives: warm_l2_begin issues the
+// loads and hands back the registers they land in, warm_l2_end waits for them. The loads write that register quadruple whenever
+// they return, so it must stay allocated until they have: the compiler does not know these asm statements are loads and would hand
+// the registers to the next values while data is still on its way into them (which is why _end takes it as an in-out operand).
+// Un-counted vector-memory operations in flight only make a counted or compiler-placed s_waitcnt vmcnt(N) return later.
+typedef unsigned warm_sink_t __attribute__((ext_vector_type(4)));
+VDN_DEV warm_sink_t warm_l2_begin(const char* blob, int bytes, long n_wg, int resident) {
+    warm_sink_t sink = {0u, 0u, 0u, 0u};
+#if VDN_WARM_L2
+    const int first = n_wg < resident ? (int)n_wg : resident;          // workgroups of the first round
+    if (bytes <= 0 || first < 128 || (int)blockIdx.x >= first) return sink;     // (a small launch's few workgroups would each read MBs)
+    const int slices = first >> 3;
+    const int j = blockIdx.x >> 3;
+    if (j >= slices) return sink;
+    const int slice = ((bytes + slices - 1) / slices + 255) & ~255;
+    const int begin = j * slice, end = begin + slice < bytes ? begin + slice : bytes;
+    for (int off = begin + (int)threadIdx.x * 16; off < end; off += (int)blockDim.x * 16)
+        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(blob + off) : "memory");
+#endif
+    return sink;
+}
+VDN_DEV void warm_l2_end(warm_sink_t& sink) {
+#if VDN_WARM_L2
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink)::"memory");
+#endif
+}
+VDN_DEV void warm_l2(const char* blob, int bytes, long n_wg, int resident) {
+    warm_sink_t sink = warm_l2_begin(blob, bytes, n_wg, resident);
+    warm_l2_end(sink);
+}
+
+// The kernel's own CODE is as cold as its weight stream: the MLP kernels are 40 - 140 KB of straight-line code (the chunk-step streams
+// are fully unrolled), far beyond the instruction cache, so every workgroup streams it from L2 - and inside a training step, from
+// HBM, at the head of every instruction-fetch miss. tools/dev/cold_probe.py: the step's fused SDF forward takes 116 us back to back,
+// 155 us behind 400 MB of unrelated loads (weight stream warmed as above), and 124 us when the same kernel has just run on 8
+// workgroups - one per XCD - in between: 31 of the 39 us are the code. So the first round of workgroups also reads the kernel's
+// code into L2 as data, sliced like the stream: `bytes` from the current program counter on - a per-kernel constant chosen BELOW
+// the kernel's code size (tests/test_boundary_cpu.py checks it against the symbol table of the built objects), so the reads stay
+// inside the kernel's own code.
+VDN_DEV warm_sink_t warm_code_begin(int bytes, long n_wg, int resident) {
+#ifdef VDN_NO_CODE_WARM                     // (development A/B: VDN_BUILD_VARIANT="nocw:-DVDN_NO_CODE_WARM")
+    bytes = 0;
+#endif
+    const char* pc = reinterpret_cast<const char*>(__builtin_amdgcn_s_getpc() & ~15L);
+    return warm_l2_begin(pc, bytes & ~255, n_wg, resident);
+}
+// bytes of code each kernel warms from its warm-up site on. One line per kernel: `// symbol: <substring of the mangled name>` is a regular expression for the
+// mangled names the constant applies to (tests/test_boundary_cpu.py: constant + 4 KiB <= the smallest matching symbol's size)
+constexpr int kWarmCodeSdfFwd2Save = 124 * 1024;      // symbol: sdf_fwd2_kernelILi1ELb1E
+constexpr int kWarmCodeSdfFwd2 = 104 * 1024;          // symbol: sdf_fwd2_kernelILi1ELb0E
+constexpr int kWarmCodeSdfFwd2Mode0 = 48 * 1024;      // symbol: sdf_fwd2_kernelILi0E
+constexpr int kWarmCodeNerfFwd2 = 48 * 1024;          // symbol: nerf_fwd2_kernelILb.ELb1E
+constexpr int kWarmCodeNerfBwd = 80 * 1024;           // symbol: nerf_bwd_kernelINS_4BF16E
+constexpr int kWarmCodeRenderFwd = 28 * 1024;         // symbol: rendernet_fwd_kernelINS_4BF16E
+constexpr int kWarmCodeRenderBwd = 36 * 1024;         // symbol: rendernet_bwd_kernelINS_4BF16E
+constexpr int kWarmCodeSdfBwdSplit = 20 * 1024;       // symbol: sdf_bwd_split_kernel
+
 // async global -> LDS copy of 16 B per lane; LDS destination = wave-uniform base + lane*16.
 // Inline asm, not __builtin_amdgcn_global_load_lds: with the builtin, hipcc's wait-count pass marks a pending FLAT access
 // and from then on emits s_waitcnt lgkmcnt(0) in front of every LDS consumer - a full LDS round trip before each MFMA
