@@ -22,7 +22,7 @@ by = defaultdict(list)
 for name, s, e in keep:
     by[name].append((e - s) / 1e3)
 # steps in the window = launches of a kernel that runs exactly once per step
-steps = len(by.get("vdn::composite_bwd_kernel(VdnCompositeBwdArgs)", [])) or 1
+steps = len(by.get("vdn::coarse_z_kernel(VdnCoarseArgs)", [])) or 1
 busy = sum(sum(v) for v in by.values())
 print("# window: last %.0f %% of the trace = %.1f ms, %d training steps, kernel time %.1f us/step (sum over kernels)" % (
     100 * frac, (t1 - cut) / 1e6, steps, busy / steps))

@@ -371,6 +371,9 @@ __global__ __launch_bounds__(kRW * 64) void composite_train_kernel(CompositeArgs
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = blockIdx.x * kRW + wave;
     if (r >= fa.B) return;
+    // (the launch sits alone on the step's critical path between the forward and the backward kernels, on caches full of their
+    // planes: its 47 KB of code arrive as data while the ray's planes are loaded - vdn_common.h)
+    warm_sink_t wcode = warm_code_begin(kWarmCodeCompositeTrain, gridDim.x, 2048);
     const RowOut ro = composite_row(fa, r, lane, CompositeGlobalSrc{fa.sdf, fa.normals, fa.color}, s_w[wave], s_in[wave]);
     CompositeBwdOvr ov;
     ov.on = true;
@@ -387,6 +390,7 @@ __global__ __launch_bounds__(kRW * 64) void composite_train_kernel(CompositeArgs
     ov.g_eik = igr_weight;
     ov.eik_den = (float)(*fg_count) + 1e-5f;
     composite_bwd_row(ba, r, wave, lane, ov);
+    warm_l2_end(wcode);
 }
 
 // Adjoint of the ray geometry (include/vdn_render.h: VdnRayAdjointArgs), one wave per ray, sample i = kE * lane + e.

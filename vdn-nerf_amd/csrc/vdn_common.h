@@ -106,6 +106,7 @@ constexpr int kWarmCodeNerfBwd = 80 * 1024;           // symbol: nerf_bwd_kernel
 constexpr int kWarmCodeRenderFwd = 28 * 1024;         // symbol: rendernet_fwd_kernelINS_4BF16E
 constexpr int kWarmCodeRenderBwd = 36 * 1024;         // symbol: rendernet_bwd_kernelINS_4BF16E
 constexpr int kWarmCodeSdfBwdSplit = 20 * 1024;       // symbol: sdf_bwd_split_kernel
+constexpr int kWarmCodeCompositeTrain = 40 * 1024;    // symbol: composite_train_kernel
 
 // async global -> LDS copy of 16 B per lane; LDS destination = wave-uniform base + lane*16.
 // Inline asm, not __builtin_amdgcn_global_load_lds: with the builtin, hipcc's wait-count pass marks a pending FLAT access

@@ -763,10 +763,10 @@ class TrainEngine:
         if self._side is None:
             self.weight_grads(group, _stream())
             return None
-        if group != "nerf":
-            self._side.wait_event(self._ev_heads)
-        if after is not None:
+        if after is not None:           # (recorded on the caller's stream behind the heads' backward: covers it)
             self._side.wait_event(after)
+        elif group != "nerf":
+            self._side.wait_event(self._ev_heads)
         self.weight_grads(group, self._side.cuda_stream)
         self._pending = False            # joined by the caller's own event, not by _join()
         return self._side
@@ -780,9 +780,10 @@ class TrainEngine:
         if self._side is None:
             self.weight_grads("rest", _stream())
             return None
-        self._side.wait_event(self._ev_heads)
-        if after is not None:
+        if after is not None:           # (recorded on the caller's stream behind the heads' backward: covers it)
             self._side.wait_event(after)
+        else:
+            self._side.wait_event(self._ev_heads)
         self.weight_grads("rest", self._side.cuda_stream)
         self._pending = False            # joined by the caller's own event, not by _join()
         return self._side
@@ -855,12 +856,18 @@ class TrainEngine:
         return c
 
     # ------------------------------------------------------------------------------------------
-    def backward(self, g_color, g_feat, g_weights, g_eik, g_cdf=None, g_gradients=None, defer_rest=False, gemm_event=None):
+    def backward(self, g_color, g_feat, g_weights, g_eik, g_cdf=None, g_gradients=None, defer_rest=False, gemm_event=None,
+                 fork_event=None, heads_event=True):
         """Upstream grads (any may be None) -> list of parameter grads (clones) per network. g_cdf [B,N] / g_gradients
         [B,N,3]: adjoints of the `cdf_fine` / `gradients` outputs (the reference returns them attached, renderer.py:426-439).
         defer_rest (the Trainer's hot loop): only the SDF network's and the variance's gradients are complete on return (on the
         caller's stream); the caller finishes the others with rest_weight_grads() - on the side stream, behind the background
-        network's backward - so that they overlap whatever follows on the main stream."""
+        network's backward - so that they overlap whatever follows on the main stream.
+        Every event recorded on the caller's stream is a marker packet in front of the next kernel of the step's critical chain
+        (3 - 4 us each: tools/dev/event_probe.py), so the Trainer passes what it already has: fork_event = an event it recorded
+        on the current stream since the forward's last launch (the side stream waits for that one instead of a new one);
+        heads_event=False when it will hand side_weight_grads / rest_weight_grads an `after` event recorded later on this stream
+        (which then also covers the heads' backward)."""
         r, w, st = self.r, self.w, _stream()
         rays_o, rays_d, background_rgb, car, z = self._ctx
         keep = [t.contiguous() if t is not None else None for t in (g_color, g_feat, g_weights, g_eik, g_cdf, g_gradients)]
@@ -899,7 +906,10 @@ class TrainEngine:
             if nerf_late:
                 self._ev_fork.record(torch.cuda.current_stream())
             else:
-                self._fork()
+                if fork_event is not None and self._side is not None:
+                    self._side.wait_event(fork_event)
+                else:
+                    self._fork()
                 lib.call("vdn_nerf_mlp_bwd" + self.sfx, nb, self._side_handle(st))
                 self._side_done()
 
@@ -927,7 +937,7 @@ class TrainEngine:
             self._side.wait_event(self._ev_fork)
             lib.call("vdn_nerf_mlp_bwd" + self.sfx, nb, self._side.cuda_stream)
             self._side_done()
-        if defer_rest and self._side is not None:
+        if defer_rest and self._side is not None and heads_event:
             self._ev_heads.record(torch.cuda.current_stream())      # the heads' deltas (operands of the rest group) are complete
 
         use_pipe = self.pipe is not None and not rg and os.environ.get("VDN_SDF_PIPE", "0") != "0"

@@ -102,7 +102,7 @@ class Trainer:
         self.overlap = (os.environ.get("VDN_OVERLAP", "1") != "0") if overlap is None else bool(overlap)
         self._ev_gemm, self._ev_rest, self._ev_tail = (torch.cuda.Event() for _ in range(3))
         self._ev_comp, self._ev_log, self._log_stream = torch.cuda.Event(), torch.cuda.Event(), None
-        self._rest_pending = False
+        self._rest_pending, self._rest_gen, self._joined = False, 0, {}
         self._jitter, self._jitter_next = None, 0
         self._main = None
         if self.overlap and self.engine._side is not None and os.environ.get("VDN_MAIN_PRIORITY", "0") == "1":
@@ -279,8 +279,14 @@ class Trainer:
             images.refresh_together([eng.nets["sdf"].img], stream, self._img_cache.setdefault("sdf", {}))
 
         grad = eng._grad_flat
-        eng.backward(self.g_color, g_feats, g_weights, self.g_eik, defer_rest=True, gemm_event=self._ev_gemm if self.overlap else None)
         split = self.overlap and os.environ.get("VDN_SPLIT_REST", "1") != "0" and "nerf" in eng.dw_groups and "heads" in eng.dw_groups
+        # (events on the critical chain are marker packets, 3 - 4 us each: the side stream's fork reuses _ev_comp - nothing was
+        # launched on this stream since - the SDF GEMM's event is only recorded for the schedule that waits for it, and the heads'
+        # event is covered by the `after` events below, which are recorded later on this stream)
+        trim = os.environ.get("VDN_EVENT_TRIM", "1") != "0"           # (0: the A/B arm that records them all)
+        eng.backward(self.g_color, g_feats, g_weights, self.g_eik, defer_rest=True,
+                     gemm_event=self._ev_gemm if (self.overlap and not (split and trim)) else None,
+                     fork_event=self._ev_comp if (fused and trim) else None, heads_event=not trim)
         side = None
         if split:
             # the background network's half right behind its backward, beside the SDF backward on the main stream ...
@@ -300,6 +306,7 @@ class Trainer:
             with torch.cuda.stream(side):
                 update_rest(side.cuda_stream, "heads")
                 self._ev_rest.record(side)
+                self._rest_gen += 1
             self._rest_pending = True
         else:
             if split:                            # no side stream: both halves on the caller's stream
@@ -317,6 +324,7 @@ class Trainer:
                     with torch.cuda.stream(side):
                         update_rest(side.cuda_stream)
                         self._ev_rest.record(side)
+                        self._rest_gen += 1
                     self._rest_pending = True
         if fused:
             torch.cuda.current_stream().wait_event(self._ev_log)      # the scalars (long done) are ordered in front of what follows
@@ -333,11 +341,15 @@ class Trainer:
         """Order torch's current stream behind the side-stream half of the last step (colour / VDN / background gradients,
         their Adam step and weight images). train_step calls it before its forward; call it before reading those parameters
         or rendering with the renderer outside the Trainer."""
-        # `_rest_pending` = a side-stream half has ever been issued. The wait is repeated on every call, on whatever stream is
-        # current: waiting for an event that has completed costs nothing, and a flag cleared by a wait on one stream would
-        # leave a step issued on another stream unordered.
+        # `_rest_pending` = a side-stream half has ever been issued. One wait per stream and per recording of the event: a
+        # wait the host cannot see to be complete is a barrier packet in the stream's queue (3 - 7 us each on the step's critical
+        # path, and the forward asks once per network: tools/dev/gap_probe.py), while a single flag cleared by a wait on one
+        # stream would leave a step issued on another stream unordered.
         if self._rest_pending:
-            torch.cuda.current_stream().wait_event(self._ev_rest)
+            cur = torch.cuda.current_stream()
+            if self._joined.get(cur.cuda_stream) != self._rest_gen or os.environ.get("VDN_EVENT_TRIM", "1") == "0":
+                cur.wait_event(self._ev_rest)
+                self._joined[cur.cuda_stream] = self._rest_gen
 
     def _eikonal_begin(self, eng):
         """Right behind the fused SDF kernel: this rank's eikonal sums (vdn_eikonal_terms: the compositor's own expressions) and
