@@ -128,3 +128,30 @@ def test_fused_shading_declines_what_it_does_not_cover():
     t = torch.zeros(1, dtype=torch.int32, device=dev)
     assert not lib.try_call("vdn_shade_fused_bf16", sa, lib.ptr(r.color_network._images().blobs["c2"]), 1, cm, lib.ptr(t),
                             torch.cuda.current_stream().cuda_stream)
+
+
+def test_persistent_background_outputs_and_jitter_blocks():
+    """render() keeps the background network's outputs in one buffer per stream (rows off the work list hold zeros or an earlier
+    batch's finite values: render_core multiplies them by zero) and draws its jitter 16 batches at a time. Neither may show:
+    a batch rendered behind a DIFFERENT batch equals the same batch on a fresh renderer bit for bit; the same seed gives the
+    same image; consecutive batches get different jitter."""
+    from vdn_train import synth, factory
+    dev = torch.device("cuda:0")
+    st = synth.make_all_states(0, variance=0.4)
+    r1 = factory.build_renderer(device=dev, states=st, precision="bf16")
+    r2 = factory.build_renderer(device=dev, states=st, precision="bf16")
+    a, kwa = _batch(512, dev, seed=0)
+    b, kwb = _batch(512, dev, seed=4, crop=420)
+    _render(r1, a, True, **kwa)
+    out1 = _render(r1, b, True, **kwb)                   # behind batch a: its scratch buffer holds a's outputs
+    out2 = _render(r2, b, True, **kwb)                   # fresh buffer: zeros
+    for k in ("color_fine", "weights", "weight_sum", "gradient_error"):
+        assert torch.equal(out1[k], out2[k]), k
+    assert "_scratch" in r1.nerf.__dict__ and len(r1.nerf.__dict__["_scratch"]) == 1
+    # jitter: seeded draws repeat, consecutive draws differ
+    torch.manual_seed(11)
+    z1 = _render(r1, a, True)["z_vals"].clone()
+    z1b = _render(r1, a, True)["z_vals"].clone()
+    torch.manual_seed(11)
+    z2 = _render(r1, a, True)["z_vals"]
+    assert torch.equal(z1, z2) and not torch.equal(z1, z1b)

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_f
     const int lane = ws.lane, c = lane & 31, h = lane >> 5;
     const WorkRow wr = work_row(a.active_idx, a.n_active, a.P, P::kWaves, ws.wave, c);
     if (wr.none) return;
-    // training step: the stream is cold (mlp_engine.h); it arrives in L2 underneath the input assembly below
+    // training step: the stream is cold (vdn_common.h: warm_l2); it arrives in L2 underneath the input assembly below
     warm_sink_t wsink = a.save_h != nullptr ? ws.warm_begin(wr.n_wg, 256 * P::kMinWavesPerEU) : warm_sink_t{0u, 0u, 0u, 0u};
     warm_sink_t wcode = warm_code_begin((a.save_h != nullptr && std::is_same<P, BF16>::value) ? kWarmCodeRenderFwd : 0, wr.n_wg, 256 * P::kMinWavesPerEU);      // (the kernel's own code: vdn_common.h)
     const bool ok = wr.ok;

@@ -358,7 +358,7 @@ struct ShadeExtra {
     const char* color_blob;     // the colour head's chunk stream ("c2", vdn_hip/images.py), same chunk format and stride
     int* ticket;                // [1] arrival counter, zero before the first launch (the last ray leaves it zero)
     int squeeze_out;            // fields.py:170-171
-    int warm_bytes, warm_bytes2;    // all modes: bytes of the weight stream(s) the first round of workgroups pulls into L2 up front (0 = off; mlp_engine.h: warm_l2)
+    int warm_bytes, warm_bytes2;    // all modes: bytes of the weight stream(s) the first round of workgroups pulls into L2 up front (0 = off; vdn_common.h: warm_l2)
     CompositeArgs cm;           // sdf / normals / color are not read (the samples come through LDS)
 };
 

@@ -329,9 +329,9 @@ class NeRF(_HipNet):
     def _streams(self):
         return images.nerf_streams(**self.conf)
 
-    def _run(self, pts4=None, dirs=None, rays=None, active=None):
+    def _run(self, pts4=None, dirs=None, rays=None, active=None, scratch=False):
         """`active` = (idx int32 [P], n int32 [1]) from vdn_background_active: only those points are evaluated, the other
-        outputs stay zero (render_core multiplies them by zero)."""
+        outputs stay zero - or, with `scratch`, finite (render_core multiplies them by zero)."""
         img = self._images()
         a = lib.VdnNerfArgs()
         a.blob = img.blobs["fwd"].data_ptr()
@@ -342,9 +342,19 @@ class NeRF(_HipNet):
         else:
             P, dev = pts4.shape[0], pts4.device
             a.pts4, a.dirs, a.n_per_ray = pts4.data_ptr(), dirs.data_ptr(), 1
-        # one allocation (and, with a work list, ONE fill launch: a 4-us launch each, on a 400-us render) for the outputs
+        # one allocation for the outputs. With a work list the rows off the list must hold FINITE values (render_core multiplies
+        # them by zero): a zero fill per call (a 5-us launch on a 360-us render) - or, for a caller that consumes the outputs
+        # before its next call on the same stream (`scratch`: NeuSRenderer.render), one buffer per stream that was zeroed once
+        # and afterwards holds zeros or an earlier call's outputs
         nf = 96 if self.gen_depth_feats else 0
-        buf = (torch.empty if active is None else torch.zeros)(P * (4 + nf), dtype=torch.float32, device=dev)
+        if active is not None and scratch:
+            key = (P, nf, str(dev), _stream())
+            buf = self.__dict__.setdefault("_scratch", {}).get(key)
+            if buf is None:
+                self.__dict__["_scratch"].clear()            # (one shape at a time: a new batch size replaces the old buffer)
+                buf = self.__dict__["_scratch"][key] = torch.zeros(P * (4 + nf), dtype=torch.float32, device=dev)
+        else:
+            buf = (torch.empty if active is None else torch.zeros)(P * (4 + nf), dtype=torch.float32, device=dev)
         density, rgb = buf[:P], buf[P:4 * P].view(P, 3)
         feat = buf[4 * P:].view(P, 96) if nf else None
         a.density, a.rgb, a.feat, a.P = density.data_ptr(), rgb.data_ptr(), (feat.data_ptr() if feat is not None else None), P

@@ -192,8 +192,22 @@ class NeuSRenderer:
             a.z_out = z_out.data_ptr()
         if perturb > 0:
             if t_rand is None and t_rand_out is None and O > 0:
-                # the two uniform draws of renderer.py:348,355 from one generator call (a launch less per batch)
-                u = torch.rand(B * (1 + O), device=dev)
+                # the two uniform draws of renderer.py:348,355 from one generator call, which covers the next 16 batches of this
+                # size (a 5-us launch in front of the sampler, on a 360-us render)
+                # - as long as nobody else touched the generator in between: re-seeding it, or drawing from it, starts a new block
+                # (a RenderPlan's capture draws its own inside the graph: every replay then gets fresh jitter)
+                if torch.cuda.is_current_stream_capturing():
+                    u = torch.rand(B * (1 + O), device=dev)
+                else:
+                    gen = torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
+                    state = (gen.initial_seed(), gen.get_offset())
+                    jit = self.__dict__.get("_jitter")
+                    if (jit is None or jit[0].shape[1] != B * (1 + O) or jit[0].device != dev or jit[1] >= jit[0].shape[0]
+                            or jit[2] != state):
+                        block = torch.rand(16, B * (1 + O), device=dev)
+                        jit = self.__dict__["_jitter"] = [block, 0, (gen.initial_seed(), gen.get_offset())]
+                    u = jit[0][jit[1]]
+                    jit[1] += 1
                 t_rand, t_rand_out = u[:B].view(B, 1), u[B:].view(B, O)
             if t_rand is None:
                 t_rand = torch.rand([B, 1], device=dev)                  # renderer.py:348
@@ -314,7 +328,8 @@ class NeuSRenderer:
             if self._pending_merge is not None:
                 tp.new_z, tp.M_old = self._pending_merge[0].data_ptr(), self._pending_merge[1]
             lib.call("vdn_train_prep", tp, st)
-            bg_density, bg_rgb, bg_feat = self.nerf._run(rays=(rays_o, rays_d, bg_mid), active=active3[:2])
+            bg_density, bg_rgb, bg_feat = self.nerf._run(rays=(rays_o, rays_d, bg_mid), active=active3[:2],
+                                                         scratch=not torch.cuda.is_current_stream_capturing())
         else:
             dists, mid_z = self._sections(z, N, sample_dist)
             if O > 0:                                                            # renderer.py:389-397
