@@ -474,12 +474,20 @@ def main():
             for i in range(2):
                 head.rend.render(*head.batches[i][:4], background_rgb=bg, cos_anneal_ratio=0.5)
             head.fence()
-            t1 = time.time()
             nf = max(100, K)
-            for i in range(nf):
-                head.rend.render(*head.batches[i % nb][:4], background_rgb=bg, cos_anneal_ratio=0.5)
-            head.fence()
-            extras["forward_only_rays_per_s"] = world * args.batch * nf / (time.time() - t1)
+            # (eager render() needs ~300 us of host time per call for ~350 us of device time: a busy host shows directly, so three
+            # regions, the median, and the host's enqueue time beside it; RenderPlan replays need 75 us of host time)
+            rates, host_us = [], []
+            for region in range(3):
+                t1 = time.time()
+                for i in range(nf):
+                    head.rend.render(*head.batches[i % nb][:4], background_rgb=bg, cos_anneal_ratio=0.5)
+                t2 = time.time()
+                head.fence()
+                rates.append(world * args.batch * nf / (time.time() - t1))
+                host_us.append((t2 - t1) / nf * 1e6)
+            extras["forward_only_rays_per_s"] = float(np.median(rates))
+            extras["forward_only_detail"] = {"regions_rays_per_s": rates, "host_enqueue_us_per_call": float(np.median(host_us)), "calls_per_region": nf}
             # the image loops may hand render() any batch size: 4 of the resident batches at once
             if nb >= 4:
                 big = [torch.cat([head.batches[(4 * j + k) % nb][c] for k in range(4)]) for j in range(2) for c in range(4)]

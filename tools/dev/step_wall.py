@@ -20,15 +20,17 @@ leg = bench.Leg(args, torch.device("cuda:0"), 1, 0, prec, wdepth, 64, crop=crop)
 for i in range(700 if prec == "bf16" else 120):
     leg.step(i)
 torch.cuda.synchronize()
-res = []
+res, host = [], []
 for r in range(R):
     torch.cuda.synchronize()
     t0 = time.time()
     for i in range(K):
         leg.step(700 + r * K + i)
+    t1 = time.time()
     torch.cuda.synchronize()
     res.append((time.time() - t0) / K * 1e6)
+    host.append((t1 - t0) / K * 1e6)
 eng = leg.trainer.engine
-print("%-14s wall %.1f us/step (min %.1f, max %.1f)  rows fg %d bg %d  loss %.5f" % (
-    tag, float(np.median(res)), min(res), max(res), int(eng.w["fg_active"][1].item()), int(eng.w["bg_active"][1].item()),
+print("%-14s wall %.1f us/step (min %.1f, max %.1f; host enqueue %.1f)  rows fg %d bg %d  loss %.5f" % (
+    tag, float(np.median(res)), min(res), max(res), float(np.median(host)), int(eng.w["fg_active"][1].item()), int(eng.w["bg_active"][1].item()),
     float(leg.trainer.scalars[0].item())))
