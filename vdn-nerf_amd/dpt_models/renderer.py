@@ -346,8 +346,9 @@ class NeuSRenderer:
 
     def _shade(self, rays_o, rays_d, dists, mid_z, bg, background_rgb, cos_anneal_ratio, depth_before_color=False):
         """render_core of the reference on sampled rays (renderer.py:239-315; SURVEY.md 8d "C2": PE + SDF MLP + gradient sweep,
-        colour / VDN heads, NeuS alpha + compositing) - three launches (four with the VDN head) on B x N points. `bg`: the
-        background pass' (density, rgb, feat, dists, mid_z) over all N + n_outside sections, or None."""
+        colour / VDN heads, NeuS alpha + compositing) on B x N points: ONE launch where vdn_shade_fused_bf16 covers the shape (bf16,
+        128 samples per ray; three with the VDN head), else the SDF kernel, the heads, the compositor and the eikonal reduce.
+        `bg`: the background pass' (density, rgb, feat, dists, mid_z) over all N + n_outside sections, or None."""
         B, N = mid_z.shape
         dev, st = mid_z.device, _stream()
         bg_density, bg_rgb, bg_feat, bg_dists, bg_mid = bg if bg is not None else (None,) * 5
