@@ -86,7 +86,11 @@ class TrainEngine:
         # bf16 SDF kernel runs one 128-point workgroup per CU: a work list of ~50 K rows is 1.5 rounds of workgroups, and the
         # half-empty round's CUs take the background network's workgroups (measured: 1.78 -> 1.65 ms per step).
         use_side = os.environ.get("VDN_SIDE_STREAM", "1") == "1" and torch.device(dev).type == "cuda"
-        self._side = torch.cuda.Stream(device=dev) if use_side else None
+        if use_side and os.environ.get("VDN_SIDE_PRIORITY", "normal") == "low":
+            from vdn_hip import streams
+            self._side = streams.low_priority_stream(dev)
+        else:
+            self._side = torch.cuda.Stream(device=dev) if use_side else None
         self._ev_fork = torch.cuda.Event() if use_side else None
         self._ev_join = torch.cuda.Event() if use_side else None
         # a second side stream for the VDN head's forward: it and the colour head read the same inputs and each fills only
