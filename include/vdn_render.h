@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VDN_ABI_VERSION 22
+#define VDN_ABI_VERSION 23
 
 int vdn_abi_version(void);
 
@@ -617,6 +617,17 @@ int vdn_composite_train(const VdnCompositeArgs* fwd_host, const VdnCompositeBwdA
                         const int32_t* fg_count, float igr_weight, float grad_scale, void* stream);
 /* gradient_error = sum(num) / (sum(den) + 1e-5) from the per-ray partial sums [B,2] -> eik_out [3] (ratio, num, den). */
 int vdn_eikonal_reduce(const float* eik_partial, int32_t B, float* eik_out, void* stream);
+/* The same idea with the VDN head (womsk_white_wdepth, one rank, no mask), where the 96 feature channels keep their own streaming
+ * launches: vdn_composite_fwd_train = the per-ray compositor + the features' weighted sums (vdn_feat_composite), which also write
+ * d loss / d render_feats of the depth-feature term (dpt_runner.py:239-243, mask = 1) into g_feats [B,C]; no eikonal reduce.
+ * vdn_composite_bwd_train = vdn_alpha_composite_bwd (bwd.g_feat = that g_feats) with the colour term's gradient made from
+ * (color_out, true_rgb) and the eikonal denominator from the foreground work list's length, as in vdn_composite_train; bwd.g_color,
+ * bwd.g_eik and bwd.eik are not read. Gradients bit-identical to vdn_alpha_composite_fwd + vdn_loss_fwd_bwd + vdn_alpha_composite_bwd;
+ * the loss SCALARS stay with vdn_eikonal_reduce + vdn_loss_fwd_bwd, which the caller may run off the critical path. -10: a
+ * configuration it does not cover (extra upstream gradients, ray adjoints). */
+int vdn_composite_fwd_train(const VdnCompositeArgs* fwd_host, const float* gt_feats, float* g_feats, float depth_weight, float grad_scale, void* stream);
+int vdn_composite_bwd_train(const VdnCompositeBwdArgs* bwd_host, const float* color_out, const float* true_rgb, float* g_color,
+                            const int32_t* fg_count, float igr_weight, float grad_scale, void* stream);
 
 /* ---- adjoint of the ray geometry of render_core / render_core_outside (renderer.py:107-115, 228-237): collects the
  * per-point input adjoints of the networks and the section-length adjoints of the compositor into

@@ -122,3 +122,47 @@ def test_fused_compositor_launch_is_bit_identical_to_the_four_launches(monkeypat
     assert torch.equal(trs[0].param_flat, trs[1].param_flat)
     assert torch.equal(trs[0].exp_avg, trs[1].exp_avg) and torch.equal(trs[0].exp_avg_sq, trs[1].exp_avg_sq)
     assert torch.isfinite(trs[0].param_flat).all()
+
+
+def test_loss_gradients_inside_the_compositor_launches_with_the_vdn_head(monkeypatch):
+    """womsk_white_wdepth, one rank, no mask: vdn_composite_fwd_train (the features' weighted sums write d loss / d render_feats on
+    the spot) + vdn_composite_bwd_train (the colour term's gradient made inside the compositor's adjoint, the eikonal denominator
+    from the foreground list's length), the eikonal reduce and the loss kernel on the logging stream - against
+    vdn_alpha_composite_fwd + vdn_loss_fwd_bwd + vdn_alpha_composite_bwd on the critical path (VDN_FUSED_COMPOSITE=0): scalars,
+    gradients, parameters and Adam moments of every step, bit for bit; the depth term switches on at step 4."""
+    import torch
+    from vdn_train import synth, factory
+    from vdn_train.trainer import Trainer
+    dev = torch.device("cuda:0")
+    B, seed = 512, 7
+    cams = synth.make_cameras(seed)
+    gg = lambda x: torch.tensor(x).to(dev)
+    conf = dict(warm_up_end=10, end_iter=300, anneal_end=40, extract_depth=True, depth_start_iter=3)
+    trs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("VDN_FUSED_COMPOSITE", fused)
+        torch.manual_seed(0)
+        trs.append(Trainer(factory.build_renderer(wdepth=True, device=dev, precision="bf16"), B, dev, conf=conf))
+    feats = gg(synth.uniform(seed, "fusedwd/feats", (B, 96)).astype(np.float32))
+    used = 0
+    for it in range(16):
+        o, d = synth.random_pixel_batch(seed, it, it % 40, B, cams=cams, crop=None if it % 2 else 420)
+        near, far = synth.near_far_from_sphere(o, d)
+        t1, t2 = synth.jitter(seed, it, B)
+        args = [gg(o), gg(d), gg(near), gg(far), gg(synth.target_colors(o, d, 0.5))]
+        sc = []
+        for fused, tr in zip(("1", "0"), trs):
+            monkeypatch.setenv("VDN_FUSED_COMPOSITE", fused)
+            sc.append(tr.train_step(*args, gt_feats=feats, t_rand=gg(t1), t_rand_out=gg(t2)).clone())
+        used += int(trs[0].__dict__.get("_g_log") is not None)
+        assert torch.equal(sc[0], sc[1]), (it, sc[0].tolist(), sc[1].tolist())
+        if it % 4 == 3:
+            assert torch.equal(trs[0].engine.grad_flat, trs[1].engine.grad_flat), it
+            assert torch.equal(trs[0].g_color, trs[1].g_color)
+            if it > 4:                                    # (the depth term is in the loss from step 4 on)
+                assert torch.equal(trs[0].g_feats, trs[1].g_feats)
+    assert used >= 10 and trs[1].__dict__.get("_g_log") is None
+    assert torch.equal(trs[0].param_flat, trs[1].param_flat)
+    assert torch.equal(trs[0].exp_avg, trs[1].exp_avg) and torch.equal(trs[0].exp_avg_sq, trs[1].exp_avg_sq)
+    assert trs[0]._depth_adam_steps == trs[1]._depth_adam_steps > 0
+    assert torch.isfinite(trs[0].param_flat).all()

@@ -104,7 +104,22 @@ __global__ __launch_bounds__(kRayWaves * 64) void composite_kernel(CompositeArgs
 // d_feats = sum_i w_i * feature_i (renderer.py:306-308) as its own launch, four waves per ray (the per-ray compositor has two
 // waves per CU: 44 us for these 56 MB inside it): wave w sums its quarter of the samples in order, lanes over channels, the
 // four partial sums are added in wave order.
-__global__ __launch_bounds__(256) void feat_composite_kernel(CompositeArgs a) {
+// fl (the training step with the VDN head, vdn_composite_fwd_train): also d loss / d render_feats of the depth-feature term
+// (dpt_runner.py:239-243 with mask = 1: loss_kernel's expressions, train_opt.hip) from the sums this block has just made
+struct FeatLoss {
+    const float* gt_feats;     // [B,C] or NULL
+    float* g_feats;            // [B,C]
+    float depth_weight, grad_scale;
+};
+VDN_DEV void feat_loss_grad(const CompositeArgs& a, const FeatLoss& fl, long idx, float f) {
+    const float mask_sum = (float)a.B + 1e-5f;                     // dpt_runner.py:213 with mask = ones
+    const float m = 1.0f;
+    const float e = (f - fl.gt_feats[idx]) * m;
+    const float sgn = e > 0.0f ? 1.0f : (e < 0.0f ? -1.0f : 0.0f);
+    fl.g_feats[idx] = sgn * m / mask_sum * fl.depth_weight * fl.grad_scale;
+}
+
+__global__ __launch_bounds__(256) void feat_composite_kernel(CompositeArgs a, FeatLoss fl) {
     __shared__ double s_part[4][128];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = blockIdx.x;
@@ -151,8 +166,16 @@ __global__ __launch_bounds__(256) void feat_composite_kernel(CompositeArgs a) {
         s_part[wave][lane + 64] = acc1;
         __syncthreads();
         if (wave == 0) {
-            if (v0) a.feat_out[(long)r * C + ch0] = (float)(((s_part[0][lane] + s_part[1][lane]) + s_part[2][lane]) + s_part[3][lane]);
-            if (v1) a.feat_out[(long)r * C + ch1] = (float)(((s_part[0][lane + 64] + s_part[1][lane + 64]) + s_part[2][lane + 64]) + s_part[3][lane + 64]);
+            if (v0) {
+                const float f = (float)(((s_part[0][lane] + s_part[1][lane]) + s_part[2][lane]) + s_part[3][lane]);
+                a.feat_out[(long)r * C + ch0] = f;
+                if (fl.gt_feats != nullptr) feat_loss_grad(a, fl, (long)r * C + ch0, f);
+            }
+            if (v1) {
+                const float f = (float)(((s_part[0][lane + 64] + s_part[1][lane + 64]) + s_part[2][lane + 64]) + s_part[3][lane + 64]);
+                a.feat_out[(long)r * C + ch1] = f;
+                if (fl.gt_feats != nullptr) feat_loss_grad(a, fl, (long)r * C + ch1, f);
+            }
         }
         __syncthreads();
     }
@@ -498,7 +521,24 @@ extern "C" int vdn_feat_composite(const VdnCompositeArgs* a, void* stream) {
     if (!a || a->B <= 0 || a->N <= 0 || a->T < a->N || a->T > kMaxT) return -1;
     if (!a->feat || !a->feat_out || a->feat_ch <= 0 || !a->weights || !a->inside_sphere) return -2;
     if (a->T > a->N && (!a->bg_density || !a->bg_feat)) return -3;
-    hipLaunchKernelGGL(feat_composite_kernel, dim3(a->B), dim3(256), 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(feat_composite_kernel, dim3(a->B), dim3(256), 0, (hipStream_t)stream, *a, FeatLoss{});
+    return (int)hipGetLastError();
+}
+
+// The training step's forward compositor with the VDN head in the plain one-rank configuration (no mask): the per-ray kernel and the
+// feature channels' weighted sums, which also make d loss / d render_feats on the spot. No eikonal reduce: the adjoint
+// (vdn_composite_bwd_train) takes the denominator from the foreground work list, the scalars are reduced off the critical path.
+extern "C" int vdn_composite_fwd_train(const VdnCompositeArgs* a, const float* gt_feats, float* g_feats, float depth_weight, float grad_scale,
+                                       void* stream) {
+    if (!a || a->B <= 0 || a->N <= 0 || a->T < a->N || a->T > kMaxT || !gt_feats || !g_feats) return -1;
+    if (!a->rays_o || !a->rays_d || !a->sdf || !a->normals || !a->dists || !a->mid_z || !a->color || !a->variance) return -2;
+    if (!a->weights || !a->cdf || !a->inside_sphere || !a->color_out || !a->weight_sum || !a->weight_max || !a->eik_partial) return -3;
+    if (a->T > a->N && (!a->bg_density || !a->bg_rgb || !a->bg_dists)) return -4;
+    if (!a->feat_out || !a->feat || a->feat_ch <= 0 || (a->T > a->N && !a->bg_feat)) return -5;
+    VdnCompositeArgs per_ray = *a;
+    per_ray.feat_out = nullptr;
+    hipLaunchKernelGGL(composite_kernel, dim3((a->B + kRayWaves - 1) / kRayWaves), dim3(kRayWaves * 64), 0, (hipStream_t)stream, per_ray);
+    hipLaunchKernelGGL(feat_composite_kernel, dim3(a->B), dim3(256), 0, (hipStream_t)stream, *a, FeatLoss{gt_feats, g_feats, depth_weight, grad_scale});
     return (int)hipGetLastError();
 }
 
@@ -513,7 +553,7 @@ extern "C" int vdn_alpha_composite_fwd(const VdnCompositeArgs* a, void* stream) 
     per_ray.feat_out = nullptr;                   // the feature channels have their own launch (feat_composite_kernel)
     hipLaunchKernelGGL(composite_kernel, dim3((a->B + kRayWaves - 1) / kRayWaves), dim3(kRayWaves * 64), 0, (hipStream_t)stream, per_ray);
     if (a->feat_out != nullptr)
-        hipLaunchKernelGGL(feat_composite_kernel, dim3(a->B), dim3(256), 0, (hipStream_t)stream, *a);
+        hipLaunchKernelGGL(feat_composite_kernel, dim3(a->B), dim3(256), 0, (hipStream_t)stream, *a, FeatLoss{});
     hipLaunchKernelGGL(eikonal_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a->eik_partial, a->B, a->eik_out);
     return (int)hipGetLastError();
 }

@@ -393,6 +393,31 @@ __global__ __launch_bounds__(kRW * 64) void composite_train_kernel(CompositeArgs
     warm_l2_end(wcode);
 }
 
+// composite_bwd_kernel with the upstream gradients made on the spot, as in composite_train_kernel: the colour term's from the colour
+// the forward left in memory (loss_kernel's expressions, mask = 1), the eikonal denominator from the foreground work list's length.
+// The feature channels' gradient a.g_feat was written by the forward (vdn_composite_fwd_train).
+__global__ __launch_bounds__(kRW * 64) void composite_bwd_train_kernel(CompositeBwdArgs a, const float* color_out, const float* true_rgb,
+                                                                       float* g_color, const int32_t* fg_count, float igr_weight, float grad_scale) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * kRW + wave;
+    if (r >= a.B) return;
+    CompositeBwdOvr ov;
+    ov.on = true;
+    const float mask_sum = (float)a.B + 1e-5f;                        // dpt_runner.py:213 with mask = ones
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float m = 1.0f;
+        const float diff = color_out[r * 3 + k] - true_rgb[r * 3 + k];
+        const float e = diff * m;
+        const float sgn = e > 0.0f ? 1.0f : (e < 0.0f ? -1.0f : 0.0f);
+        ov.gc[k] = sgn * m / mask_sum * grad_scale;
+        if (lane == 0) g_color[r * 3 + k] = ov.gc[k];
+    }
+    ov.g_eik = igr_weight;
+    ov.eik_den = (float)(*fg_count) + 1e-5f;
+    composite_bwd_row(a, r, wave, lane, ov);
+}
+
 // Adjoint of the ray geometry (include/vdn_render.h: VdnRayAdjointArgs), one wave per ray, sample i = kE * lane + e.
 //   d o = sum_i d pts_i;  d d = sum_i (d pts_i mid_i + d dirs_i) + d dir_cos;  d mid_i = d pts_i . d
 //   mid_i = (z_i + z_{i+1}) / 2 and dists_i = z_{i+1} - z_i for i < n-1;  mid_{n-1} = z_{n-1} + sample_dist / 2, dists_{n-1} const
@@ -495,6 +520,28 @@ extern "C" int vdn_composite_train(const VdnCompositeArgs* f, const VdnComposite
                        g_color, fg_count, igr_weight, grad_scale);
     if (b->d_variance != nullptr)
         hipLaunchKernelGGL(variance_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, b->d_var_partial, b->B, b->d_variance);
+    return (int)hipGetLastError();
+}
+
+extern "C" int vdn_composite_bwd_train(const VdnCompositeBwdArgs* a, const float* color_out, const float* true_rgb, float* g_color,
+                                       const int32_t* fg_count, float igr_weight, float grad_scale, void* stream) {
+    using namespace vdn;
+    if (!a || !color_out || !true_rgb || !g_color || !fg_count || a->B <= 0 || a->N <= 0 || a->T < a->N || a->T > kMaxTB) return -1;
+    if (!a->rays_o || !a->rays_d || !a->sdf || !a->normals || !a->dists || !a->mid_z || !a->color || !a->variance ||
+        !a->alpha || !a->weights) return -2;
+    if (!a->d_sdf || !a->d_normals || !a->d_color || !a->d_var_partial) return -3;
+    if (a->T > a->N && (!a->bg_density || !a->bg_rgb || !a->bg_dists || !a->d_bg_density || !a->d_bg_rgb)) return -4;
+    if (a->d_feat && (!a->feat || a->feat_ch <= 0 || a->feat_ch > 128)) return -5;
+    // the Trainer's configuration only: no extra upstream gradients, no ray adjoints
+    if (a->g_weights || a->g_cdf || a->d_dists || a->d_dir_cos) return -10;
+    const bool ext_feat = a->d_feat && a->g_feat && a->feat_scratch;
+    const int row_blocks = (int)(((long)a->B * a->T + 3) / 4);
+    if (ext_feat) hipLaunchKernelGGL(feat_dot_kernel, dim3(row_blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(composite_bwd_train_kernel, dim3((a->B + kRW - 1) / kRW), dim3(kRW * 64), 0, (hipStream_t)stream, *a, color_out, true_rgb,
+                       g_color, fg_count, igr_weight, grad_scale);
+    if (ext_feat) hipLaunchKernelGGL(feat_outer_kernel, dim3(row_blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    if (a->d_variance != nullptr)
+        hipLaunchKernelGGL(variance_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a->d_var_partial, a->B, a->d_variance);
     return (int)hipGetLastError();
 }
 

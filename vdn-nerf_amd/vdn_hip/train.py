@@ -516,7 +516,9 @@ class TrainEngine:
         `gradients` for every sample).
         fuse_loss (the Trainer's plain configuration): dict(true_rgb, g_color, igr_weight, grad_scale) - the compositor, the
         colour term's gradient and the compositor's adjoint run as ONE launch (vdn_composite_train); backward() then starts at
-        the heads. Needs skip_far (the eikonal denominator is the foreground list's length)."""
+        the heads. With the VDN head and the dict's gt_feats / g_feats / depth_weight: vdn_composite_fwd_train here and
+        vdn_composite_bwd_train in backward() (the loss gradients are made inside them). Needs skip_far (the eikonal denominator
+        is the foreground list's length)."""
         r, w, B, N, T = self.r, self.w, self.B, self.N, self.T
         st = _stream()
         if ray_grads and skip_far:
@@ -644,7 +646,14 @@ class TrainEngine:
         self._join()
         self._ctx = (rays_o, rays_d, background_rgb, cos_anneal_ratio, z)
         self._composite_bwd_done = False
-        if fuse_loss is not None and self._fg_compact and not self.wdepth and not ray_grads:
+        self._bwd_train = None
+        if fuse_loss is not None and self._fg_compact and self.wdepth and fuse_loss.get("gt_feats") is not None and not ray_grads:
+            # with the VDN head: the per-ray kernel and the features' weighted sums, which write d loss / d render_feats on the spot;
+            # backward() then makes the colour term's gradient inside the compositor's adjoint (vdn_composite_bwd_train)
+            lib.call("vdn_composite_fwd_train", c, lib.ptr(fuse_loss["gt_feats"]), lib.ptr(fuse_loss["g_feats"]),
+                     float(fuse_loss["depth_weight"]), float(fuse_loss["grad_scale"]), st)
+            self._bwd_train = fuse_loss
+        elif fuse_loss is not None and self._fg_compact and not self.wdepth and not ray_grads:
             cb = self._composite_bwd_args(None, None, None, None, None)
             self._fused_keep = (c, cb, fuse_loss)
             lib.call("vdn_composite_train", c, cb, lib.ptr(fuse_loss["true_rgb"]), lib.ptr(fuse_loss["g_color"]), lib.ptr(w["fg_active"][1]),
@@ -882,6 +891,11 @@ class TrainEngine:
         rg = getattr(self, "_ray_grads", False)
         if getattr(self, "_composite_bwd_done", False):
             self._composite_bwd_done = False          # (forward(fuse_loss=...) ran the compositor's adjoint already)
+        elif getattr(self, "_bwd_train", None) is not None:
+            fl, self._bwd_train = self._bwd_train, None
+            c = self._composite_bwd_args(None, g_feat, None, None, None)
+            lib.call("vdn_composite_bwd_train", c, lib.ptr(w["color"]), lib.ptr(fl["true_rgb"]), lib.ptr(fl["g_color"]), lib.ptr(w["fg_active"][1]),
+                     float(fl["igr_weight"]), float(fl["grad_scale"]), st)
         else:
             c = self._composite_bwd_args(g_color, g_feat, g_weights, g_eik, g_cdf)
             lib.call("vdn_alpha_composite_bwd", c, st)

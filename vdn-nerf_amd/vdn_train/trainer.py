@@ -205,9 +205,19 @@ class Trainer:
         fuse = (not self.coll.enabled and mask is None and self.conf["mask_weight"] == 0.0 and not eng.wdepth
                 and os.environ.get("VDN_FUSED_COMPOSITE", "1") != "0")
         fl = dict(true_rgb=true_rgb, g_color=self.g_color, igr_weight=self.conf["igr_weight"], grad_scale=1.0 / self.world) if fuse else None
+        # ... and with the VDN head in the loss (womsk_white_wdepth): the 96 feature channels keep their streaming launches, but the
+        # loss gradients are made inside the compositor's launches (vdn_composite_fwd_train / vdn_composite_bwd_train) and the
+        # eikonal reduce + loss kernel leave the critical path the same way
+        depth_w = self.depth_iter_weight() if depth_on else 0.0
+        fuse_wd = (not self.coll.enabled and mask is None and self.conf["mask_weight"] == 0.0 and eng.wdepth and depth_on
+                   and os.environ.get("VDN_FUSED_COMPOSITE", "1") != "0")
+        if fuse_wd:
+            fl = dict(true_rgb=true_rgb, g_color=self.g_color, igr_weight=self.conf["igr_weight"], grad_scale=1.0 / self.world,
+                      gt_feats=gt_feats, g_feats=self.g_feats, depth_weight=depth_w)
         w = eng.forward(rays_o, rays_d, z.contiguous(), z_out, self.bg, self.cos_anneal_ratio(), skip_far=True,
                         pending_merge=r._pending_merge, after_sdf=after_sdf, fuse_loss=fl)
-        fused = bool(getattr(eng, "_composite_bwd_done", False))
+        fused_wd = getattr(eng, "_bwd_train", None) is not None
+        fused = bool(getattr(eng, "_composite_bwd_done", False)) or fused_wd
         if self.coll.enabled:
             # the eikonal term is a ratio of sums over the GLOBAL batch (renderer.py:313-315): its two sums were
             # on their way since the SDF kernel finished; the loss kernel and the compositor's adjoint read w["eik"]
@@ -226,7 +236,7 @@ class Trainer:
             a.g_weights = self.g_weights.data_ptr()
         if depth_on:
             a.feats, a.gt_feats, a.g_feats = w["feat_out"].data_ptr(), gt_feats.data_ptr(), self.g_feats.data_ptr()
-            a.depth_weight = self.depth_iter_weight()
+            a.depth_weight = depth_w
             self.depth_iter += 1
         if fused:
             if self._log_stream is None:
@@ -234,6 +244,12 @@ class Trainer:
             ls = self._log_stream
             self._ev_comp.record(torch.cuda.current_stream())
             ls.wait_event(self._ev_comp)
+            if fused_wd:
+                # (the kernel rewrites the gradients with the values the compositor's launches made: into copies, since the
+                # adjoint's feature launches read g_feats on the main stream meanwhile)
+                if self.__dict__.get("_g_log") is None:
+                    self._g_log = (torch.empty_like(self.g_color), torch.empty_like(self.g_feats))
+                a.g_color, a.g_feats = self._g_log[0].data_ptr(), self._g_log[1].data_ptr()
             lib.call("vdn_eikonal_reduce", lib.ptr(w["eik_partial"]), B, lib.ptr(w["eik"]), ls.cuda_stream)
             lib.call("vdn_loss_fwd_bwd", a, ls.cuda_stream)      # the scalars (it rewrites g_color / g_eik with the values already used)
             self._ev_log.record(ls)
@@ -281,12 +297,12 @@ class Trainer:
         grad = eng._grad_flat
         split = self.overlap and os.environ.get("VDN_SPLIT_REST", "1") != "0" and "nerf" in eng.dw_groups and "heads" in eng.dw_groups
         # (events on the critical chain are marker packets, 3 - 4 us each: the side stream's fork reuses _ev_comp - nothing was
-        # launched on this stream since - the SDF GEMM's event is only recorded for the schedule that waits for it, and the heads'
+        # launched on this stream since; not with the VDN head, where the compositor's adjoint is still to come in backward() - the SDF GEMM's event is only recorded for the schedule that waits for it, and the heads'
         # event is covered by the `after` events below, which are recorded later on this stream)
         trim = os.environ.get("VDN_EVENT_TRIM", "1") != "0"           # (0: the A/B arm that records them all)
         eng.backward(self.g_color, g_feats, g_weights, self.g_eik, defer_rest=True,
                      gemm_event=self._ev_gemm if (self.overlap and not (split and trim)) else None,
-                     fork_event=self._ev_comp if (fused and trim) else None, heads_event=not trim)
+                     fork_event=self._ev_comp if (fused and not fused_wd and trim) else None, heads_event=not trim)
         side = None
         if split:
             # the background network's half right behind its backward, beside the SDF backward on the main stream ...
