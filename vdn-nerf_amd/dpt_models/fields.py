@@ -67,11 +67,12 @@ class _HipNet(nn.Module):
     def _store_dtype(self):
         return torch.float32 if self.precision == "fp32" else torch.bfloat16
 
-    def _images(self):
+    def _images(self, join=True):
         # A vdn_train.Trainer updates this network's parameters and weight images on its side stream (raw pointers: torch's
         # version counters do not move). It leaves a hook here that orders torch's current stream behind that update, so
-        # render() / validate_image right after train_step never read half-rebuilt images. (An event wait; free once done.)
-        hook = self.__dict__.get("_stream_join")
+        # render() / validate_image right after train_step never read half-rebuilt images. (An event wait; free once done.
+        # join=False: the Trainer's own forward, which places that wait itself - right in front of the first launch that needs it.)
+        hook = self.__dict__.get("_stream_join") if join else None
         if hook is not None:
             hook()
         dev = next(self.parameters()).device

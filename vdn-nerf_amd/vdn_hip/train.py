@@ -508,7 +508,7 @@ class TrainEngine:
         return w
 
     def forward(self, rays_o, rays_d, z, z_out, background_rgb, cos_anneal_ratio, skip_far=False, ray_grads=False, pending_merge=None,
-                after_sdf=None, fuse_loss=None):
+                after_sdf=None, fuse_loss=None, before_heads=None):
         """Differentiable part of render() at detached z [B,N] (+ z_out [B,O]); returns the output tensors.
         skip_far (the Trainer's hot loop): inside samples beyond the relaxed sphere (|p| >= 1.2: inside_sphere = 0 and
         relax_inside_sphere = 0, renderer.py:284-286) enter the loss only through exact zeros, so the SDF / colour / VDN
@@ -527,8 +527,11 @@ class TrainEngine:
         self._fwd_rays = (rays_o, rays_d)
         if ray_grads:
             self._ray_workspaces()
+        # before_heads (the Trainer): called right in front of the colour / VDN heads' launches - the first ones on this stream that
+        # read what its side stream updates (the wait for that update then sits behind the SDF kernel instead of in front of the
+        # step preparation, where the update has only just finished; the background network runs on the side stream itself)
         for net in self.nets.values():
-            net.img = net.module._images()           # refresh weight images if parameters changed
+            net.img = net.module._images(join=before_heads is None)           # refresh weight images if parameters changed
         if self._ptr_key() != self._param_ptrs:
             raise RuntimeError("parameters were re-allocated after the training engine was built; rebuild it")
         sample_dist = 2.0 / r.n_samples
@@ -624,6 +627,8 @@ class TrainEngine:
             if net == "color" and self.dbc:          # renderer.py:247-248
                 c.extra, c.save_extra = w["vdn_out"].data_ptr(), w["col_extra"].data_ptr()
             lib.call("vdn_rendernet_fwd" + self.sfx, self._fg(c), st if stream is None else stream)
+        if before_heads is not None:
+            before_heads()
         vdn_beside = self.wdepth and self._side2 is not None and not self.dbc     # (depth_before_color: the colour head reads the VDN output)
         if self.wdepth:
             if vdn_beside:

@@ -194,7 +194,11 @@ class Trainer:
             # (the sampler only reads the SDF weight images: it runs beside the previous step's side-stream half)
             z, z_out = r._sample(rays_o, rays_d, near.reshape(B), far.reshape(B), r.perturb, t_rand, t_rand_out, z_vals_inject,
                                  defer_last_merge=True)
-        self.join()
+        # (the side-stream half of the last step is joined in front of the heads' launches: eng.forward(before_heads=...). Without
+        # a side stream for the background network it runs on this stream and needs the join here. VDN_JOIN_EARLY=1: the A/B arm)
+        late_join = eng._side is not None and os.environ.get("VDN_JOIN_EARLY", "0") != "1"
+        if not late_join:
+            self.join()
         after_sdf = self._eikonal_begin if self.coll.enabled else None
         depth_on = self.conf["extract_depth"] and self.iter_step > self.conf["depth_start_iter"] and gt_feats is not None
         # Plain configuration (one rank, no mask, no mask loss, no VDN head): compositor, colour-term gradient and the compositor's
@@ -215,7 +219,7 @@ class Trainer:
             fl = dict(true_rgb=true_rgb, g_color=self.g_color, igr_weight=self.conf["igr_weight"], grad_scale=1.0 / self.world,
                       gt_feats=gt_feats, g_feats=self.g_feats, depth_weight=depth_w)
         w = eng.forward(rays_o, rays_d, z.contiguous(), z_out, self.bg, self.cos_anneal_ratio(), skip_far=True,
-                        pending_merge=r._pending_merge, after_sdf=after_sdf, fuse_loss=fl)
+                        pending_merge=r._pending_merge, after_sdf=after_sdf, fuse_loss=fl, before_heads=self.join if late_join else None)
         fused_wd = getattr(eng, "_bwd_train", None) is not None
         fused = bool(getattr(eng, "_composite_bwd_done", False)) or fused_wd
         if self.coll.enabled:
