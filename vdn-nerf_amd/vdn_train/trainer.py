@@ -16,6 +16,7 @@ The heads' HBM-bound GEMM and the collectives run beside the latency-bound sampl
 have no GEMM beside them. Results are identical to the in-order
 schedule (overlap=False) bit for bit: the same launches on the same data, only on two streams.
 """
+import ctypes
 import math
 import os
 
@@ -226,9 +227,10 @@ class Trainer:
             # the eikonal term is a ratio of sums over the GLOBAL batch (renderer.py:313-315): its two sums were
             # on their way since the SDF kernel finished; the loss kernel and the compositor's adjoint read w["eik"]
             self.coll.finish(self._eik_handles, tag="eikonal")
+            # (ratio, num, den) from the reduced pair in one launch: vdn_eikonal_reduce over ONE "ray" whose partial sums are the
+            # global ones - the same f32 expression as three tiny torch launches on the critical path
             eg = self._eik_global
-            eg[0:1] = eg[1:2] / (eg[2:3] + 1e-5)
-            w["eik"].copy_(eg)
+            lib.call("vdn_eikonal_reduce", ctypes.c_void_p(eg.data_ptr() + 4), 1, lib.ptr(w["eik"]), st)
         a = lib.VdnLossArgs()
         a.color, a.true_rgb, a.weights, a.eik = w["color"].data_ptr(), true_rgb.data_ptr(), w["weights"].data_ptr(), w["eik"].data_ptr()
         a.mask = mask.data_ptr() if mask is not None else None
