@@ -273,10 +273,13 @@ class Leg:
             regions.append(self.region(warmup + len(regions) * steps, steps))
         med = float(np.median(regions))
         eng = self.trainer.engine
-        # mean work-list rows of the steady state: `steps` more (untimed) steps with the device-side row counters copied out per
-        # step (the kernel statistics under profiles/ quote them: roofline fractions are recomputed from rows / AverageUs)
+        # mean work-list rows of the steady state: one more (untimed) pass over ALL resident batches - the lists differ by +-10 %
+        # between images, and every mean that is compared with another (the kernel statistics under profiles/ quote this one:
+        # roofline fractions are recomputed from rows / AverageUs) has to cover whole cycles of them - with the device-side row
+        # counters copied out per step
         counts = []
-        for i in range(steps):
+        n_cycle = len(self.batches)
+        for i in range(n_cycle):
             self.step(warmup + len(regions) * steps + i)
             counts.append((eng.w["fg_active"][1].clone(), eng.w["bg_active"][1].clone() if "bg_active" in eng.w else None))
         self.fence()
@@ -289,7 +292,7 @@ class Leg:
         return {"value": rays / med, "ms_per_step": med / steps * 1e3,
                 "trials": {"regions": len(regions), "steps_per_region": steps, "timed_seconds": float(sum(regions)),
                            "ms_per_step_min": min(regions) / steps * 1e3, "ms_per_step_max": max(regions) / steps * 1e3},
-                "work_list_rows_mean": {"foreground": rows_fg, "background": rows_bg, "over_steps": steps},
+                "work_list_rows_mean": {"foreground": rows_fg, "background": rows_bg, "over_steps": n_cycle},
                 "foreground_points_evaluated_last_step": fg, "foreground_points_total": eng.P,
                 "background_points_evaluated_last_step": bg, "background_points_total": eng.Q,
                 "executed_flop_per_ray": fpr, "executed_model_flops_per_s": rays / med * fpr,
@@ -307,6 +310,7 @@ class Leg:
         collectives); only rank 0 reports."""
         eng, rend = self.trainer.engine, self.rend
         dtype = "f32" if self.precision == "fp32" else "bf16"
+        in_situ_steps = max(1, int(round(in_situ_steps / float(len(self.batches))))) * len(self.batches)     # whole cycles of the batches
         situ_two = self.sdf_in_situ(in_situ_steps)
         situ = situ_two
         if one_stream is not None:
