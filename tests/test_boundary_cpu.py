@@ -33,6 +33,17 @@ def test_argument_errors_are_reported_not_ignored():
         lib.call("vdn_sdf_mlp_fwd_f32", 0, a, None)       # P == 0 / null blob -> status < 0, never reaches the GPU
     with pytest.raises(lib.VdnError):
         lib.call("vdn_merge_sorted", lib.VdnMergeArgs(), None)
+    # this round's entry points: empty argument blocks / null pointers are refused before anything is launched
+    c, b, s = lib.VdnCompositeArgs(), lib.VdnCompositeBwdArgs(), lib.VdnSdfArgs()
+    for name, args in (("vdn_shade_fused_bf16", (s, None, 1, c, None, None)),
+                       ("vdn_sdf_fwd_tail_bf16", (s, None)),
+                       ("vdn_feat_composite", (c, None)),
+                       ("vdn_composite_train", (c, b, None, None, None, 0.1, 1.0, None)),
+                       ("vdn_composite_fwd_train", (c, None, None, 1.0, 1.0, None)),
+                       ("vdn_composite_bwd_train", (b, None, None, None, None, 0.1, 1.0, None)),
+                       ("vdn_eikonal_reduce", (None, 0, None, None))):
+        with pytest.raises(lib.VdnError):
+            lib.call(name, *args)
 
 
 def test_state_dict_schema_and_param_counts():
