@@ -567,6 +567,8 @@ class TrainEngine:
                 tp.fg_active_idx, tp.fg_n_active, tp.fg_ray_counts = (t.data_ptr() for t in w["fg_active"])
             tp.bg_active_idx, tp.bg_n_active, tp.bg_ray_counts = (t.data_ptr() for t in w["bg_active"])
             lib.call("vdn_train_prep", tp, st)
+            if fuse_loss is not None and fuse_loss.get("after_prep") is not None:
+                fuse_loss["after_prep"](self)            # (the data-parallel Trainer: the list's length starts its all-reduce here)
         else:
             a = lib.VdnSectionArgs()
             a.z, a.dists, a.mid_z, a.sample_dist, a.B, a.n, a.ld = z.data_ptr(), w["dists"].data_ptr(), w["mid_z"].data_ptr(), sample_dist, B, N, z.stride(0)
@@ -652,6 +654,11 @@ class TrainEngine:
         self._ctx = (rays_o, rays_d, background_rgb, cos_anneal_ratio, z)
         self._composite_bwd_done = False
         self._bwd_train = None
+        if fuse_loss is not None and fuse_loss.get("before_composite") is not None:
+            if not (fused_prep and self._fg_compact):
+                raise RuntimeError("fuse_loss with a global foreground count needs the fused step preparation and the work lists")
+            fuse_loss["before_composite"]()              # (... and has arrived: vdn_composite_train / _bwd_train read the global count)
+        fg_count = lib.ptr(fuse_loss["fg_count"] if (fuse_loss is not None and fuse_loss.get("fg_count") is not None) else w["fg_active"][1])
         if fuse_loss is not None and self._fg_compact and self.wdepth and fuse_loss.get("gt_feats") is not None and not ray_grads:
             # with the VDN head: the per-ray kernel and the features' weighted sums, which write d loss / d render_feats on the spot;
             # backward() then makes the colour term's gradient inside the compositor's adjoint (vdn_composite_bwd_train)
@@ -661,7 +668,7 @@ class TrainEngine:
         elif fuse_loss is not None and self._fg_compact and not self.wdepth and not ray_grads:
             cb = self._composite_bwd_args(None, None, None, None, None)
             self._fused_keep = (c, cb, fuse_loss)
-            lib.call("vdn_composite_train", c, cb, lib.ptr(fuse_loss["true_rgb"]), lib.ptr(fuse_loss["g_color"]), lib.ptr(w["fg_active"][1]),
+            lib.call("vdn_composite_train", c, cb, lib.ptr(fuse_loss["true_rgb"]), lib.ptr(fuse_loss["g_color"]), fg_count,
                      float(fuse_loss["igr_weight"]), float(fuse_loss["grad_scale"]), st)
             self._composite_bwd_done = True
         else:
@@ -899,7 +906,8 @@ class TrainEngine:
         elif getattr(self, "_bwd_train", None) is not None:
             fl, self._bwd_train = self._bwd_train, None
             c = self._composite_bwd_args(None, g_feat, None, None, None)
-            lib.call("vdn_composite_bwd_train", c, lib.ptr(w["color"]), lib.ptr(fl["true_rgb"]), lib.ptr(fl["g_color"]), lib.ptr(w["fg_active"][1]),
+            lib.call("vdn_composite_bwd_train", c, lib.ptr(w["color"]), lib.ptr(fl["true_rgb"]), lib.ptr(fl["g_color"]),
+                     lib.ptr(fl["fg_count"] if fl.get("fg_count") is not None else w["fg_active"][1]),
                      float(fl["igr_weight"]), float(fl["grad_scale"]), st)
         else:
             c = self._composite_bwd_args(g_color, g_feat, g_weights, g_eik, g_cdf)

@@ -200,30 +200,42 @@ class Trainer:
         late_join = eng._side is not None and os.environ.get("VDN_JOIN_EARLY", "0") != "1"
         if not late_join:
             self.join()
-        after_sdf = self._eikonal_begin if self.coll.enabled else None
         depth_on = self.conf["extract_depth"] and self.iter_step > self.conf["depth_start_iter"] and gt_feats is not None
         # Plain configuration (one rank, no mask, no mask loss, no VDN head): compositor, colour-term gradient and the compositor's
         # adjoint are ONE launch (vdn_composite_train) - nothing global sits between them but the eikonal denominator, which is
         # the foreground list's length - and the loss SCALARS (logging only) are reduced on a stream of their own, off the
         # critical path: 4 launches of 5 - 15 us each (compositor, eikonal reduce, loss, adjoint) become one. Same device
         # functions, same expressions: gradients bit-identical (tests/test_gpu_train_parity.py). VDN_FUSED_COMPOSITE=0: off.
-        fuse = (not self.coll.enabled and mask is None and self.conf["mask_weight"] == 0.0 and not eng.wdepth
-                and os.environ.get("VDN_FUSED_COMPOSITE", "1") != "0")
+        # With more than one rank the denominator is the sum of the ranks' list lengths: an all-reduce of ONE int32, started right behind
+        # the step preparation and long done when the compositor needs it; the global numerator is only needed for the scalars, on the
+        # logging stream. (VDN_DP_FUSED=0: compositor, early eikonal all-reduce, loss kernel and adjoint as separate launches.)
+        dp = self.coll.enabled
+        fusable = (mask is None and self.conf["mask_weight"] == 0.0 and os.environ.get("VDN_FUSED_COMPOSITE", "1") != "0"
+                   and (not dp or (os.environ.get("VDN_DP_FUSED", "1") != "0" and r.n_outside > 0
+                                   and os.environ.get("VDN_FG_COMPACT", "1") != "0")))
+        fuse = fusable and not eng.wdepth
         fl = dict(true_rgb=true_rgb, g_color=self.g_color, igr_weight=self.conf["igr_weight"], grad_scale=1.0 / self.world) if fuse else None
         # ... and with the VDN head in the loss (womsk_white_wdepth): the 96 feature channels keep their streaming launches, but the
         # loss gradients are made inside the compositor's launches (vdn_composite_fwd_train / vdn_composite_bwd_train) and the
         # eikonal reduce + loss kernel leave the critical path the same way
         depth_w = self.depth_iter_weight() if depth_on else 0.0
-        fuse_wd = (not self.coll.enabled and mask is None and self.conf["mask_weight"] == 0.0 and eng.wdepth and depth_on
-                   and os.environ.get("VDN_FUSED_COMPOSITE", "1") != "0")
+        fuse_wd = fusable and eng.wdepth and depth_on
         if fuse_wd:
             fl = dict(true_rgb=true_rgb, g_color=self.g_color, igr_weight=self.conf["igr_weight"], grad_scale=1.0 / self.world,
                       gt_feats=gt_feats, g_feats=self.g_feats, depth_weight=depth_w)
+        if dp and fl is not None:
+            if self.__dict__.get("_fg_cnt_g") is None:
+                self._fg_cnt_g = torch.zeros(1, dtype=torch.int32, device=self.dev)
+            fl.update(fg_count=self._fg_cnt_g, after_prep=self._count_begin,
+                      before_composite=lambda: self.coll.finish(self._cnt_handles, tag="fg_count"))
+        after_sdf = self._eikonal_begin if (dp and fl is None) else None
         w = eng.forward(rays_o, rays_d, z.contiguous(), z_out, self.bg, self.cos_anneal_ratio(), skip_far=True,
                         pending_merge=r._pending_merge, after_sdf=after_sdf, fuse_loss=fl, before_heads=self.join if late_join else None)
         fused_wd = getattr(eng, "_bwd_train", None) is not None
         fused = bool(getattr(eng, "_composite_bwd_done", False)) or fused_wd
-        if self.coll.enabled:
+        if dp and fl is not None and not fused:
+            raise RuntimeError("the engine did not take the fused compositor path the data-parallel step was set up for")
+        if dp and not fused:
             # the eikonal term is a ratio of sums over the GLOBAL batch (renderer.py:313-315): its two sums were
             # on their way since the SDF kernel finished; the loss kernel and the compositor's adjoint read w["eik"]
             self.coll.finish(self._eik_handles, tag="eikonal")
@@ -257,6 +269,12 @@ class Trainer:
                     self._g_log = (torch.empty_like(self.g_color), torch.empty_like(self.g_feats))
                 a.g_color, a.g_feats = self._g_log[0].data_ptr(), self._g_log[1].data_ptr()
             lib.call("vdn_eikonal_reduce", lib.ptr(w["eik_partial"]), B, lib.ptr(w["eik"]), ls.cuda_stream)
+            if dp:
+                # the reported eikonal term is the GLOBAL ratio: this rank's (num, den) summed over the ranks in place, then the
+                # ratio of the pair by the same kernel over one "ray" (it reads the two sums before it writes the triple)
+                with torch.cuda.stream(ls):
+                    self.coll.finish(self.coll.begin([w["eik"][1:3]], side=True), tag="eikonal")
+                lib.call("vdn_eikonal_reduce", ctypes.c_void_p(w["eik"].data_ptr() + 4), 1, lib.ptr(w["eik"]), ls.cuda_stream)
             lib.call("vdn_loss_fwd_bwd", a, ls.cuda_stream)      # the scalars (it rewrites g_color / g_eik with the values already used)
             self._ev_log.record(ls)
         else:
@@ -372,6 +390,12 @@ class Trainer:
             if self._joined.get(cur.cuda_stream) != self._rest_gen or os.environ.get("VDN_EVENT_TRIM", "1") == "0":
                 cur.wait_event(self._ev_rest)
                 self._joined[cur.cuda_stream] = self._rest_gen
+
+    def _count_begin(self, eng):
+        """Right behind the step preparation: the length of this rank's foreground work list - the eikonal term's denominator
+        (the compositor's own norm test made the list) - on its way to the sum over the ranks, under the SDF kernel."""
+        self._fg_cnt_g.copy_(eng.w["fg_active"][1])
+        self._cnt_handles = self.coll.begin([self._fg_cnt_g])
 
     def _eikonal_begin(self, eng):
         """Right behind the fused SDF kernel: this rank's eikonal sums (vdn_eikonal_terms: the compositor's own expressions) and
