@@ -27,5 +27,10 @@ for r in range(6):
     for i in range(60):
         tr.train_step(*batches[i % 23])
     torch.cuda.synchronize(); res.append((time.time() - t0) / 60 * 1e6)
+tr.coll.timing = True
+for i in range(40):
+    tr.train_step(*batches[i % 23])
+torch.cuda.synchronize()
+print({k: round(v["mean_ms"] * 1e3, 1) for k, v in tr.coll.exposed_ms().items()}, "us exposed per call")
 print("%-12s one-rank DP step %.1f us (min %.1f)" % (sys.argv[1] if len(sys.argv) > 1 else "dp", float(np.median(res)), min(res)))
 dist.destroy_process_group()
