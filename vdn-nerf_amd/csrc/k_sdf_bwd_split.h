@@ -60,8 +60,13 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 VDN_DEV rsrc_t make_rsrc(const void* base, long bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)(bytes > 0xffffffffL ? 0xffffffffL : bytes), 0x00020000);
 }
-VDN_DEV u32x4 bload(rsrc_t r, unsigned voff, unsigned soff) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0); }
-VDN_DEV void bstore(rsrc_t r, unsigned voff, unsigned soff, const u32x4& v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, 0); }
+#ifndef VDN_BS_LD_AUX
+#define VDN_BS_LD_AUX 0         // cache-policy bits of the plane loads (bit 1 = non-temporal; the stores': VDN_BS_ST_AUX, vdn_common.h).
+#endif                          // 2 costs the step 140 us: the kernel reads every H plane twice
+// (VDN_BS_LDV_AUX, vdn_common.h: ... of the V planes' loads (read once) and of the H planes' SECOND reading (fbar))
+VDN_DEV u32x4 bload(rsrc_t r, unsigned voff, unsigned soff) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, VDN_BS_LD_AUX); }
+VDN_DEV u32x4 bload_once(rsrc_t r, unsigned voff, unsigned soff) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, VDN_BS_LDV_AUX); }
+VDN_DEV void bstore(rsrc_t r, unsigned voff, unsigned soff, const u32x4& v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, VDN_BS_ST_AUX); }
 
 template <int I>
 VDN_DEV void load_weights(WSet& W, rsrc_t blob_r, rsrc_t blob_f, int wave, unsigned lane16) {
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(kWaves * 64, 1) void sdf_bwd_split_kernel(SdfRbarAr
     struct Raw { u32x4 k[2]; };
     Raw rs, rv;                                     // plane tiles of the current step's epilogue (loaded one step ahead)
     rs.k[0] = bload(RS, v256, tile_off); rs.k[1] = bload(RS, v256, tile_off + 1024);
-    rv.k[0] = bload(RV, v256, tile_off); rv.k[1] = bload(RV, v256, tile_off + 1024);
+    rv.k[0] = bload_once(RV, v256, tile_off); rv.k[1] = bload_once(RV, v256, tile_off + 1024);
 
     static_for<16>([&](auto i_c) VDN_INL {
         constexpr int I = decltype(i_c)::value;
@@ -260,8 +265,9 @@ __global__ __launch_bounds__(kWaves * 64, 1) void sdf_bwd_split_kernel(SdfRbarAr
         if constexpr (I + 1 < 16) {
             constexpr StepDesc n = step_desc(I + 1);
             const unsigned so = (unsigned)n.l * PSB + (unsigned)(wave < n.nt ? wave : n.nt - 1) * 2048;
-            ns.k[0] = bload(RS, v256, so); ns.k[1] = bload(RS, v256, so + 1024);
-            if constexpr (!n.fbar) { nv.k[0] = bload(RV, v256, so); nv.k[1] = bload(RV, v256, so + 1024); }
+            if constexpr (n.fbar) { ns.k[0] = bload_once(RS, v256, so); ns.k[1] = bload_once(RS, v256, so + 1024); }
+            else { ns.k[0] = bload(RS, v256, so); ns.k[1] = bload(RS, v256, so + 1024); }
+            if constexpr (!n.fbar) { nv.k[0] = bload_once(RV, v256, so); nv.k[1] = bload_once(RV, v256, so + 1024); }
         }
         __builtin_amdgcn_sched_barrier(0);
         // the epilogue in two halves of 8 values (one 16-byte piece each): half the temporaries of a 16-value pass

@@ -307,7 +307,11 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // (development harness, 65 536 rows, variants interleaved: training launch 205.6 -> 196.8 us, inference launch 161.9 -> 157.1)
 VDN_DEV void plane_store16(unsigned short* p, const u32x4& v) {
 #if VDN_SDF2_WT_SAVES
+#if VDN_SAVE_NT             // non-temporal as well (vdn_common.h)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#else
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#endif
 #else
     *reinterpret_cast<u32x4*>(p) = v;
 #endif

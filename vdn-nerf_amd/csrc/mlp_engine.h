@@ -229,9 +229,8 @@ struct F32 {
     }
 };
 
-#ifndef VDN_WT_PLANES
-#define VDN_WT_PLANES 0       // write-through plane stores in every chain kernel: measured neutral on the step (same-box A/B of two builds), off
-#endif
+// (VDN_PLANE_ST_MODE, vdn_common.h: cache policy of the chain kernels' plane stores - store_tile below. 0 plain; 1 write-through:
+// measured neutral on the step in round 3; 2 non-temporal: neutral; 3 both: the default since round 4)
 struct BF16 {
     // 4 waves per workgroup and two workgroups resident per CU (2 waves / SIMD): the workgroups run their
     // chunk barriers independently, so one computes while the other waits on memory
@@ -382,12 +381,18 @@ struct BF16 {
             o.y = pack_bf16x2(v[8 * k + 2], v[8 * k + 3]);
             o.z = pack_bf16x2(v[8 * k + 4], v[8 * k + 5]);
             o.w = pack_bf16x2(v[8 * k + 6], v[8 * k + 7]);
-#if VDN_WT_PLANES
-            // write-through (sc1): the line is not kept in this XCD's L2 - saved planes and deltas are next read by other
-            // kernels, while the L2 is what feeds every MLP kernel's weight stream
+#if VDN_PLANE_ST_MODE
+            // 1: write-through (sc1: the line is not kept in this XCD's L2 - saved planes and deltas are next read by other kernels,
+            // while the L2 is what feeds every MLP kernel's weight stream); 2: non-temporal; 3: both (vdn_common.h)
             typedef unsigned wt_u32x4 __attribute__((ext_vector_type(4)));
             const wt_u32x4 ov = {o.x, o.y, o.z, o.w};
+#if VDN_PLANE_ST_MODE == 1
             asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p + 512 * k), "v"(ov) : "memory");
+#elif VDN_PLANE_ST_MODE == 2
+            asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p + 512 * k), "v"(ov) : "memory");
+#else
+            asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p + 512 * k), "v"(ov) : "memory");
+#endif
 #else
             *reinterpret_cast<uint4*>(p + 512 * k) = o;
 #endif
@@ -398,8 +403,16 @@ struct BF16 {
     static VDN_DEV raw_tile load_raw(const unsigned short* base, long row, int ld, int tile, int h) {
         const unsigned short* p = base + (row >> 5) * (32L * ld) + tile * 1024 + h * 256 + (row & 31) * 8;
         raw_tile r;
+#ifdef VDN_PLANE_LD_NT          // (development A/B: the chain kernels read a saved plane once)
+        typedef unsigned nt_u32x4 __attribute__((ext_vector_type(4)));
+        const nt_u32x4 a = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4*>(p));
+        const nt_u32x4 b = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4*>(p + 512));
+        r.k[0] = make_uint4(a[0], a[1], a[2], a[3]);
+        r.k[1] = make_uint4(b[0], b[1], b[2], b[3]);
+#else
         r.k[0] = *reinterpret_cast<const uint4*>(p);
         r.k[1] = *reinterpret_cast<const uint4*>(p + 512);
+#endif
         return r;
     }
     static VDN_DEV f32x16 unpack(const raw_tile& t) {

@@ -39,6 +39,35 @@ VDN_DEV void static_for(F&& f) {
 
 VDN_DEV int rho(int t, int h) { return (t & 3) + 8 * (t >> 2) + 4 * h; }
 
+// Cache policy of the big streaming stores. The activation planes a training-step forward saves are read next by another kernel
+// hundreds of microseconds and gigabytes later: stored write-through AND non-temporal they do not push the data the step is about to
+// re-read (weight streams, code, the planes written just before) out of L2 and the 256-MB memory-side cache. The fused SDF
+// forward's saves (k_sdf_fwd2.h: plane_store16): same-box A/B of two builds, 1 219 / 1 210 / 1 216 -> 1 172 / 1 175 / 1 169 us per step.
+#ifndef VDN_SAVE_NT
+#define VDN_SAVE_NT 1
+#endif
+// The same for every chain kernel's plane stores (mlp_engine.h: store_tile - the background network's and the heads' saves, the
+// backward kernels' deltas: 3 = write-through + non-temporal), the one-launch SDF backward's stores (k_sdf_bwd_split.h: bit 1 of the
+// buffer instructions' cache-policy operand = non-temporal) and the weight-gradient GEMM's operand loads, which read every plane
+// exactly once (train_dw_bf16.hip). Same-box A/B of builds, three alternating runs, against the build with only the line above:
+// plane stores 1 171 / 1 179 / 1 216 -> 1 144 / 1 146 / 1 148 us with the SDF backward's, -> 1 124 / 1 124 / 1 129 us with the GEMM's
+// loads as well. What must NOT be non-temporal: the SDF backward's plane LOADS (it reads H twice: + 140 us), anything a kernel re-reads.
+#ifndef VDN_PLANE_ST_MODE
+#define VDN_PLANE_ST_MODE 3
+#endif
+#ifndef VDN_BS_ST_AUX
+#define VDN_BS_ST_AUX 2
+#endif
+#ifndef VDN_DW_LD_NT
+#define VDN_DW_LD_NT 1
+#endif
+// ... and, in the SDF backward, of the loads that ARE the last reading: the V planes (read once) and the H planes' second reading
+// (fbar): 1 119 / 1 119 / 1 122 -> 1 113 / 1 115 / 1 112 us. The chain kernels' plane loads (mlp_engine.h: load_raw,
+// -DVDN_PLANE_LD_NT) as non-temporal: nothing (1 127 / 1 120 / 1 123).
+#ifndef VDN_BS_LDV_AUX
+#define VDN_BS_LDV_AUX 2
+#endif
+
 // L2 warm-up of a kernel's weight stream. Inside a training step every MLP kernel starts on caches full of other kernels'
 // planes: each chunk of its weight stream is then an HBM miss for the first workgroup of each XCD that asks for it, and as the
 // workgroups of a launch walk the stream in lockstep, every one of its ~40-140 chunk steps waits that miss out (measured on the fused
