@@ -42,7 +42,9 @@ VDN_DEV const char* dw_uniform(const char* p) {
 }
 
 VDN_DEV void dw_glds16(const char* base_uniform, unsigned lane_off, unsigned lds_wave_base) {
-#if VDN_DW_LD_NT                // non-temporal: the operand planes are read exactly once (vdn_common.h)
+#if VDN_DW_LD_NT == 2           // (development A/B: system-coherent as well)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 sc1 nt" ::"v"(lane_off), "s"(lds_wave_base), "s"(base_uniform) : "memory", "m0");
+#elif VDN_DW_LD_NT              // non-temporal: the operand planes are read exactly once (vdn_common.h)
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 nt" ::"v"(lane_off), "s"(lds_wave_base), "s"(base_uniform) : "memory", "m0");
 #else
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" ::"v"(lane_off), "s"(lds_wave_base), "s"(base_uniform) : "memory", "m0");
