@@ -148,10 +148,11 @@ def test_chunk_tables_cover_every_chunk_once(precision):
 
 
 def test_code_warm_up_sizes_stay_inside_their_kernels(tmp_path):
-    """csrc/vdn_common.h warm_code_begin: the first workgroups of a training-step kernel read kWarmCode* bytes of their own code from
-    the warm-up site on, so that every XCD's L2 holds it before the other workgroups arrive. A constant larger than the kernel
-    would read past the end of the loaded code object: each constant + 4 KiB (the warm-up site sits within the first KiB's of the
-    kernel) must fit the smallest symbol its `// symbol:` note names, in the library that ships."""
+    """csrc/vdn_common.h warm_code_issue: the first workgroups of a training-step kernel read kWarmCode* bytes of their own code from
+    the warm-up site on (s_getpc), so that every XCD's L2 holds it before the other workgroups arrive. Reads past the kernel's end
+    would leave the loaded code object: for every kernel a `// symbol:` note names, in the library that ships, the disassembly gives
+    the offset of every s_getpc_b64 inside the symbol (the compiler, not the source, decides where the site lands), and
+    offset + constant must stay inside the symbol."""
     import os
     import shutil
     import subprocess
@@ -161,20 +162,37 @@ def test_code_warm_up_sizes_stay_inside_their_kernels(tmp_path):
     from vdn_hip import build
     shutil.copy(build.LIB, tmp_path / "lib.so")
     subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", str(tmp_path / "lib.so")], check=True, capture_output=True)
-    sizes = {}
-    for f in os.listdir(tmp_path):
+    src = open(os.path.join(os.path.dirname(build.__file__), "..", "csrc", "vdn_common.h")).read()
+    notes = re.findall(r"constexpr int (kWarmCode\w+) = (\d+) \* 1024;\s*// symbol: (\S+)", src)
+    assert len(notes) >= 8
+    syms = {}           # name -> (size, file, address)
+    for f in sorted(os.listdir(tmp_path)):
         if "amdgcn" not in f:
             continue
         out = subprocess.run([os.path.join(llvm, "llvm-readelf"), "-s", "-W", str(tmp_path / f)], check=True, capture_output=True, text=True).stdout
         for line in out.splitlines():
             p = line.split()
             if len(p) >= 8 and p[3] == "FUNC":
-                sizes[p[7]] = int(p[2], 0)
-    assert sizes
-    src = open(os.path.join(os.path.dirname(build.__file__), "..", "csrc", "vdn_common.h")).read()
-    notes = re.findall(r"constexpr int (kWarmCode\w+) = (\d+) \* 1024;\s*// symbol: (\S+)", src)
-    assert len(notes) >= 8
+                syms[p[7]] = (int(p[2], 0), f, int(p[1], 16))
+    assert syms
+    checked = 0
     for name, kib, sub in notes:
-        match = [s for n, s in sizes.items() if re.search(sub, n)]
+        match = {n: v for n, v in syms.items() if re.search(sub, n)}
         assert match, (name, sub)
-        assert int(kib) * 1024 + 4096 <= min(match), (name, kib, min(match))
+        for n, (size, f, addr) in match.items():
+            dis = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", "--disassemble-symbols=" + n, str(tmp_path / f)],
+                                 check=True, capture_output=True, text=True).stdout
+            # the warm-up site is `s_getpc_b64 s[N:N+1]` whose low half is rounded down to 16 bytes (`s_and_b32 sN, sN, -16`) within the
+            # next instructions; the compiler's own s_getpc (pc-relative addresses, relaxed long branches) add a literal instead
+            lines = dis.splitlines()
+            sites = []
+            for i, ln in enumerate(lines):
+                m = re.search(r"s_getpc_b64 s\[(\d+):\d+\]\s*//\s*([0-9A-Fa-f]+):", ln)
+                if m and any(re.search(r"s_and_b32 s%s, s%s, -16\b" % (m.group(1), m.group(1)), x) for x in lines[i + 1:i + 5]):
+                    sites.append(int(m.group(2), 16) - addr)
+            assert sites, (name, n, "no s_getpc in the kernel: the warm-up site is gone")
+            assert all(0 <= o < size for o in sites), (name, n, sites, size)
+            # (+ 16: the site's address is rounded down to 16 bytes, the slices up to 256 inside `bytes & ~255`)
+            assert max(sites) + int(kib) * 1024 + 16 <= size, (name, n, max(sites), kib, size)
+            checked += 1
+    assert checked >= 8

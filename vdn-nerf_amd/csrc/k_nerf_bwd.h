@@ -19,8 +19,8 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void nerf_bwd_ke
     // p = row in the (possibly compacted) work list = row of the saves and deltas; pd = dense point id of the upstream grads
     const long n_rows = a.active_idx != nullptr ? (long)*a.n_active : (long)a.P;
     if ((long)blockIdx.x * P::kWaves * 32 >= n_rows) return;
-    warm_sink_t wsink = ws.warm_begin((n_rows + P::kWaves * 32 - 1) / (P::kWaves * 32), 256 * P::kMinWavesPerEU);      // (mlp_engine.h)
-    warm_sink_t wcode = warm_code_begin((std::is_same<P, BF16>::value) ? kWarmCodeNerfBwd : 0, (n_rows + P::kWaves * 32 - 1) / (P::kWaves * 32), 256 * P::kMinWavesPerEU);      // (the kernel's own code: vdn_common.h)
+    ws.warm_issue((n_rows + P::kWaves * 32 - 1) / (P::kWaves * 32), 256 * P::kMinWavesPerEU);      // (mlp_engine.h)
+    warm_code_issue((std::is_same<P, BF16>::value) ? kWarmCodeNerfBwd : 0, (n_rows + P::kWaves * 32 - 1) / (P::kWaves * 32), 256 * P::kMinWavesPerEU, ws.warm_dump());      // (the kernel's own code: vdn_common.h)
     const long p_raw = ((long)blockIdx.x * P::kWaves + ws.wave) * 32 + c;
     const bool ok = p_raw < n_rows;
     const long p = ok ? p_raw : n_rows - 1;
@@ -81,8 +81,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void nerf_bwd_ke
         };
     };
     ws.all_issue = __any(ok);
-    warm_l2_end(wsink);
-    warm_l2_end(wcode);
+    warm_l2_wait();
     ws.start();
     // Wout^T: -> d hv (128), masked by the views layer's ReLU
     dense<P, KO, 4, false>(ws, X, 0, [&](int nt) VDN_INL { return P::load_tile(save_hv, p, 128, nt, h); },

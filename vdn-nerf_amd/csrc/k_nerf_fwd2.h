@@ -51,8 +51,9 @@ __global__ __launch_bounds__(256, 2) void nerf_fwd2_kernel(NerfArgs a) {
     const long n_rows = a.active_idx != nullptr ? (long)*a.n_active : (long)a.P;
     if ((long)blockIdx.x * 4 * 32 >= n_rows) return;          // whole workgroup beyond the active list
     // (mlp_engine.h: cold weight stream inside a training step; it arrives underneath the encodings below)
-    warm_sink_t wsink = SAVE ? warm_l2_begin(a.blob, PG::total * kSlot, (n_rows + 127) / 128, 512) : warm_sink_t{0u, 0u, 0u, 0u};
-    warm_sink_t wcode = warm_code_begin(SAVE ? kWarmCodeNerfFwd2 : 0, (n_rows + 127) / 128, 512);
+    char* const wdump = smem + pp.wave * 1024;       // (this wave's own first DMA piece of ring slot 0: vdn_common.h)
+    if constexpr (SAVE) warm_l2_issue(a.blob, PG::total * kSlot, (n_rows + 127) / 128, 512, wdump);
+    warm_code_issue(SAVE ? kWarmCodeNerfFwd2 : 0, (n_rows + 127) / 128, 512, wdump);
     const long q_raw = ((long)blockIdx.x * 4 + pp.wave) * 32 + c;
     const bool ok = q_raw < n_rows;
     const long q = ok ? q_raw : n_rows - 1;                   // out-of-range lanes repeat the last row (their plane stores are duplicates)
@@ -109,8 +110,7 @@ __global__ __launch_bounds__(256, 2) void nerf_fwd2_kernel(NerfArgs a) {
         };
     };
     auto sv = [&](int l) VDN_INL { return save_h + l * PS; };
-    warm_l2_end(wsink);
-    warm_l2_end(wcode);
+    warm_l2_wait();
     pp.template start<PG>();
     auto f0 = flow::flow_begin();
     auto f1 = flow::dense2<PG, 8>(f0, pp, X, flow::NoLoad{}, relu_into(Y, 0, sv(0), 256));          // pts_linears.0

@@ -19,8 +19,8 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_b
     const int lane = ws.lane, c = lane & 31, h = lane >> 5;
     const WorkRow wr = work_row(a.active_idx, a.n_active, a.P, P::kWaves, ws.wave, c);
     if (wr.none) return;
-    warm_sink_t wsink = ws.warm_begin(wr.n_wg, 256 * P::kMinWavesPerEU);      // (mlp_engine.h; ends before the ring starts)
-    warm_sink_t wcode = warm_code_begin((std::is_same<P, BF16>::value) ? kWarmCodeRenderBwd : 0, wr.n_wg, 256 * P::kMinWavesPerEU);      // (the kernel's own code: vdn_common.h)
+    ws.warm_issue(wr.n_wg, 256 * P::kMinWavesPerEU);      // (mlp_engine.h; ends before the ring starts)
+    warm_code_issue((std::is_same<P, BF16>::value) ? kWarmCodeRenderBwd : 0, wr.n_wg, 256 * P::kMinWavesPerEU, ws.warm_dump());      // (the kernel's own code: vdn_common.h)
     const bool ok = wr.ok;
     const long p = wr.row, pd = wr.point;          // p: row of saves / deltas / d_feat; pd: dense point id
     const long PS = P::plane(a.P, 256);
@@ -67,8 +67,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_b
         };
     };
     ws.all_issue = __any(ok);
-    warm_l2_end(wsink);
-    warm_l2_end(wcode);
+    warm_l2_wait();
     ws.start();
     dense<P, NT_OUT, 8, false, kBwdPrefetch>(ws, X, 0, ldH(3), mask_store(Y, 3), P::kTileOps, P::kTileOps);   // W4^T
     dense<P, 8, 8, false, kBwdPrefetch>(ws, Y, 0, ldH(2), mask_store(X, 2), P::kTileOps, P::kTileOps);        // W3^T

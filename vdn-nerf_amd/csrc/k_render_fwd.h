@@ -23,8 +23,8 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_f
     const WorkRow wr = work_row(a.active_idx, a.n_active, a.P, P::kWaves, ws.wave, c);
     if (wr.none) return;
     // training step: the stream is cold (vdn_common.h: warm_l2); it arrives in L2 underneath the input assembly below
-    warm_sink_t wsink = a.save_h != nullptr ? ws.warm_begin(wr.n_wg, 256 * P::kMinWavesPerEU) : warm_sink_t{0u, 0u, 0u, 0u};
-    warm_sink_t wcode = warm_code_begin((a.save_h != nullptr && std::is_same<P, BF16>::value) ? kWarmCodeRenderFwd : 0, wr.n_wg, 256 * P::kMinWavesPerEU);      // (the kernel's own code: vdn_common.h)
+    if (a.save_h != nullptr) ws.warm_issue(wr.n_wg, 256 * P::kMinWavesPerEU);
+    warm_code_issue((a.save_h != nullptr && std::is_same<P, BF16>::value) ? kWarmCodeRenderFwd : 0, wr.n_wg, 256 * P::kMinWavesPerEU, ws.warm_dump());      // (the kernel's own code: vdn_common.h)
     const bool ok = wr.ok;
     const long p = wr.row, pd = wr.point;          // p: row of feat and of the saves; pd: dense point id
     const long r = pd / a.n_per_ray;
@@ -77,8 +77,7 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_f
     };
     const int est = save_h != nullptr ? P::kTileOps : 0;
     ws.all_issue = __any(ok);
-    warm_l2_end(wsink);
-    warm_l2_end(wcode);
+    warm_l2_wait();
     ws.start();
     dense<P, 10 + EX, 8, true>(ws, X, 0, NoPre{}, relu_into(Y, 0), est);
     dense<P, 8, 8, true>(ws, Y, 0, NoPre{}, relu_into(X, 1), est);

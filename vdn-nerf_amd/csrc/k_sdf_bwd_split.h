@@ -152,9 +152,12 @@ __global__ __launch_bounds__(kWaves * 64, 1) void sdf_bwd_split_kernel(SdfRbarAr
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     const WorkRow wr = work_row(ra.active_idx, ra.n_active, ra.P, 1, 0, c);
     if (wr.none) return;
-    warm_l2(ra.blob, 63 * kStride, wr.n_wg, 256);       // (mlp_engine.h: both weight streams are cold inside a training step)
-    warm_l2(fa.blob, 67 * kStride, wr.n_wg, 256);
-    { warm_sink_t wcode = warm_code_begin(kWarmCodeSdfBwdSplit, wr.n_wg, 256); warm_l2_end(wcode); }
+    // (vdn_common.h: both weight streams and the code are cold inside a training step; the LDS of this kernel holds activations
+    // that any wave writes: the barrier behind the wait keeps them out of a slower wave's dump area)
+    warm_l2_issue(ra.blob, 63 * kStride, wr.n_wg, 256, smem + wave * 1024);
+    warm_l2_issue(fa.blob, 67 * kStride, wr.n_wg, 256, smem + wave * 1024);
+    warm_code_issue(kWarmCodeSdfBwdSplit, wr.n_wg, 256, smem + wave * 1024);
+    warm_l2_sync();
     const bool ok = wr.ok;
     const long p = wr.row, pd = wr.point;
     const long Pn = P::rows(ra.P), PS = Pn * 256;

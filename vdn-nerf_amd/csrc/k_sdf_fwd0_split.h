@@ -115,7 +115,10 @@ __global__ __launch_bounds__(kWaves * 64, 1) void sdf_fwd0_split_kernel(SdfArgs 
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     const WorkRow wr = work_row(a.active_idx, a.n_active, a.P, 1, 0, c);
     if (wr.none) return;
-    if (a.cold_start) warm_l2(a.blob, PG::total * sdf2::kStride, wr.n_wg, 256);      // (vdn_common.h)
+    if (a.cold_start) {         // (vdn_common.h; wave-uniform condition: every wave takes the barrier)
+        warm_l2_issue(a.blob, PG::total * sdf2::kStride, wr.n_wg, 256, smem + wave * 1024);
+        warm_l2_sync();
+    }
 
     WSet WA, WB;                                    // even / odd layers
     load_weights<0>(WA, a.blob, wave, lane);

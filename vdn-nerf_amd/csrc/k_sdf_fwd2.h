@@ -436,11 +436,12 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
     // the input loads above have to be back first: the compiler waits for them with vmcnt(0), which would also wait for younger
     // warm-up loads; behind this wait the stream arrives in L2 while the encoding below is computed from registers
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    warm_sink_t warm_a = warm_l2_begin(a.blob, ex.warm_bytes, wr.n_wg, MODE == 0 ? 512 : 256);
-    warm_sink_t warm_b = warm_l2_begin(MODE == 2 ? ex.color_blob : nullptr, MODE == 2 ? ex.warm_bytes2 : 0, wr.n_wg, 256);
+    char* const wdump = smem + pp.wave * 1024;       // (this wave's own first DMA piece of ring slot 0: vdn_common.h)
+    warm_l2_issue(a.blob, ex.warm_bytes, wr.n_wg, MODE == 0 ? 512 : 256, wdump);
+    warm_l2_issue(MODE == 2 ? ex.color_blob : nullptr, MODE == 2 ? ex.warm_bytes2 : 0, wr.n_wg, 256, wdump);
     // (and the kernel's own code: vdn_common.h; MODE 2 is the inference launch and is never cold)
     constexpr int kCode = MODE == 0 ? kWarmCodeSdfFwd2Mode0 : (MODE == 1 ? (SAVE ? kWarmCodeSdfFwd2Save : kWarmCodeSdfFwd2) : 0);
-    warm_sink_t warm_c = warm_code_begin(ex.warm_bytes > 0 ? kCode : 0, wr.n_wg, MODE == 0 ? 512 : 256);
+    warm_code_issue(ex.warm_bytes > 0 ? kCode : 0, wr.n_wg, MODE == 0 ? 512 : 256, wdump);
 
     typename P::template Act<9> X, Y;
     typename P::template Act<9> F;          // MODE 2: the feature vector as the colour head's input fragments (tiles 0..7) + its small tile (8)
@@ -476,9 +477,6 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
         pe7[0] = X.r[0]; pe7[1] = X.r[1];
         X.r[16] = X.r[2]; X.r[17] = X.r[3];
     }
-    warm_l2_end(warm_a);
-    warm_l2_end(warm_b);
-    warm_l2_end(warm_c);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ordinary loads and stores above: nothing but DMA and counted stores from here on
     // ring start (behind the PE stores, so that nothing but counted operations is younger than a DMA): W8 row 0 into its
     // fixed place (wave 0), chunks 0 .. DEPTH-1 in flight, chunk 0 certified, its opening fragments read

@@ -60,8 +60,10 @@ struct WStream {
         all_issue = false;
     }
     // L2 warm-up of the whole stream by the launch's first round of workgroups (warm_l2 above); before start()
-    VDN_DEV void warm(long n_wg, int resident) const { warm_l2(g, total * STRIDE, n_wg, resident); }
-    VDN_DEV warm_sink_t warm_begin(long n_wg, int resident) const { return warm_l2_begin(g, total * STRIDE, n_wg, resident); }
+    // (the dump area of the warm-up's LDS-DMA: this wave's own first piece of ring slot 0 - vdn_common.h)
+    VDN_DEV char* warm_dump() const { return lds + (threadIdx.x >> 6) * 1024; }
+    VDN_DEV void warm(long n_wg, int resident) const { warm_l2(g, total * STRIDE, n_wg, resident, warm_dump()); }
+    VDN_DEV void warm_issue(long n_wg, int resident) const { warm_l2_issue(g, total * STRIDE, n_wg, resident, warm_dump()); }
     VDN_DEV void issue_next() {
         char* dst = lds + (issued % NSLOT) * STRIDE;
 #pragma unroll

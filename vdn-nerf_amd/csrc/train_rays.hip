@@ -368,12 +368,13 @@ __global__ __launch_bounds__(kRW * 64) void composite_bwd_kernel(CompositeBwdArg
 __global__ __launch_bounds__(kRW * 64) void composite_train_kernel(CompositeArgs fa, CompositeBwdArgs ba, const float* true_rgb, float* g_color,
                                                                    const int32_t* fg_count, float igr_weight, float grad_scale) {
     __shared__ float s_w[kRW][kMaxTB], s_in[kRW][kMaxTB];
+    __shared__ __attribute__((aligned(16))) char s_dump[kRW][1024];       // the code warm-up's LDS-DMA lands here (vdn_common.h); never read
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = blockIdx.x * kRW + wave;
     if (r >= fa.B) return;
     // (the launch sits alone on the step's critical path between the forward and the backward kernels, on caches full of their
     // planes: its 47 KB of code arrive as data while the ray's planes are loaded - vdn_common.h)
-    warm_sink_t wcode = warm_code_begin(kWarmCodeCompositeTrain, gridDim.x, 2048);
+    warm_code_issue(kWarmCodeCompositeTrain, gridDim.x, 2048, s_dump[wave]);
     const RowOut ro = composite_row(fa, r, lane, CompositeGlobalSrc{fa.sdf, fa.normals, fa.color}, s_w[wave], s_in[wave]);
     CompositeBwdOvr ov;
     ov.on = true;
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(kRW * 64) void composite_train_kernel(CompositeArgs
     ov.g_eik = igr_weight;
     ov.eik_den = (float)(*fg_count) + 1e-5f;
     composite_bwd_row(ba, r, wave, lane, ov);
-    warm_l2_end(wcode);
+    warm_l2_wait();
 }
 
 // composite_bwd_kernel with the upstream gradients made on the spot, as in composite_train_kernel: the colour term's from the colour

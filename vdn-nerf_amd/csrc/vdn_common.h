@@ -68,6 +68,17 @@ VDN_DEV int rho(int t, int h) { return (t & 3) + 8 * (t >> 2) + 4 * h; }
 #define VDN_BS_LDV_AUX 2
 #endif
 
+// async global -> LDS copy of 16 B per lane; LDS destination = wave-uniform base + lane*16.
+// Inline asm, not __builtin_amdgcn_global_load_lds: with the builtin, hipcc's wait-count pass marks a pending FLAT access
+// and from then on emits s_waitcnt lgkmcnt(0) in front of every LDS consumer - a full LDS round trip before each MFMA
+// group instead of a counted wait (measured on the SDF forward kernel, profiles/README.md round 2). The kernels count
+// these loads themselves (WStream::acquire's vmcnt); the compiler does not see them. M0 (the LDS destination base) is
+// declared clobbered.
+VDN_DEV void glds16(const void* gsrc_lane, void* lds_wave_base) {
+    const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc_lane), "s"(lds) : "memory", "m0");
+}
+
 // L2 warm-up of a kernel's weight stream. Inside a training step every MLP kernel starts on caches full of other kernels'
 // planes: each chunk of its weight stream is then an HBM miss for the first workgroup of each XCD that asks for it, and as the
 // workgroups of a launch walk the stream in lockstep, every one of its ~40-140 chunk steps waits that miss out (measured on the fused
@@ -79,35 +90,44 @@ VDN_DEV int rho(int t, int h) { return (t & 3) + 8 * (t >> 2) + 4 * h; }
 #ifndef VDN_WARM_L2
 #define VDN_WARM_L2 1
 #endif
-// Two halves, so that a kernel can do its own prologue (input loads, encodings) while the stream arrives: warm_l2_begin issues the
-// loads and hands back the registers they land in, warm_l2_end waits for them. The loads write that register quadruple whenever
-// they return, so it must stay allocated until they have: the compiler does not know these asm statements are loads and would hand
-// the registers to the next values while data is still on its way into them (which is why _end takes it as an in-out operand).
+// Two halves, so that a kernel can do its own prologue (input loads, encodings) while the stream arrives: warm_l2_issue issues the
+// loads, warm_l2_wait (s_waitcnt vmcnt(0)) waits for them. The loads are LDS-DMA (global_load_lds_dwordx4): their data lands in a
+// 1-KiB LDS dump area, NOT in registers. (Round 4 loaded into a VGPR quadruple handed from an asm statement in _begin to one in
+// _end: the compiler does not know that such registers are the target of loads still in flight, and any copy, coalescing or spill
+// of the value in between would have freed the physical registers for live values that the returning data then overwrites - ADVICE
+// round 4.) `lds_dump` (wave-uniform): 1 KiB that nothing else reads or writes until THIS wave has passed its next
+// s_waitcnt vmcnt(0) - in the ring kernels the wave's own first DMA piece of ring slot 0 (lds + wave * 1024: written only by this
+// wave's own DMA, which it issues behind that wait; read by the others only behind the chunk's barrier); in kernels whose LDS holds
+// activations, any 1 KiB per wave with a workgroup barrier behind the wait (warm_l2_sync).
 // Un-counted vector-memory operations in flight only make a counted or compiler-placed s_waitcnt vmcnt(N) return later.
-typedef unsigned warm_sink_t __attribute__((ext_vector_type(4)));
-VDN_DEV warm_sink_t warm_l2_begin(const char* blob, int bytes, long n_wg, int resident) {
-    warm_sink_t sink = {0u, 0u, 0u, 0u};
+VDN_DEV void warm_l2_issue(const char* blob, int bytes, long n_wg, int resident, char* lds_dump) {
 #if VDN_WARM_L2
     const int first = n_wg < resident ? (int)n_wg : resident;          // workgroups of the first round
-    if (bytes <= 0 || first < 128 || (int)blockIdx.x >= first) return sink;     // (a small launch's few workgroups would each read MBs)
+    if (bytes <= 0 || first < 128 || (int)blockIdx.x >= first) return;     // (a small launch's few workgroups would each read MBs)
     const int slices = first >> 3;
     const int j = blockIdx.x >> 3;
-    if (j >= slices) return sink;
+    if (j >= slices) return;
     const int slice = ((bytes + slices - 1) / slices + 255) & ~255;
     const int begin = j * slice, end = begin + slice < bytes ? begin + slice : bytes;
-    for (int off = begin + (int)threadIdx.x * 16; off < end; off += (int)blockDim.x * 16)
-        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(blob + off) : "memory");
+    for (int off = begin + (int)threadIdx.x * 16; off < end; off += (int)blockDim.x * 16) glds16(blob + off, lds_dump);
 #endif
-    return sink;
 }
-VDN_DEV void warm_l2_end(warm_sink_t& sink) {
+VDN_DEV void warm_l2_wait() {
 #if VDN_WARM_L2
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink)::"memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
 }
-VDN_DEV void warm_l2(const char* blob, int bytes, long n_wg, int resident) {
-    warm_sink_t sink = warm_l2_begin(blob, bytes, n_wg, resident);
-    warm_l2_end(sink);
+VDN_DEV void warm_l2(const char* blob, int bytes, long n_wg, int resident, char* lds_dump) {
+    warm_l2_issue(blob, bytes, n_wg, resident, lds_dump);
+    warm_l2_wait();
+}
+// ... for kernels whose LDS holds activations that ANY wave may write: every wave's dump has landed before anyone goes on
+// (all waves of the workgroup must call it)
+VDN_DEV void warm_l2_sync() {
+#if VDN_WARM_L2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#endif
 }
 
 // The kernel's own CODE is as cold as its weight stream: the MLP kernels are 40 - 140 KB of straight-line code (the chunk-step streams
@@ -118,12 +138,12 @@ VDN_DEV void warm_l2(const char* blob, int bytes, long n_wg, int resident) {
 // code into L2 as data, sliced like the stream: `bytes` from the current program counter on - a per-kernel constant chosen BELOW
 // the kernel's code size (tests/test_boundary_cpu.py checks it against the symbol table of the built objects), so the reads stay
 // inside the kernel's own code.
-VDN_DEV warm_sink_t warm_code_begin(int bytes, long n_wg, int resident) {
+VDN_DEV void warm_code_issue(int bytes, long n_wg, int resident, char* lds_dump) {
 #ifdef VDN_NO_CODE_WARM                     // (development A/B: VDN_BUILD_VARIANT="nocw:-DVDN_NO_CODE_WARM")
     bytes = 0;
 #endif
     const char* pc = reinterpret_cast<const char*>(__builtin_amdgcn_s_getpc() & ~15L);
-    return warm_l2_begin(pc, bytes & ~255, n_wg, resident);
+    warm_l2_issue(pc, bytes & ~255, n_wg, resident, lds_dump);
 }
 // bytes of code each kernel warms from its warm-up site on. One line per kernel: `// symbol: <substring of the mangled name>` is a regular expression for the
 // mangled names the constant applies to (tests/test_boundary_cpu.py: constant + 4 KiB <= the smallest matching symbol's size)
@@ -136,17 +156,6 @@ constexpr int kWarmCodeRenderFwd = 28 * 1024;         // symbol: rendernet_fwd_k
 constexpr int kWarmCodeRenderBwd = 36 * 1024;         // symbol: rendernet_bwd_kernelINS_4BF16E
 constexpr int kWarmCodeSdfBwdSplit = 20 * 1024;       // symbol: sdf_bwd_split_kernel
 constexpr int kWarmCodeCompositeTrain = 40 * 1024;    // symbol: composite_train_kernel
-
-// async global -> LDS copy of 16 B per lane; LDS destination = wave-uniform base + lane*16.
-// Inline asm, not __builtin_amdgcn_global_load_lds: with the builtin, hipcc's wait-count pass marks a pending FLAT access
-// and from then on emits s_waitcnt lgkmcnt(0) in front of every LDS consumer - a full LDS round trip before each MFMA
-// group instead of a counted wait (measured on the SDF forward kernel, profiles/README.md round 2). The kernels count
-// these loads themselves (WStream::acquire's vmcnt); the compiler does not see them. M0 (the LDS destination base) is
-// declared clobbered.
-VDN_DEV void glds16(const void* gsrc_lane, void* lds_wave_base) {
-    const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc_lane), "s"(lds) : "memory", "m0");
-}
 
 // Hardware transcendental forms (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp each): what the MLP
 // epilogues use - the ocml expf/log1pf expansions cost more VALU time than the layer's MFMAs.

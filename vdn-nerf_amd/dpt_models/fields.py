@@ -74,7 +74,9 @@ class _HipNet(nn.Module):
         # join=False: the Trainer's own forward, which places that wait itself - right in front of the first launch that needs it.)
         hook = self.__dict__.get("_stream_join") if join else None
         if hook is not None:
-            hook()
+            hook = hook()             # (a weakref.WeakMethod: the network does not keep its Trainer alive, and copies / pickles of
+            if hook is not None:      # the module carry no Trainer - __getstate__ below)
+                hook()
         dev = next(self.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("%s lives on %s; move it to the MI355X with .to('cuda') (no CPU path)"
@@ -85,6 +87,14 @@ class _HipNet(nn.Module):
             st = images.NetImages(self._matrices(), self._streams(), dev, fmt)
             self.__dict__["_img"] = st
         st.refresh(_stream())
+        return st
+
+
+    def __getstate__(self):
+        # device state and Trainer hooks are per-process / per-object: copy.deepcopy and torch.save(module) rebuild them lazily
+        st = dict(self.__dict__)
+        for k in ("_img", "_stream_join", "_scratch", "_cold_start"):
+            st.pop(k, None)
         return st
 
 
@@ -350,10 +360,17 @@ class NeRF(_HipNet):
         nf = 96 if self.gen_depth_feats else 0
         if active is not None and scratch:
             key = (P, nf, str(dev), _stream())
-            buf = self.__dict__.setdefault("_scratch", {}).get(key)
-            if buf is None:
+            ent = self.__dict__.setdefault("_scratch", {}).get(key)
+            if ent is None:
                 self.__dict__["_scratch"].clear()            # (one shape at a time: a new batch size replaces the old buffer)
-                buf = self.__dict__["_scratch"][key] = torch.zeros(P * (4 + nf), dtype=torch.float32, device=dev)
+                ent = self.__dict__["_scratch"][key] = [torch.zeros(P * (4 + nf), dtype=torch.float32, device=dev), img._key]
+            elif ent[1] != img._key:
+                # the parameters changed since the buffer was last zeroed (an optimizer step, a checkpoint reload): rows off the
+                # list may hold outputs of the OLD weights - non-finite ones if that state had diverged, and 0 * NaN would poison
+                # every later render. One fill per parameter change, none in a render loop
+                ent[0].zero_()
+                ent[1] = img._key
+            buf = ent[0]
         else:
             buf = (torch.empty if active is None else torch.zeros)(P * (4 + nf), dtype=torch.float32, device=dev)
         density, rgb = buf[:P], buf[P:4 * P].view(P, 3)

@@ -1,6 +1,7 @@
 """Build libvdn_render.so (gfx950) from csrc/*.hip with hipcc, in-tree.
 
-hipcc cross-compiles without a GPU. Objects are rebuilt only when a source or header is newer.
+hipcc cross-compiles without a GPU. An object is rebuilt only when its source or one of the headers it includes
+(hipcc -MD dependency files next to the objects) is newer.
 Usage: python -m vdn_hip.build [--force] [-j N]
 """
 import concurrent.futures as cf
@@ -42,14 +43,33 @@ def _headers_mtime():
     return m
 
 
+def _deps_mtime(depfile, hm):
+    """Newest mtime among the headers an object really includes (hipcc -MD wrote them next to the object); without a
+    dependency file, the newest header of the tree."""
+    try:
+        toks = open(depfile).read().replace("\\\n", " ").split()
+    except OSError:
+        return hm
+    m = 0.0
+    for t in toks[1:]:
+        if t.endswith(".h") and not t.startswith(("/opt/", "/usr/")):
+            q = t if os.path.isabs(t) else os.path.join(PKG, t)
+            try:
+                m = max(m, os.path.getmtime(q))
+            except OSError:
+                return hm           # a header was removed or renamed: rebuild
+    return m
+
+
 def _compile(src, force, hm):
     obj = os.path.join(OBJDIR, src[:-4] + ".o")
+    dep = obj[:-2] + ".d"
     sp = os.path.join(CSRC, src)
-    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(sp), hm):
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(sp), _deps_mtime(dep, hm)):
         return src, 0.0, ""
     t = time.time()
-    cmd = ["hipcc"] + BASE_FLAGS + PER_FILE_FLAGS.get(src, []) + ["-c", sp, "-o", obj]
-    r = subprocess.run(cmd, capture_output=True, text=True)
+    cmd = ["hipcc"] + BASE_FLAGS + PER_FILE_FLAGS.get(src, []) + ["-MD", "-MF", dep, "-c", sp, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=PKG)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))
     return src, time.time() - t, r.stderr

@@ -780,11 +780,13 @@ class TrainEngine:
                 tab, n, wgs = self.dw_groups[group]
                 lib.call("vdn_dw_gemm" + self.sfx, lib.ptr(tab), n, wgs, _stream())
 
-    def side_weight_grads(self, group, after=None):
+    def side_weight_grads(self, group, after=None, gemm_event=None):
         """One half of the rest group on the side stream (backward(defer_rest=True) came first): "nerf" = the background
         network's weight gradients, behind its backward on that stream; "heads" = the colour / VDN heads', behind the heads'
-        backward on the caller's stream. `after`: one more event to wait for. Returns the torch stream (None without a side
-        stream: the work was issued on the caller's)."""
+        backward on the caller's stream. `after`: one more event to wait for. gemm_event: recorded on the side stream right
+        behind the GEMM launch - the last reader of the forward's workspaces on that stream (saved planes, deltas, the device-side
+        row counts of the work lists): the next step's preparation, which rewrites them, waits for it. Returns the torch
+        stream (None without a side stream: the work was issued on the caller's)."""
         if self._side is None:
             self.weight_grads(group, _stream())
             return None
@@ -792,11 +794,11 @@ class TrainEngine:
             self._side.wait_event(after)
         elif group != "nerf":
             self._side.wait_event(self._ev_heads)
-        self.weight_grads(group, self._side.cuda_stream)
+        self.weight_grads(group, self._side.cuda_stream, gemm_event, event_stream=self._side)
         self._pending = False            # joined by the caller's own event, not by _join()
         return self._side
 
-    def rest_weight_grads(self, after=None):
+    def rest_weight_grads(self, after=None, gemm_event=None):
         """Second half of backward(defer_rest=True): the colour / VDN / background networks' weight gradients, issued on the side
         stream behind the background network's backward (or, without a side stream, on the caller's stream). `after`: an event
         the work should also wait for (the Trainer passes the SDF group's GEMM, so that the two HBM-bound GEMMs do not share the
@@ -809,20 +811,20 @@ class TrainEngine:
             self._side.wait_event(after)
         else:
             self._side.wait_event(self._ev_heads)
-        self.weight_grads("rest", self._side.cuda_stream)
+        self.weight_grads("rest", self._side.cuda_stream, gemm_event, event_stream=self._side)
         self._pending = False            # joined by the caller's own event, not by _join()
         return self._side
 
-    def weight_grads(self, group, stream, gemm_event=None):
+    def weight_grads(self, group, stream, gemm_event=None, event_stream=None):
         """Weight-gradient GEMM + finalize + weight-norm backward of one launch group ("sdf": the SDF network and the variance;
         "rest": colour / VDN heads and the background network) on `stream` (a raw handle). The two groups touch disjoint
-        slabs and disjoint ranges of the flat gradient buffer. gemm_event: recorded on torch's current stream (which must be
-        `stream`) right behind the GEMM launch."""
+        slabs and disjoint ranges of the flat gradient buffer. gemm_event: recorded right behind the GEMM launch on
+        `event_stream` (the torch stream object of `stream`; default: torch's current stream, which must then be `stream`)."""
         if group in self.dw_groups:
             tab, n, wgs = self.dw_groups[group]
             lib.call("vdn_dw_gemm" + self.sfx, lib.ptr(tab), n, wgs, stream)
         if gemm_event is not None:
-            gemm_event.record(torch.cuda.current_stream())
+            gemm_event.record(event_stream if event_stream is not None else torch.cuda.current_stream())
         if group in self.fin_groups:
             tab, n, max_m, phase1 = self.fin_groups[group]
             lib.call("vdn_dw_finalize", lib.ptr(tab), n, max_m, 0, stream)

@@ -31,7 +31,11 @@ class Collectives:
     the identity), which is how the RCCL path is exercised on a single GPU (tests/test_gpu_dp.py).
     """
 
-    def __init__(self, world_size, group=None, force=False):
+    def __init__(self, world_size, group=None, force=False, side_group=None):
+        """group: the process group of this Trainer's replicas (None = the world). Every rank of the WORLD must construct its
+        Trainer when the side communicator is made here (dist.new_group is collective over the world group): for a Trainer on a
+        sub-group, create the second communicator yourself - in every world rank - and pass it as `side_group`; without one a
+        sub-group Trainer runs all its collectives on `group`."""
         self.group = group
         self.enabled = bool(force) or world_size > 1
         if self.enabled and not dist.is_initialized():
@@ -41,10 +45,10 @@ class Collectives:
         # stream), the next step's 8-byte eikonal sums (critical path). In one group the critical ones would queue behind the
         # side-stream slices and their GEMMs; the side-stream slices therefore get a communicator of their own (same ranks).
         # Created by every rank in the same order (dist.new_group is collective). VDN_DP_SIDE_GROUP=0: one group for all.
-        self.side_group = group
-        if self.enabled and os.environ.get("VDN_DP_SIDE_GROUP", "1") != "0":
-            ranks = None if group is None else dist.get_process_group_ranks(group)
-            self.side_group = dist.new_group(ranks=ranks)
+        self.side_group = group if side_group is None else side_group
+        whole_world = group is None or (dist.is_initialized() and group is dist.group.WORLD)
+        if self.enabled and side_group is None and whole_world and os.environ.get("VDN_DP_SIDE_GROUP", "1") != "0":
+            self.side_group = dist.new_group(ranks=None)
         self.timing = False         # bench.py: HIP events around finish() -> exposed wait per tag
         self._timed = {}
 

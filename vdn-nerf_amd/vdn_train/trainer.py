@@ -19,6 +19,7 @@ schedule (overlap=False) bit for bit: the same launches on the same data, only o
 import ctypes
 import math
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -103,6 +104,7 @@ class Trainer:
         self.overlap = (os.environ.get("VDN_OVERLAP", "1") != "0") if overlap is None else bool(overlap)
         self._ev_gemm, self._ev_rest, self._ev_tail = (torch.cuda.Event() for _ in range(3))
         self._ev_comp, self._ev_log, self._log_stream = torch.cuda.Event(), torch.cuda.Event(), None
+        self._ev_ws, self._ws_pending = torch.cuda.Event(), False      # the side stream's last reader of the forward's workspaces
         self._rest_pending, self._rest_gen, self._joined = False, 0, {}
         self._jitter, self._jitter_next = None, 0
         self._main = None
@@ -115,7 +117,7 @@ class Trainer:
         # them beside the side-stream half).
         for m in (renderer.nerf, renderer.color_network, renderer.depth_network):
             if m is not None:
-                m.__dict__["_stream_join"] = self.join
+                m.__dict__["_stream_join"] = weakref.WeakMethod(self.join)
         # the sampler's first SDF pass of a step starts on caches full of the previous step's planes: it warms its weight stream
         # (VdnSdfArgs.cold_start; the kernels that save activations do so on their own)
         renderer.sdf_network.__dict__["_cold_start"] = True
@@ -195,11 +197,20 @@ class Trainer:
             # (the sampler only reads the SDF weight images: it runs beside the previous step's side-stream half)
             z, z_out = r._sample(rays_o, rays_d, near.reshape(B), far.reshape(B), r.perturb, t_rand, t_rand_out, z_vals_inject,
                                  defer_last_merge=True)
-        # (the side-stream half of the last step is joined in front of the heads' launches: eng.forward(before_heads=...). Without
-        # a side stream for the background network it runs on this stream and needs the join here. VDN_JOIN_EARLY=1: the A/B arm)
-        late_join = eng._side is not None and os.environ.get("VDN_JOIN_EARLY", "0") != "1"
+        # The side-stream half of the last step is joined in two places. (1) Here, in front of the step preparation, which rewrites
+        # the work lists' device-side row counts, and of the forward kernels, which rewrite the saved planes: the side stream's LAST
+        # READER of those workspaces - the heads' weight-gradient GEMM (it reads the feature plane, the heads' saves and deltas and
+        # fg_active[1]; the background network's backward and GEMM precede it on that stream) - has an event right behind its launch
+        # (write-after-read: ADVICE round 4; the first version of the late join left this ordering to timing). (2) In front of
+        # the heads' forward launches, the first ones on this stream that read what the side stream UPDATES (parameters, weight
+        # images): eng.forward(before_heads=...) - the rest of that stream's work (finalize, all-reduce, Adam, image build) stays
+        # off this stream's critical path until then. Without a side stream everything runs on this stream.
+        late_join = eng._side is not None
         if not late_join:
             self.join()
+        elif self._ws_pending:
+            torch.cuda.current_stream().wait_event(self._ev_ws)
+            self._ws_pending = False
         depth_on = self.conf["extract_depth"] and self.iter_step > self.conf["depth_start_iter"] and gt_feats is not None
         # Plain configuration (one rank, no mask, no mask loss, no VDN head): compositor, colour-term gradient and the compositor's
         # adjoint are ONE launch (vdn_composite_train) - nothing global sits between them but the eikonal denominator, which is
@@ -342,7 +353,8 @@ class Trainer:
             # halves behind the SDF GEMM; deferring the background half too (its next forward has slack) costs 1.48 - its GEMM
             # then starves the sampler's 256-workgroup SDF passes (150 us for an 18-us pass)
             self._ev_tail.record(torch.cuda.current_stream())
-            eng.side_weight_grads("heads", after=self._ev_tail)
+            eng.side_weight_grads("heads", after=self._ev_tail, gemm_event=self._ev_ws)
+            self._ws_pending = True
             with torch.cuda.stream(side):
                 update_rest(side.cuda_stream, "heads")
                 self._ev_rest.record(side)
@@ -354,7 +366,8 @@ class Trainer:
                 eng.weight_grads("heads", st)
                 update_rest(st, "heads")
             else:
-                side = eng.rest_weight_grads(after=self._ev_gemm) if self.overlap else None
+                side = eng.rest_weight_grads(after=self._ev_gemm, gemm_event=self._ev_ws) if self.overlap else None
+                self._ws_pending = side is not None
                 if side is None:
                     if not self.overlap:
                         eng._join()                     # the background network's backward (side stream) feeds the rest group
