@@ -476,6 +476,101 @@ def rays_fixture():
     return fx
 
 
+def pnf_fixture():
+    """The reference-held DATA on this path: the learned camera parameters it ships, pretrained-models/*/*/pnf_300000.pth
+    (schema: dpt_runner.py:383-401 - `pose_param_net` = LearnPose.state_dict() {init_c2w, r, t}, `intrin_net` = LearnIntrin {fx}).
+    Each checkpoint is loaded into the REFERENCE's own LearnPose / LearnIntrin (poses.py:16-93), and its learnable ray branch
+    (RaysGenerator.gen_random_rays_at with learnable=True, poses.py:189-212) runs on CPU with seeded, recorded pixels; the
+    reference's autograd gives d loss / d (r, t) for a fixed linear loss on the rays. Stored: the checkpoint's parameters
+    (a few hundred floats each: the reference does not travel), every camera's c2w and the intrinsics as the reference's modules
+    return them, rays and pose gradients. The image size is not part of the checkpoint (the scenes are not shipped):
+    H x W = 24 x 32 here - LearnIntrin's K is fx^2 W on the diagonal and (W/2, H/2) as principal point for any size."""
+    import glob
+    import importlib.util
+    fx = {}
+    store = {}
+    cv = types.ModuleType("cv2")
+    cv.imread = lambda name, flag=None: store[name].copy()
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "dpt_models" or k.startswith("dpt_models.") or k == "cv2"}
+    sys.modules["cv2"] = cv
+    pkg = types.ModuleType("dpt_models")
+    pkg.__path__ = [os.path.join(REFERENCE, "dpt_models")]
+    sys.modules["dpt_models"] = pkg
+    mods = {}
+    orig_cuda = torch.Tensor.cuda
+    orig_to = torch.Tensor.to
+    try:
+        for name in ("lie_group_helper", "poses"):
+            path = os.path.join(REFERENCE, "dpt_models", name + ".py")
+            spec = importlib.util.spec_from_file_location("dpt_models." + name, path)
+            mod = importlib.util.module_from_spec(spec)
+            sys.modules["dpt_models." + name] = mod
+            spec.loader.exec_module(mod)
+            assert os.path.realpath(mod.__file__).startswith(REFERENCE + os.sep), mod.__file__
+            mods[name] = mod
+        poses = mods["poses"]
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        # LearnIntrin.forward moves its matrix to torch.device('cuda') (poses.py:54, 89): the identity while this runs
+        torch.Tensor.to = lambda self, *a, **k: self if (a and isinstance(a[0], torch.device) and a[0].type == "cuda") else orig_to(self, *a, **k)
+        H, W, B = 24, 32, 16
+        files = sorted(glob.glob(os.path.join(REFERENCE, "pretrained-models", "*", "*", "pnf_300000.pth")))
+        assert len(files) == 10, files
+        names = []
+        rng = np.random.RandomState(17)
+        for f in files:
+            tag = "%s.%s" % tuple(f.split(os.sep)[-3:-1])
+            names.append(tag)
+            ck = torch.load(f, map_location="cpu", weights_only=False)
+            sd_pose, sd_intr = ck["pose_param_net"], ck["intrin_net"]
+            n = sd_pose["r"].shape[0]
+            pose_net = poses.LearnPose(n, True, True, torch.zeros(n, 4, 4))          # dpt_runner.py:76-84 builds it with the scene's poses
+            pose_net.load_state_dict(sd_pose)
+            intrin_net = poses.LearnIntrin(H, W, req_grad=True)
+            intrin_net.load_state_dict(sd_intr)
+            for k in ("init_c2w", "r", "t"):
+                fx["%s/%s" % (tag, k)] = sd_pose[k].numpy()
+            fx[tag + "/fx"] = sd_intr["fx"].numpy()
+            fx[tag + "/poses_iter_step"] = int(ck["poses_iter_step"])
+            with torch.no_grad():
+                fx[tag + "/c2w"] = np.stack([pose_net(i).numpy() for i in range(n)])
+                fx[tag + "/intrinsic"] = intrin_net().numpy()
+            # images: what cv.imread would return (RGBA, 8 bit); only the gathers of colour / mask touch them
+            imgs = []
+            bgra = rng.randint(0, 256, (n, H, W, 4)).astype(np.uint8)
+            for i in range(n):
+                imgs.append("/pnf/%s/%03d.png" % (tag, i))
+                store[imgs[-1]] = bgra[i]
+            gen = poses.RaysGenerator(imgs, None, None, pose_net, intrin_net, learnable=True, with_depth=False)
+            fx[tag + "/bgra"] = bgra[:3]                 # (the three cameras' images used below)
+            cams = [0, 1, 2]
+            for j, idx in enumerate(cams):
+                # swap the tested camera's image into slot idx: only three images are stored
+                seed = 100 + 7 * len(names) + j
+                torch.manual_seed(seed)
+                data = gen.gen_random_rays_at(idx, B)
+                torch.manual_seed(seed)
+                px = torch.randint(low=0, high=W, size=[B])
+                py = torch.randint(low=0, high=H, size=[B])
+                wgt = torch.tensor(rng.randn(B, 6).astype(np.float32))
+                loss = (data[:, :6] * wgt).sum()
+                gr, gt = torch.autograd.grad(loss, [pose_net.r, pose_net.t])
+                k = "%s/cam%d" % (tag, idx)
+                fx[k + "/pixels_x"], fx[k + "/pixels_y"], fx[k + "/data"] = px.numpy(), py.numpy(), data.detach().numpy()
+                fx[k + "/loss_weights"], fx[k + "/loss"] = wgt.numpy(), float(loss)
+                fx[k + "/grad_r"], fx[k + "/grad_t"] = gr[idx].numpy(), gt[idx].numpy()
+                assert all(float(g[i].abs().sum()) == 0.0 for g in (gr, gt) for i in range(n) if i != idx)       # only that camera's row
+        fx["names"] = np.array(names)
+        fx["H"], fx["W"] = H, W
+        print("[pnf] %d checkpoints, %d keys; cameras per scene: %s" % (len(names), len(fx), [fx[n + "/r"].shape[0] for n in names]))
+    finally:
+        torch.Tensor.cuda = orig_cuda
+        torch.Tensor.to = orig_to
+        for k in [k for k in sys.modules if k == "dpt_models" or k.startswith("dpt_models.") or k == "cv2"]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+    return fx
+
+
 CASES = [
     # name, seed, B, wdepth, variance, cos_anneal, perturb, kwargs
     ("white_v03_c0", 1, 24, False, 0.3, 0.0, 1.0, {}),
@@ -517,6 +612,8 @@ def generate(only=None):
         out["raygrad"] = raygrad_fixture(fields, renderer)
     if want("rays"):
         out["rays"] = rays_fixture()
+    if want("pnf_rays"):
+        out["pnf_rays"] = pnf_fixture()
     return out
 
 

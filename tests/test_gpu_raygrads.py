@@ -259,3 +259,51 @@ def test_learnable_rays_equal_the_fixed_pose_generator_and_carry_the_graph():
     o, v = lr.gen_rays_at(2, resolution_level=2)
     o2, v2 = fixed.gen_rays_at(2, resolution_level=2)
     assert o.shape == (H // 2, W // 2, 3) and (v - v2).abs().max().item() < 2e-6 and (o - o2).abs().max().item() < 1e-6
+
+
+@pytest.mark.gpu
+def test_learnable_rays_on_the_reference_shipped_cameras():
+    """tests/golden/pnf_rays.npz: the reference's learnable ray branch (RaysGenerator.gen_random_rays_at with learnable=True,
+    poses.py:189-212) run by the reference itself on the cameras IT SHIPS (pretrained-models/*/*/pnf_300000.pth, loaded into its
+    own LearnPose / LearnIntrin), with recorded pixels, and its autograd's d loss / d (r, t) for a fixed linear loss on the rays.
+    The same state_dicts in dpt_models.poses + LearnableRays on the device: rays, pixel gathers and pose gradients."""
+    from vdn_train.rays import RaysGenerator
+    from dpt_models.poses import LearnPose, LearnIntrin, LearnableRays
+    fx = load_golden("pnf_rays")
+    dev = torch.device("cuda:0")
+    H, W = int(fx["H"]), int(fx["W"])
+    worst = {"o": 0.0, "d": 0.0, "gr": 0.0, "gt": 0.0}
+    for tag in fx["names"]:
+        tag = str(tag)
+        n = fx[tag + "/r"].shape[0]
+        pose = LearnPose(n, True, True, torch.zeros(n, 4, 4))
+        pose.load_state_dict({k: torch.tensor(fx["%s/%s" % (tag, k)]) for k in ("init_c2w", "r", "t")})
+        intr = LearnIntrin(H, W, req_grad=True)
+        intr.load_state_dict({"fx": torch.tensor(fx[tag + "/fx"])})
+        pose, intr = pose.to(dev), intr.to(dev)
+        # the constructor's image branch (poses.py:117-122: RGBA composited on white) on the three stored images
+        bgra = fx[tag + "/bgra"].astype(np.float64) / 255.0
+        img, a = bgra[..., :3], bgra[..., 3:]
+        img = (img * a + (1 - a)).astype(np.float32)
+        fixed = RaysGenerator(img, a.astype(np.float32), fx[tag + "/c2w"][:3], fx[tag + "/intrinsic"], device=dev)
+        lr = LearnableRays(pose, intr, fixed)
+        for idx in (0, 1, 2):
+            k = "%s/cam%d" % (tag, idx)
+            want = fx[k + "/data"]
+            pose.zero_grad()
+            got = lr.gen_random_rays_at(idx, want.shape[0], pixels=(fx[k + "/pixels_x"].astype(np.float32), fx[k + "/pixels_y"].astype(np.float32)))
+            assert got.shape == want.shape == (16, 11)
+            g = got.detach().cpu().numpy()
+            worst["o"] = max(worst["o"], float(np.abs(g[:, :3] - want[:, :3]).max()))
+            worst["d"] = max(worst["d"], float(np.abs(g[:, 3:6] - want[:, 3:6]).max()))
+            assert np.array_equal(g[:, 6:], want[:, 6:]), (tag, idx)          # mask | colour | the zero feature column
+            loss = (got[:, :6] * torch.tensor(fx[k + "/loss_weights"], device=dev)).sum()
+            assert abs(float(loss) - float(fx[k + "/loss"])) < 2e-5 * max(1.0, abs(float(fx[k + "/loss"])))
+            loss.backward()
+            gr, gt = pose.r.grad.cpu().numpy(), pose.t.grad.cpu().numpy()
+            worst["gr"] = max(worst["gr"], float(np.abs(gr[idx] - fx[k + "/grad_r"]).max() / (np.abs(fx[k + "/grad_r"]).max() + 1e-30)))
+            worst["gt"] = max(worst["gt"], float(np.abs(gt[idx] - fx[k + "/grad_t"]).max() / (np.abs(fx[k + "/grad_t"]).max() + 1e-30)))
+            assert all(np.abs(gr[i]).sum() == 0 for i in range(n) if i != idx)
+    # origins: the translation column itself; directions: one normalise + two 3x3 products in fp32
+    assert worst["o"] < 1e-6 and worst["d"] < 2e-6, worst
+    assert worst["gr"] < 2e-5 and worst["gt"] < 2e-5, worst
