@@ -32,7 +32,7 @@ import torch
 # algorithmic FLOPs (2 per MAC, GEMM work only) - SURVEY.md 8d
 F_SDF, F_SDF1, F_GRAD, F_COL, F_VDN, F_NERF, F_NERF_DPT = 1049088, 918016, 918016, 542720, 590336, 1208320, 1232896
 PEAK = {"f32": 157.3e12, "bf16": 2.5e15}     # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
-PROFILE_ROUND = "r04"      # profiles/<round>_traffic_*.json: the PMC traffic figures quoted in `roofline.traffic`
+PROFILE_ROUND = "r05"      # profiles/<round>_traffic_*.json: the PMC traffic figures quoted in `roofline.traffic`
 
 
 def _profile_file(suffix):
@@ -198,7 +198,8 @@ def spawn_ranks(n):
 class Leg:
     """One configuration of the training step (precision x config) with its own renderer, trainer and resident batches."""
 
-    def __init__(self, args, dev, world, rank, precision, wdepth, n_batches, crop=None):
+    def __init__(self, args, dev, world, rank, precision, wdepth, n_batches, crop=None, cams=None, focal=None):
+        """cams / focal: another camera rig than the synthetic one (c2w [n,4,4], focal length in pixels of the 800 x 800 frame)."""
         from vdn_train import synth, factory
         from vdn_train.trainer import Trainer
         self.world, self.rank, self.dev, self.B, self.wdepth, self.precision = world, rank, dev, args.batch, wdepth, precision
@@ -208,13 +209,14 @@ class Leg:
         # wdepth: the depth-feature loss is live from the first timed step (dpt_runner.py:236 with depth_start_iter behind us)
         self.trainer = Trainer(self.rend, self.B, dev, conf=dict(extract_depth=True, depth_start_iter=-1) if wdepth else None,
                                world_size=world, rank=rank)
-        cams = synth.make_cameras(seed)
+        cams = synth.make_cameras(seed) if cams is None else cams
         perm = np.argsort(synth.uniform(seed, "perm", (len(cams),)))
         g = lambda x: torch.tensor(x).to(dev)
         self.gt_feats = g(synth.uniform(seed, "bench/feats/%d" % rank, (self.B, 96)).astype(np.float32)) if wdepth else None
+        focal = synth.FOCAL if focal is None else focal
 
         def batch(step):
-            o, d = synth.random_pixel_batch(seed, step, int(perm[step % len(perm)]), self.B, rank=rank, cams=cams, crop=crop)
+            o, d = synth.random_pixel_batch(seed, step, int(perm[step % len(perm)]), self.B, rank=rank, cams=cams, crop=crop, focal=focal)
             near, far = synth.near_far_from_sphere(o, d)
             return g(o), g(d), g(near), g(far), g(synth.target_colors(o, d))
         self.batches = [batch(s) for s in range(n_batches)]     # resident in HBM before any timed region
@@ -402,6 +404,67 @@ class Leg:
                 "traffic": traffic, "kernel_ms": tdw * 1e3, "tflops": dw_flops / tdw / 1e12}
 
 
+def runner_flow(args, dev, precision, steps, warmup=5):
+    """What an UNCHANGED dpt_runner.py executes on the drop-in classes (dpt_runner.py:117-144, 197-257): networks from the conf's
+    kwargs, torch.optim.Adam over .parameters(), per iteration render() under grad (one autograd node) -> the runner's torch
+    loss -> zero_grad -> loss.backward() -> optimizer.step(); the jitter from torch.rand inside render(). The path of
+    tests/test_gpu_runner_flow.py, timed: K steps bracketed by synchronize, median of >= 5 regions."""
+    import torch.nn.functional as F
+    from vdn_train import synth, factory
+    seed = 0
+    rend = factory.build_renderer(wdepth=False, device=dev, states=synth.make_all_states(seed), precision=precision)
+    params = rend._all_parameters()
+    opt = torch.optim.Adam(params, lr=5e-4)
+    cams = synth.make_cameras(seed)
+    g = lambda x: torch.tensor(x).to(dev)
+    B = args.batch
+    batches = []
+    for s in range(16):
+        o, d = synth.random_pixel_batch(seed, s, s % len(cams), B, cams=cams)
+        near, far = synth.near_far_from_sphere(o, d)
+        batches.append((g(o), g(d), g(near), g(far), g(synth.target_colors(o, d))))
+    bg = torch.ones([1, 3], device=dev)
+
+    def step(i):
+        rays_o, rays_d, near, far, true_rgb = batches[i % len(batches)]
+        mask = torch.ones(B, 1, device=dev)
+        mask_sum = mask.sum() + 1e-5
+        out = rend.render(rays_o, rays_d, near, far, background_rgb=bg, cos_anneal_ratio=0.5, depth_before_color=False)
+        color_error = (out["color_fine"] - true_rgb) * mask
+        color_fine_loss = F.l1_loss(color_error, torch.zeros_like(color_error), reduction="sum") / mask_sum
+        mask_loss = F.binary_cross_entropy(out["weight_sum"].clip(1e-3, 1.0 - 1e-3), mask)
+        loss = color_fine_loss + out["gradient_error"] * 0.1 + mask_loss * 0.0
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+    for i in range(warmup):
+        step(i)
+    regions = []
+    while len(regions) < 5 or (sum(regions) < 1.0 and len(regions) < 200):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for i in range(steps):
+            loss = step(len(regions) * steps + i)
+        torch.cuda.synchronize()
+        regions.append(time.time() - t0)
+    med = float(np.median(regions))
+    return {"rays_per_s": B * steps / med, "ms_per_step": med / steps * 1e3, "regions": len(regions), "final_loss": float(loss.item()),
+            "dtype": "f32" if precision == "fp32" else "bf16"}
+
+
+def real_cameras():
+    """A camera rig the reference SHIPS: the 33 learned poses and the focal coefficient of pretrained-models/pixiu/
+    womsk_learn_white_colmap/pnf_300000.pth, as the reference's own LearnPose / LearnIntrin return them (tests/golden/pnf_rays.npz,
+    written by tests/golden/make_golden.py::pnf_fixture) -> (c2w [33,4,4], focal in pixels of an 800-px-wide frame)."""
+    f = os.path.join(ROOT, "tests", "golden", "pnf_rays.npz")
+    if not os.path.exists(f):
+        return None
+    d = np.load(f, allow_pickle=False)
+    tag = "pixiu.womsk_learn_white_colmap"
+    return d[tag + "__c2w"].astype(np.float64), float(d[tag + "__fx"]) ** 2 * 800.0         # poses.py:80-84: focal = fx^2 * W
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -520,7 +583,12 @@ def main():
         for i in range(head.steps_done):             # to the same training state (the work lists shrink over the first ~600 steps)
             one.step(i)
         one.fence()
+        r1 = one.measure(0, K, min_trials=3, min_seconds=0.3)      # the one-stream schedule's own step time, beside its kernel figure
         roof = head.sdf_kernel_roofline(one_stream=one)   # every rank takes part (steps hold collectives); rank 0 gets the numbers
+        if roof is not None:
+            roof["schedule"] = ("one stream (VDN_SIDE_STREAM=0 VDN_OVERLAP=0: every launch of the step in order; the schedule of the committed "
+                                "rocprofv3 kernel trace). NOT the schedule of the line's ms_per_step: see roofline_in_step_two_streams")
+            roof["ms_per_step_of_this_schedule"] = r1["ms_per_step"]
         del one
         torch.cuda.empty_cache()
         roof_dw = head.dw_roofline() if rank == 0 else None
@@ -542,6 +610,22 @@ def main():
                                          note="same step on the exact-fp32 MFMA kernels (v_mfma_f32_32x32x2_f32): the path the 1e-4 parity tests hold on")
         if not wdepth:
             extras["wdepth"] = dict(other_leg(args.precision, True), config="womsk_white_wdepth (VDN head 4x256->96 + depth-feature loss, BASELINE.json configs[4])")
+        # what an unchanged dpt_runner.py executes: render() + loss.backward() + torch.optim.Adam through the drop-in classes
+        if world == 1:
+            extras["runner_flow"] = {"what": "render() under grad -> torch loss -> loss.backward() -> torch.optim.Adam.step() through the drop-in "
+                                             "classes (dpt_runner.py:214-257), 512 rays per step, default jitter",
+                                     "bf16": runner_flow(args, dev, "bf16", K), "fp32": runner_flow(args, dev, "fp32", max(4, K // 4))}
+            torch.cuda.empty_cache()
+        rc = real_cameras()
+        if rc is not None and args.crop is None:
+            leg = Leg(args, dev, world, rank, args.precision, wdepth, nb, cams=rc[0], focal=rc[1])
+            r = leg.measure(W, K)
+            del leg
+            torch.cuda.empty_cache()
+            extras["real_cameras"] = dict({k: r[k] for k in ("value", "ms_per_step", "trials", "work_list_rows_mean", "executed_model_flops_per_s")},
+                                          note="the same step with the camera rig of a scene the reference ships (33 learned poses + focal of "
+                                               "pretrained-models/pixiu/womsk_learn_white_colmap/pnf_300000.pth, via tests/golden/pnf_rays.npz), "
+                                               "pixels uniform over the 800 x 800 frame; networks and targets as in the headline leg")
         if args.crop is None:
             # the same step on an object-centric capture (pixels from the central 420-px window: the object fills the frame, as in
             # the DTU scenes the shipped configs train on): nearly every foreground sample lies inside the relaxed sphere, so the
@@ -582,6 +666,11 @@ def main():
             "model_flops_per_s": res["executed_model_flops_per_s"],
             "final_loss": res["final_loss"],
             "roofline": roof, "roofline_dw_gemm": roof_dw,
+            # the north-star kernel inside the steps of THIS line's schedule (default: two streams; what ms_per_step is measured on)
+            "roofline_in_step_two_streams": (dict({k: roof["in_step_two_streams"][k] for k in ("frac", "kernel_ms", "points", "steps")},
+                                                  schedule="default two-stream schedule = the schedule of ms_per_step: the background network's "
+                                                           "kernels share the chip with the launch", ms_per_step=res["ms_per_step"])
+                                             if roof is not None else None),
         }
         line.update(extras)
         if not args.no_cpu_baseline and world == 1:

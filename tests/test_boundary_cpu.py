@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) >= 10
     for name in declared:
         assert hasattr(l, name), name
-    assert l.vdn_abi_version() == int(re.search(r"#define\s+VDN_ABI_VERSION\s+(\d+)", text).group(1)) == 23
+    assert l.vdn_abi_version() == int(re.search(r"#define\s+VDN_ABI_VERSION\s+(\d+)", text).group(1)) == 24
 
 
 def test_struct_layouts_are_c_layouts():
@@ -196,3 +196,38 @@ def test_code_warm_up_sizes_stay_inside_their_kernels(tmp_path):
             assert max(sites) + int(kib) * 1024 + 16 <= size, (name, n, max(sites), kib, size)
             checked += 1
     assert checked >= 8
+
+
+def test_nothing_but_the_dma_statements_writes_m0_in_the_weight_stream_kernels(tmp_path):
+    """csrc/vdn_common.h glds16_imm*: a wave's LDS-DMA pieces of one chunk share ONE write of M0 (the LDS destination base), made
+    by the first piece's statement and read by the others up to a chunk step later. That holds as long as nothing else writes M0
+    in between: in the library that ships, every instruction with M0 as destination, in every kernel that issues LDS-DMA, must
+    be the head of one of the DMA statements (`s_mov_b32 / s_add_u32 m0` - `s_nop 0` - `global_load_lds_dwordx4`)."""
+    import os
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(llvm, "llvm-objdump")):
+        pytest.skip("no llvm-objdump")
+    from vdn_hip import build
+    shutil.copy(build.LIB, tmp_path / "lib.so")
+    subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", str(tmp_path / "lib.so")], check=True, capture_output=True)
+    kernels, writes = 0, 0
+    for f in sorted(os.listdir(tmp_path)):
+        if "amdgcn" not in f:
+            continue
+        dis = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", str(tmp_path / f)], check=True, capture_output=True, text=True).stdout
+        # split into functions at the symbol labels
+        for fn in re.split(r"\n(?=[0-9a-f]{16} <)", dis):
+            if "global_load_lds_dwordx4" not in fn:
+                continue
+            kernels += 1
+            name = fn.split("\n", 1)[0]
+            lines = [ln.split("//")[0].strip() for ln in fn.splitlines()[1:] if ln.strip()]
+            for i, ln in enumerate(lines):
+                parts = ln.replace(",", " ").split()
+                if len(parts) >= 2 and parts[1] == "m0" and not parts[0].startswith(("s_cmp", "s_bitcmp")):     # M0 as the destination operand
+                    writes += 1
+                    assert parts[0] in ("s_mov_b32", "s_add_u32"), (name, ln)
+                    assert lines[i + 1].startswith("s_nop") and lines[i + 2].startswith("global_load_lds_dwordx4"), (name, lines[i:i + 3])
+    assert kernels >= 20 and writes >= 1000

@@ -163,6 +163,98 @@ def test_one_rank_group_runs_the_collective_path_bit_for_bit(backend):
     assert same and np.isfinite(loss) and gmax > 0
 
 
+def _steps_batch(rank, it):
+    from vdn_train import synth
+    cams = synth.make_cameras(SEED)
+    o, d = synth.random_pixel_batch(SEED, it, it % len(cams), B, rank=rank, cams=cams)
+    near, far = synth.near_far_from_sphere(o, d)
+    t1, t2 = synth.jitter(SEED, it, B, rank=rank)
+    return [o, d, near, far, synth.target_colors(o, d), t1, t2]
+
+
+MULTI_CONF = dict(extract_depth=True, depth_start_iter=2, warm_up_end=10)     # the depth-feature loss switches on at the 4th step
+N_STEPS = 6
+
+
+def _multi_worker(rank, port, q, fused):
+    import hashlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "vdn-nerf_amd"))
+    os.environ["VDN_DP_FUSED"] = "1" if fused else "0"
+    import torch.distributed as dist
+    from vdn_train import synth, factory
+    from vdn_train.trainer import Trainer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    rend = factory.build_renderer(wdepth=True, device=dev, states=synth.make_all_states(SEED, wdepth=True), precision="bf16")
+    tr = Trainer(rend, B, dev, conf=MULTI_CONF, world_size=2, rank=rank)          # the default schedule: two streams, overlapped
+    g = lambda x: torch.tensor(x).to(dev)
+    feats = g(_gt_feats(rank))
+    digests, scal = [], []
+    for it in range(N_STEPS):
+        o, d, near, far, rgb, t1, t2 = _steps_batch(rank, it)
+        sc = tr.train_step(g(o), g(d), g(near), g(far), g(rgb), gt_feats=feats, t_rand=g(t1), t_rand_out=g(t2))
+        scal.append(sc.clone())
+        flat = tr.param_flat                        # (joins the side stream)
+        torch.cuda.synchronize()
+        digests.append(hashlib.md5(flat.cpu().numpy().tobytes()).hexdigest())
+    q.put((rank, digests, [x.cpu().numpy() for x in scal], tr.param_flat.cpu().numpy() if rank == 0 else None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_two_ranks_keep_identical_parameters_over_overlapped_steps(fused):
+    """Six steps of the DEFAULT (two-stream, overlapped) data-parallel schedule on two ranks, VDN head on, the depth-feature loss
+    switching on mid-run (the late Adam group starts stepping then): after EVERY step both ranks hold bit-identical parameters
+    (replicas never drift: every gradient slice is all-reduced before its Adam step, on whichever stream), and the run stays with
+    one process on the concatenated batches (losses to 1e-3, parameters to 1e-4 of their norm: Adam turns last-bit differences of
+    near-zero gradients into sign flips of the update, so an element-wise bound does not exist). Both forms of the step: the
+    one-launch compositor with the all-reduced foreground count (fused) and the early eikonal all-reduce (VDN_DP_FUSED=0)."""
+    import torch.multiprocessing as mp
+    from vdn_train import synth, factory
+    from vdn_train.trainer import Trainer
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_multi_worker, args=(r, port, q, fused)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        r, dig, scal, flat = q.get(timeout=900)
+        got[r] = (dig, scal, flat)
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    assert got[0][0] == got[1][0], "replicas drifted apart: %s" % [a == b for a, b in zip(got[0][0], got[1][0])]
+    assert len(set(got[0][0])) == N_STEPS                           # ... and the parameters did move every step
+    # one process, the concatenated batches
+    dev = torch.device("cuda:0")
+    rend = factory.build_renderer(wdepth=True, device=dev, states=synth.make_all_states(SEED, wdepth=True), precision="bf16")
+    tr = Trainer(rend, 2 * B, dev, conf=MULTI_CONF)
+    g = lambda x: torch.tensor(x).to(dev)
+    feats = g(np.concatenate([_gt_feats(0), _gt_feats(1)], 0))
+    for it in range(N_STEPS):
+        parts = [_steps_batch(0, it), _steps_batch(1, it)]
+        cat = [np.concatenate([parts[0][i], parts[1][i]], 0) for i in range(7)]
+        sc = tr.train_step(g(cat[0]), g(cat[1]), g(cat[2]), g(cat[3]), g(cat[4]), gt_feats=feats, t_rand=g(cat[5]), t_rand_out=g(cat[6])).cpu().numpy()
+        # [loss, colour, psnr, eikonal, depth, mask]: the eikonal term is global on every rank; colour / depth are per-rank means
+        r0, r1 = got[0][1][it], got[1][1][it]
+        assert abs(r0[3] - sc[3]) < 1e-3 * abs(sc[3]) and abs(r1[3] - sc[3]) < 1e-3 * abs(sc[3]), (it, r0[3], sc[3])
+        assert abs(0.5 * (r0[1] + r1[1]) - sc[1]) < 1e-3 * abs(sc[1]), (it, r0[1], r1[1], sc[1])
+        assert (sc[4] > 0) == (it > 2) and (r0[4] > 0) == (it > 2)         # the depth term enters at the 4th step, on every rank alike
+    ref = tr.param_flat.cpu().numpy()
+    dp = got[0][2]
+    assert np.linalg.norm(dp - ref) < 1e-4 * np.linalg.norm(ref), np.linalg.norm(dp - ref) / np.linalg.norm(ref)
+
+
 def _bench(cmd, env=None):
     import json
     import subprocess

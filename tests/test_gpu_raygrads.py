@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import load_golden
 from test_gpu_grads import _loss, g
 
 pytestmark = pytest.mark.gpu

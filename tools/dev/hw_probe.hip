@@ -1,0 +1,109 @@
+// Hardware facts the kernels' design leans on, measured rather than assumed (development probe; build: hipcc --offload-arch=gfx950 -O3
+// -o tools/dev/_build/hw_probe tools/dev/hw_probe.hip):
+//  1. global_load_lds_dwordx4 with an immediate offset: which LDS bytes and which global bytes does `offset:N` move?
+//  2. HBM bandwidth of pure stores (plain / nt / sc1 nt), pure loads and a copy over 1 GiB: what a kernel that only writes planes can reach.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ void glds_probe(const unsigned* src, unsigned* out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned* l = reinterpret_cast<unsigned*>(smem);
+    for (int i = threadIdx.x; i < 4096; i += 64) l[i] = 0xdead0000u + i;
+    __syncthreads();
+    const unsigned lane_off = threadIdx.x * 16;
+    const unsigned m0v = 4096;     // LDS byte address 4096
+    // global: src + lane*16 + 1024 (offset:1024) ; LDS: M0 (+ 1024 ?) + lane*16
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 offset:1024\n\ts_waitcnt vmcnt(0)" ::"v"(lane_off), "s"(m0v), "s"(src) : "memory", "m0");
+    // negative offset: global src + 8192 - 2048, LDS M0 = 12288 (- 2048 ?)
+    const unsigned m0b = 12288;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 offset:-2048\n\ts_waitcnt vmcnt(0)" ::"v"(lane_off + 8192u), "s"(m0b), "s"(src) : "memory", "m0");
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4096; i += 64) out[i] = l[i];
+}
+
+template <int MODE>   // 0 plain, 1 nt, 2 sc1 nt, 3 sc1
+__global__ void fill_kernel(u32x4* p, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    const u32x4 v = {1u, 2u, 3u, 4u};
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if constexpr (MODE == 0) p[i] = v;
+        else if constexpr (MODE == 1) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p + i), "v"(v) : "memory");
+        else if constexpr (MODE == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p + i), "v"(v) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p + i), "v"(v) : "memory");
+    }
+}
+__global__ void read_kernel(const u32x4* p, long n, unsigned* out) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    unsigned acc = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const u32x4 v = __builtin_nontemporal_load(p + i);
+        acc ^= v[0] ^ v[1] ^ v[2] ^ v[3];
+    }
+    if (acc == 0x12345u) out[0] = acc;
+}
+__global__ void copy_kernel(const u32x4* a, u32x4* b, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) b[i] = a[i];
+}
+
+template <class F>
+double time_us(F&& f, int reps = 7) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    std::vector<double> t;
+    for (int r = 0; r < reps; ++r) {
+        hipEventRecord(e0); f(); hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); t.push_back(ms * 1e3);
+    }
+    std::sort(t.begin(), t.end());
+    return t[t.size() / 2];
+}
+
+int main() {
+    // ---- 1. LDS-DMA with an immediate offset
+    unsigned *src, *out;
+    hipMalloc(&src, 65536 * 4); hipMalloc(&out, 4096 * 4);
+    std::vector<unsigned> h(65536);
+    for (int i = 0; i < 65536; ++i) h[i] = i;              // dword index = its own value
+    hipMemcpy(src, h.data(), 65536 * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(glds_probe, dim3(1), dim3(64), 16384, 0, src, out);
+    hipDeviceSynchronize();
+    std::vector<unsigned> o(4096);
+    hipMemcpy(o.data(), out, 4096 * 4, hipMemcpyDeviceToHost);
+    int first = -1, last = -1;
+    for (int i = 0; i < 4096; ++i) if (o[i] != 0xdead0000u + i) { if (first < 0) first = i; last = i; }
+    printf("glds offset probe: LDS dwords changed %d .. %d\n", first, last);
+    for (int i = 0; i < 4096; ++i) {
+        if (o[i] != 0xdead0000u + i && (i % 256 == 0 || (i > 0 && o[i - 1] == 0xdead0000u + i - 1)))
+            printf("  LDS byte %5d <- global dword %u (global byte %u)\n", i * 4, o[i], o[i] * 4);
+    }
+    printf("  (offset:1024 with M0 = 4096, lane off 0: LDS byte 4096 + 1024 = 5120 if the offset applies to the LDS address too; global byte 1024)\n");
+    printf("  (offset:-2048 with M0 = 12288, lane off 8192: LDS byte 10240 if it applies; global byte 6144)\n");
+    // ---- 2. bandwidth
+    const long bytes = 1L << 30, n = bytes / 16;
+    u32x4 *a, *b;
+    hipMalloc(&a, bytes); hipMalloc(&b, bytes);
+    hipMemset(a, 1, bytes); hipMemset(b, 2, bytes);
+    for (int grid : {2048, 8192}) {
+        printf("grid %d x 256 threads, 1 GiB:\n", grid);
+        printf("  store plain   %7.1f us = %5.2f TB/s\n", time_us([&] { hipLaunchKernelGGL(fill_kernel<0>, dim3(grid), dim3(256), 0, 0, a, n); }), 0.0);
+        double t;
+        t = time_us([&] { hipLaunchKernelGGL(fill_kernel<0>, dim3(grid), dim3(256), 0, 0, a, n); }); printf("  store plain   %7.1f us = %5.2f TB/s\n", t, bytes / t / 1e6);
+        t = time_us([&] { hipLaunchKernelGGL(fill_kernel<1>, dim3(grid), dim3(256), 0, 0, a, n); }); printf("  store nt      %7.1f us = %5.2f TB/s\n", t, bytes / t / 1e6);
+        t = time_us([&] { hipLaunchKernelGGL(fill_kernel<2>, dim3(grid), dim3(256), 0, 0, a, n); }); printf("  store sc1 nt  %7.1f us = %5.2f TB/s\n", t, bytes / t / 1e6);
+        t = time_us([&] { hipLaunchKernelGGL(fill_kernel<3>, dim3(grid), dim3(256), 0, 0, a, n); }); printf("  store sc1     %7.1f us = %5.2f TB/s\n", t, bytes / t / 1e6);
+        t = time_us([&] { hipLaunchKernelGGL(read_kernel, dim3(grid), dim3(256), 0, 0, a, n, (unsigned*)b); }); printf("  load nt       %7.1f us = %5.2f TB/s\n", t, bytes / t / 1e6);
+        t = time_us([&] { hipLaunchKernelGGL(copy_kernel, dim3(grid), dim3(256), 0, 0, a, b, n); }); printf("  copy          %7.1f us = %5.2f TB/s (read + write)\n", t, 2.0 * bytes / t / 1e6);
+    }
+    // 300 MB, the size of the background forward's saves
+    const long n300 = 300L * 1000 * 1000 / 16;
+    double t = time_us([&] { hipLaunchKernelGGL(fill_kernel<2>, dim3(2048), dim3(256), 0, 0, a, n300); });
+    printf("store sc1 nt, 300 MB: %7.1f us = %5.2f TB/s\n", t, 300e6 / t / 1e6);
+    t = time_us([&] { hipLaunchKernelGGL(fill_kernel<0>, dim3(2048), dim3(256), 0, 0, a, n300); });
+    printf("store plain,  300 MB: %7.1f us = %5.2f TB/s\n", t, 300e6 / t / 1e6);
+    return 0;
+}

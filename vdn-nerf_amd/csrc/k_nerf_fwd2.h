@@ -37,8 +37,12 @@ struct NerfFwdProg {
     }
 };
 
+#ifndef VDN_NERF_FWD_ST_MODE
+#define VDN_NERF_FWD_ST_MODE VDN_PLANE_ST_MODE      // cache policy of this kernel's saves (development A/B; mlp_engine.h: BF16::store_tile)
+#endif
 template <bool DPT, bool SAVE>
 __global__ __launch_bounds__(256, 2) void nerf_fwd2_kernel(NerfArgs a) {
+    constexpr int kSt = VDN_NERF_FWD_ST_MODE;
     using P = BF16;
     using ST = unsigned short;
     using PG = NerfFwdProg<DPT, SAVE>;
@@ -51,7 +55,7 @@ __global__ __launch_bounds__(256, 2) void nerf_fwd2_kernel(NerfArgs a) {
     const long n_rows = a.active_idx != nullptr ? (long)*a.n_active : (long)a.P;
     if ((long)blockIdx.x * 4 * 32 >= n_rows) return;          // whole workgroup beyond the active list
     // (mlp_engine.h: cold weight stream inside a training step; it arrives underneath the encodings below)
-    char* const wdump = smem + pp.wave * 1024;       // (this wave's own first DMA piece of ring slot 0: vdn_common.h)
+    char* const wdump = pp.warm_dump();              // (this wave's own first DMA piece of ring slot 0: vdn_common.h)
     if constexpr (SAVE) warm_l2_issue(a.blob, PG::total * kSlot, (n_rows + 127) / 128, 512, wdump);
     warm_code_issue(SAVE ? kWarmCodeNerfFwd2 : 0, (n_rows + 127) / 128, 512, wdump);
     const long q_raw = ((long)blockIdx.x * 4 + pp.wave) * 32 + c;
@@ -93,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void nerf_fwd2_kernel(NerfArgs a) {
             const f32x16 t16 = vals_tile<84>(pe, h, kt);
             X.set(kt, t16);
             if constexpr (SAVE) {
-                if (a.save_pe != nullptr) P::store_tile(reinterpret_cast<ST*>(a.save_pe), q, 96, kt, h, t16, true);
+                if (a.save_pe != nullptr) P::template store_tile<kSt>(reinterpret_cast<ST*>(a.save_pe), q, 96, kt, h, t16, true);
             }
         }
 #pragma unroll
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void nerf_fwd2_kernel(NerfArgs a) {
 #pragma unroll
             for (int t = 0; t < 16; ++t) o[t] = relu0(acc[t]);
             D.set(t0 + nt, o);
-            if constexpr (SAVE) P::store_tile(save, q, ld, nt, h, o, true);
+            if constexpr (SAVE) P::template store_tile<kSt>(save, q, ld, nt, h, o, true);
         };
     };
     auto sv = [&](int l) VDN_INL { return save_h + l * PS; };
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void nerf_fwd2_kernel(NerfArgs a) {
         if (nt < 8) {
             X.set(nt, acc);
             if constexpr (SAVE) {
-                if (a.save_feature != nullptr) P::store_tile(reinterpret_cast<ST*>(a.save_feature), q, 256, nt, h, acc, true);
+                if (a.save_feature != nullptr) P::template store_tile<kSt>(reinterpret_cast<ST*>(a.save_feature), q, 256, nt, h, acc, true);
             }
         } else {
             if (ok && h == 0) a.density[p] = acc[0];
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void nerf_fwd2_kernel(NerfArgs a) {
         const f32x16 t16 = vals_tile<27>(pe, h, 0);
         X.set(8, t16);
         if constexpr (SAVE) {
-            if (a.save_vpe != nullptr) P::store_tile(reinterpret_cast<ST*>(a.save_vpe), q, 32, 0, h, t16, true);
+            if (a.save_vpe != nullptr) P::template store_tile<kSt>(reinterpret_cast<ST*>(a.save_vpe), q, 32, 0, h, t16, true);
         }
     }
     auto f10 = flow::dense2<PG, 4, false>(f9, pp, X, flow::NoLoad{}, relu_into(Y, 0, reinterpret_cast<ST*>(a.save_hv), 128));

@@ -133,14 +133,17 @@ VDN_DEV void wait_vmcnt() {
 
 // LDS-DMA of 16 B per lane, written as inline asm: the builtin makes hipcc's wait-count pass treat every later LDS
 // wait as out of order (it marks a pending FLAT access), and it then emits s_waitcnt lgkmcnt(0) in front of every MFMA
-// that consumes a fragment - a full LDS round trip per MFMA group instead of a counted wait. Scalar base (wave-uniform)
-// + 32-bit per-lane offset; the LDS destination (wave-uniform byte address) goes through M0, which nothing else in this
-// kernel uses. Completion is tracked by the kernel's own counted vmcnt (the compiler does not see these loads).
+// that consumes a fragment - a full LDS round trip per MFMA group instead of a counted wait. Completion is tracked by the
+// kernel's own counted vmcnt (the compiler does not see these loads).
+// Addressing (round 5): immediate offsets, one M0 write per chunk (vdn_common.h: glds16_imm*). VDN_SDF2_DMA_IMM=0: the A/B arm
+// with one scalar base and one M0 write per piece.
+#ifndef VDN_SDF2_DMA_IMM
+#define VDN_SDF2_DMA_IMM 1
+#endif
 VDN_DEV void glds16_saddr(const char* base_uniform, unsigned lane_off, char* lds_wave_base) {
     const unsigned lds = (unsigned)(size_t)lds_wave_base;
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" ::"v"(lane_off), "s"(lds), "s"(base_uniform) : "memory", "m0");
 }
-
 // ---- pipeline state ---------------------------------------------------------------------------------------------
 template <int NSLOT, int SPLIT = (1 << 30)>
 struct Pipe {
@@ -154,12 +157,29 @@ struct Pipe {
     template <int C>
     VDN_DEV char* slot() const { return lds + (C % NSLOT) * kStride; }
     // DMA piece I (of kG) of chunk C: 1 KiB, wave-uniform base + per-lane 32-bit offset (scalar-base addressing)
+    unsigned voff0;     // lane * 16 + this wave's first byte in a chunk + 4096 (the centre of the pieces' immediate offsets)
+    unsigned m0_wave;   // LDS byte address of the same place in ring slot 0
+    VDN_DEV void init_dma() {
+        voff0 = lane16 + wave * (kG * 1024) + 4096;
+        m0_wave = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds + wave * (kG * 1024) + 4096);
+    }
     template <int C, int I>
     VDN_DEV void issue_piece() {
 #if !(VDN_SDF2_ABL & 4)
+#if VDN_SDF2_DMA_IMM
+        static_assert(kG <= 8, "one group of immediate offsets");
+        constexpr int IMM = glds_imm(I);
+        constexpr long COFF = (C >= SPLIT ? (long)(C - SPLIT) : (long)C) * kStride;
+        static_assert(COFF + kStride < (1L << 31), "32-bit chunk offsets");
+        const char* base = C >= SPLIT ? g2 : g;
+        const unsigned voff = voff0 + (unsigned)COFF;
+        if constexpr (I == 0) glds16_imm_m0add<(C % NSLOT) * kStride, IMM>(base, voff, m0_wave);
+        else glds16_imm<IMM>(base, voff);
+#else
         const int piece = wave + I * kWaves;
         if constexpr (C >= SPLIT) glds16_saddr(g2 + ((long)(C - SPLIT) * kStride + piece * 1024), lane16, slot<C>() + piece * 1024);
         else glds16_saddr(g + ((long)C * kStride + piece * 1024), lane16, slot<C>() + piece * 1024);
+#endif
 #endif
     }
     template <int C>
@@ -235,17 +255,6 @@ VDN_DEV f32x16 chunk_step(PipeT& pp, const ActT& X, Group&& group) {
         if constexpr (HAS_DMA && dma_burst<MODE, SAVE>(C)) {
             if constexpr (gi == 0) static_for<kG>([&](auto i_c) VDN_INL { pp.template issue_piece<C + DEPTH, decltype(i_c)::value>(); });
         } else if constexpr (HAS_DMA) {
-#ifdef VDN_SDF2_STAGGER
-            // even waves issue in even groups, odd waves in odd groups: at most two of the four waves' pieces meet in the
-            // CU's vector-memory path (the waves run in lockstep, so an unstaggered piece always meets three others)
-            if constexpr (NG >= 2 * kG - 2) {
-                constexpr int i = gi / 2;
-                if constexpr (i < kG - 1) {
-                    if ((pp.wave & 1) == (gi & 1)) pp.template issue_piece<C + DEPTH, i>();
-                }
-                if constexpr (gi == NG - 1) pp.template issue_piece<C + DEPTH, kG - 1>();
-            } else
-#endif
             static_for<kG>([&](auto i_c) VDN_INL {
                 constexpr int i = decltype(i_c)::value;
                 if constexpr ((NG >= kG ? i * NG / kG : (i < NG ? i : NG - 1)) == gi) pp.template issue_piece<C + DEPTH, i>();
@@ -387,6 +396,7 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
     pp.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     pp.lane = threadIdx.x & 63;
     pp.lane16 = pp.lane * 16;
+    pp.init_dma();
     const int lane = pp.lane, c = lane & 31, h = lane >> 5;
     const WorkRow wr = work_row(a.active_idx, a.n_active, a.P, kWaves, pp.wave, c);
     if (wr.none) return;
@@ -436,7 +446,7 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
     // the input loads above have to be back first: the compiler waits for them with vmcnt(0), which would also wait for younger
     // warm-up loads; behind this wait the stream arrives in L2 while the encoding below is computed from registers
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    char* const wdump = smem + pp.wave * 1024;       // (this wave's own first DMA piece of ring slot 0: vdn_common.h)
+    char* const wdump = smem + pp.wave * (VDN_SDF2_DMA_IMM ? kG * 1024 : 1024);       // (this wave's own first DMA piece of ring slot 0: vdn_common.h)
     warm_l2_issue(a.blob, ex.warm_bytes, wr.n_wg, MODE == 0 ? 512 : 256, wdump);
     warm_l2_issue(MODE == 2 ? ex.color_blob : nullptr, MODE == 2 ? ex.warm_bytes2 : 0, wr.n_wg, 256, wdump);
     // (and the kernel's own code: vdn_common.h; MODE 2 is the inference launch and is never cold)
@@ -814,16 +824,10 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
 template <int MODE, bool SAVE, int NSLOT, int DEPTH, int VID = 0, bool UPS = false>
 int launch(const VdnSdfArgs* args, hipStream_t stream, const VdnUpsampleArgs* up = nullptr, const ShadeExtra* ex = nullptr) {
     constexpr size_t lds_min = MODE >= 1 ? 160 * 1024 : NSLOT * kStride;
-    constexpr size_t lds_solo = 96 * 1024;          // more than half a CU's LDS: one workgroup per CU
-    static bool once = (allow_big_lds(sdf_fwd2_kernel<MODE, SAVE, NSLOT, DEPTH, VID, UPS>, lds_min > lds_solo ? lds_min : lds_solo), true);
+    static bool once = (allow_big_lds(sdf_fwd2_kernel<MODE, SAVE, NSLOT, DEPTH, VID, UPS>, lds_min), true);
     (void)once;
     const int grid = (args->P + kWaves * 32 - 1) / (kWaves * 32);
-    // MODE 0 may run two workgroups per CU, but two waves on a SIMD serialise their VALU work (they only hide each other's
-    // stalls). VDN_SDF0_SOLO=1: a launch that fits the chip at one workgroup per CU (the sampler's passes: 64 or 256
-    // workgroups) asks for enough LDS to get a CU to itself. Measured neutral on the step (same-box A/B, +-10 us): the
-    // dispatcher already spreads 64 workgroups over 64 CUs; off by default
-    static const bool solo = [] { const char* e = getenv("VDN_SDF0_SOLO"); return e != nullptr && e[0] == '1'; }();
-    const size_t lds = (MODE == 0 && solo && grid <= 256) ? lds_solo : lds_min;
+    const size_t lds = lds_min;
     // VDN_SDF2_WARM=0: no L2 warm-up (A/B); by default every launch that fills the chip at least once warms the stream it walks
     static const bool warm = [] { const char* e = getenv("VDN_SDF2_WARM"); return e == nullptr || e[0] != '0'; }();
     ShadeExtra exv = ex != nullptr ? *ex : ShadeExtra{};

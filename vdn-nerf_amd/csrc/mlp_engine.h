@@ -49,6 +49,7 @@ struct WStream {
     int wave, lane;
     bool all_issue;  // set by the kernel: this wave has at least one in-range lane (so it issues every store)
 
+    unsigned voff0, m0_wave;    // this wave's G KiB of a chunk (+ 4096: the centre of the pieces' immediate offsets, vdn_common.h): lane offset / LDS address in slot 0
     VDN_DEV void init(const char* blob, char* smem, int total_chunks) {
         g = blob;
         lds = smem;
@@ -58,19 +59,23 @@ struct WStream {
         wave = threadIdx.x >> 6;
         lane = threadIdx.x & 63;
         all_issue = false;
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        voff0 = lane * 16 + wv * (G * 1024) + 4096;
+        m0_wave = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem + wv * (G * 1024) + 4096);
     }
     // L2 warm-up of the whole stream by the launch's first round of workgroups (warm_l2 above); before start()
     // (the dump area of the warm-up's LDS-DMA: this wave's own first piece of ring slot 0 - vdn_common.h)
-    VDN_DEV char* warm_dump() const { return lds + (threadIdx.x >> 6) * 1024; }
+    VDN_DEV char* warm_dump() const { return lds + (threadIdx.x >> 6) * (G * 1024); }
     VDN_DEV void warm(long n_wg, int resident) const { warm_l2(g, total * STRIDE, n_wg, resident, warm_dump()); }
     VDN_DEV void warm_issue(long n_wg, int resident) const { warm_l2_issue(g, total * STRIDE, n_wg, resident, warm_dump()); }
     VDN_DEV void issue_next() {
-        char* dst = lds + (issued % NSLOT) * STRIDE;
-#pragma unroll
-        for (int i = 0; i < G; ++i) {
-            const int piece = wave + i * NWAVES;
-            glds16(g + piece * 1024 + lane * 16, dst + piece * 1024);
-        }
+        // (vdn_common.h: glds16_imm*) one M0 write per group of 8 pieces, the pieces by immediate offset from the chunk's scalar base
+        const unsigned m0v = m0_wave + (unsigned)((issued % NSLOT) * STRIDE);
+        static_for<G>([&](auto i_c) VDN_INL {
+            constexpr int I = decltype(i_c)::value;
+            if constexpr (I % 8 == 0) glds16_imm_m0<glds_imm(I)>(g, voff0 + glds_group_off(I), m0v + glds_group_off(I));
+            else glds16_imm<glds_imm(I)>(g, voff0 + glds_group_off(I));
+        });
         g += STRIDE;
         ++issued;
     }
@@ -373,6 +378,10 @@ struct BF16 {
     static constexpr int kTileOps = 2;      // vector-memory instructions per store_tile / load_tile (the kernels' vmcnt accounting)
     static VDN_DEV long rows(long P) { return (P + 31) & ~31L; }
     static VDN_DEV long plane(long P, int ld) { return rows(P) * ld; }
+    // MODE: cache policy of the two 16-byte stores. 0 plain; 1 write-through (sc1: the line is not kept in this XCD's L2 - saved
+    // planes and deltas are next read by other kernels, while the L2 is what feeds every MLP kernel's weight stream); 2 non-temporal;
+    // 3 both (vdn_common.h: VDN_PLANE_ST_MODE, the default)
+    template <int MODE = VDN_PLANE_ST_MODE>
     static VDN_DEV void store_tile(unsigned short* base, long row, int ld, int tile, int h, const f32x16& v, bool ok) {
         if (!ok) return;
         unsigned short* p = base + (row >> 5) * (32L * ld) + tile * 1024 + h * 256 + (row & 31) * 8;
@@ -383,21 +392,13 @@ struct BF16 {
             o.y = pack_bf16x2(v[8 * k + 2], v[8 * k + 3]);
             o.z = pack_bf16x2(v[8 * k + 4], v[8 * k + 5]);
             o.w = pack_bf16x2(v[8 * k + 6], v[8 * k + 7]);
-#if VDN_PLANE_ST_MODE
-            // 1: write-through (sc1: the line is not kept in this XCD's L2 - saved planes and deltas are next read by other kernels,
-            // while the L2 is what feeds every MLP kernel's weight stream); 2: non-temporal; 3: both (vdn_common.h)
             typedef unsigned wt_u32x4 __attribute__((ext_vector_type(4)));
             const wt_u32x4 ov = {o.x, o.y, o.z, o.w};
-#if VDN_PLANE_ST_MODE == 1
-            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p + 512 * k), "v"(ov) : "memory");
-#elif VDN_PLANE_ST_MODE == 2
-            asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p + 512 * k), "v"(ov) : "memory");
-#else
-            asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p + 512 * k), "v"(ov) : "memory");
-#endif
-#else
-            *reinterpret_cast<uint4*>(p + 512 * k) = o;
-#endif
+            if constexpr (MODE == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p + 512 * k), "v"(ov) : "memory");
+            else if constexpr (MODE == 2) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p + 512 * k), "v"(ov) : "memory");
+            else if constexpr (MODE == 3) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p + 512 * k), "v"(ov) : "memory");
+            else if constexpr (MODE == 4) { asm volatile("" ::"v"(p + 512 * k), "v"(ov)); }      // (timing ablation: no store)
+            else *reinterpret_cast<uint4*>(p + 512 * k) = o;
         }
     }
     // a tile as loaded: 8 registers of packed bf16 (the chains keep these, not the 16 converted values, in flight across steps)

@@ -32,10 +32,7 @@ VDN_DEV void wait_vmcnt() {
 
 // LDS-DMA of 16 B per lane: scalar base (wave-uniform) + 32-bit per-lane offset; destination = wave-uniform LDS byte address
 // through M0 (used by nothing else in these kernels). See vdn_common.h: glds16 for why this is not the builtin.
-VDN_DEV void glds16_saddr(const char* base_uniform, unsigned lane_off, char* lds_wave_base) {
-    const unsigned lds = (unsigned)(size_t)lds_wave_base;
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" ::"v"(lane_off), "s"(lds), "s"(base_uniform) : "memory", "m0");
-}
+// Immediate-offset addressing, one M0 write per chunk: vdn_common.h (glds16_imm*).
 
 // A program: struct with
 //   static constexpr int total;                      chunks in the stream
@@ -57,19 +54,26 @@ struct Pipe {
     unsigned lane16;
     bf16x8 fr[kPre];    // opening fragments of the next chunk step (already read)
     f32x4 bias[4];      // its bias rows
+    unsigned voff0, m0_wave;        // this wave's range of a chunk (+ 4096: the centre of the pieces' immediate offsets): per-lane global offset, LDS address in slot 0
     VDN_DEV void init(const char* blob, char* smem) {
+        static_assert(kG <= 8 && (long)STRIDE * 256 < (1L << 31), "one group of immediate offsets; 32-bit chunk offsets");
         g = blob;
         lds = smem;
         wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         lane = threadIdx.x & 63;
         lane16 = lane * 16;
+        voff0 = lane16 + wave * (kG * 1024) + 4096;
+        m0_wave = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem + wave * (kG * 1024) + 4096);
     }
+    // (the dump area of the warm-up's LDS-DMA: this wave's own first piece of ring slot 0 - vdn_common.h)
+    VDN_DEV char* warm_dump() const { return lds + wave * (kG * 1024); }
     template <int C>
     VDN_DEV char* slot() const { return lds + (C % NSLOT) * STRIDE; }
     template <int C, int I>
     VDN_DEV void issue_piece() {
-        const int piece = wave + I * NWAVES;
-        glds16_saddr(g + ((long)C * STRIDE + piece * 1024), lane16, slot<C>() + piece * 1024);
+        const unsigned voff = voff0 + (unsigned)((long)C * STRIDE);
+        if constexpr (I == 0) glds16_imm_m0add<(C % NSLOT) * STRIDE, glds_imm(I)>(g, voff, m0_wave);
+        else glds16_imm<glds_imm(I)>(g, voff);
     }
     // ring start: chunks 0 .. DEPTH-1 in flight, chunk 0 certified, its opening fragments read. Call it behind every ordinary
     // load / store of the prologue (nothing but counted operations may be younger than a DMA): it drains them first.

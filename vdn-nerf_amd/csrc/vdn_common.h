@@ -79,6 +79,34 @@ VDN_DEV void glds16(const void* gsrc_lane, void* lds_wave_base) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc_lane), "s"(lds) : "memory", "m0");
 }
 
+// LDS-DMA of a weight chunk with IMMEDIATE offsets (round 5). A wave fetches G consecutive KiB of a chunk - pieces wave * G ..
+// + G - 1 - so that one wave-uniform scalar base, ONE per-lane offset register and ONE M0 value serve all of them: the
+// instruction's 13-bit signed immediate moves both addresses, global = base + lane offset + imm and LDS = M0 + 16 * lane + imm
+// (measured: tools/dev/hw_probe.hip), and piece I sits at imm = (I % 8) KiB - 4096 around `centre` = first byte of the wave's
+// range + 4096 (a wave with more than 8 pieces re-bases every 8). Per chunk and wave: one scalar write of M0 (+ its wait state);
+// per piece: the load alone. (Rounds 1 - 4 gave every piece its own 64-bit base and its own s_mov m0 + s_nop: 4 scalar
+// instructions per piece in kernels whose bound is the instruction issue of one or two waves per SIMD.) M0 is written by a
+// group's first piece and must survive until its last one: nothing else in these kernels writes M0 (the compiler has no use for
+// it here - no indirect register addressing, no LDS instruction that takes M0 on gfx9 - and tests/test_boundary_cpu.py checks the
+// disassembly of the shipped library for foreign writes).
+constexpr int glds_imm(int I) { return (I % 8) * 1024 - 4096; }
+constexpr int glds_group_off(int I) { return (I / 8) * 8192; }
+template <int IMM>
+VDN_DEV void glds16_imm(const char* base_uniform, unsigned voff) {
+    asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(voff), "s"(base_uniform), "n"(IMM) : "memory");
+}
+// ... the first piece of a group: M0 = m0v (wave-uniform LDS byte address of the group's centre)
+template <int IMM>
+VDN_DEV void glds16_imm_m0(const char* base_uniform, unsigned voff, unsigned m0v) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 offset:%3" ::"v"(voff), "s"(m0v), "s"(base_uniform), "n"(IMM) : "memory", "m0");
+}
+// ... with the LDS address formed in the same instruction: M0 = m0_wave + ADD (a compile-time slot / group offset)
+template <int ADD, int IMM>
+VDN_DEV void glds16_imm_m0add(const char* base_uniform, unsigned voff, unsigned m0_wave) {
+    asm volatile("s_add_u32 m0, %1, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 offset:%4" ::"v"(voff), "s"(m0_wave), "s"(base_uniform), "n"(ADD), "n"(IMM)
+                 : "memory", "m0", "scc");
+}
+
 // L2 warm-up of a kernel's weight stream. Inside a training step every MLP kernel starts on caches full of other kernels'
 // planes: each chunk of its weight stream is then an HBM miss for the first workgroup of each XCD that asks for it, and as the
 // workgroups of a launch walk the stream in lockstep, every one of its ~40-140 chunk steps waits that miss out (measured on the fused
@@ -147,11 +175,11 @@ VDN_DEV void warm_code_issue(int bytes, long n_wg, int resident, char* lds_dump)
 }
 // bytes of code each kernel warms from its warm-up site on. One line per kernel: `// symbol: <substring of the mangled name>` is a regular expression for the
 // mangled names the constant applies to (tests/test_boundary_cpu.py: constant + 4 KiB <= the smallest matching symbol's size)
-constexpr int kWarmCodeSdfFwd2Save = 124 * 1024;      // symbol: sdf_fwd2_kernelILi1ELb1E
-constexpr int kWarmCodeSdfFwd2 = 104 * 1024;          // symbol: sdf_fwd2_kernelILi1ELb0E
-constexpr int kWarmCodeSdfFwd2Mode0 = 48 * 1024;      // symbol: sdf_fwd2_kernelILi0E
-constexpr int kWarmCodeNerfFwd2 = 48 * 1024;          // symbol: nerf_fwd2_kernelILb.ELb1E
-constexpr int kWarmCodeNerfBwd = 80 * 1024;           // symbol: nerf_bwd_kernelINS_4BF16E
+constexpr int kWarmCodeSdfFwd2Save = 120 * 1024;      // symbol: sdf_fwd2_kernelILi1ELb1E
+constexpr int kWarmCodeSdfFwd2 = 102 * 1024;          // symbol: sdf_fwd2_kernelILi1ELb0E
+constexpr int kWarmCodeSdfFwd2Mode0 = 46 * 1024;      // symbol: sdf_fwd2_kernelILi0E
+constexpr int kWarmCodeNerfFwd2 = 46 * 1024;          // symbol: nerf_fwd2_kernelILb.ELb1E
+constexpr int kWarmCodeNerfBwd = 78 * 1024;           // symbol: nerf_bwd_kernelINS_4BF16E
 constexpr int kWarmCodeRenderFwd = 28 * 1024;         // symbol: rendernet_fwd_kernelINS_4BF16E
 constexpr int kWarmCodeRenderBwd = 36 * 1024;         // symbol: rendernet_bwd_kernelINS_4BF16E
 constexpr int kWarmCodeSdfBwdSplit = 20 * 1024;       // symbol: sdf_bwd_split_kernel

@@ -86,11 +86,7 @@ class TrainEngine:
         # bf16 SDF kernel runs one 128-point workgroup per CU: a work list of ~50 K rows is 1.5 rounds of workgroups, and the
         # half-empty round's CUs take the background network's workgroups (measured: 1.78 -> 1.65 ms per step).
         use_side = os.environ.get("VDN_SIDE_STREAM", "1") == "1" and torch.device(dev).type == "cuda"
-        if use_side and os.environ.get("VDN_SIDE_PRIORITY", "normal") == "low":
-            from vdn_hip import streams
-            self._side = streams.low_priority_stream(dev)
-        else:
-            self._side = torch.cuda.Stream(device=dev) if use_side else None
+        self._side = torch.cuda.Stream(device=dev) if use_side else None
         self._ev_fork = torch.cuda.Event() if use_side else None
         self._ev_join = torch.cuda.Event() if use_side else None
         # a second side stream for the VDN head's forward: it and the colour head read the same inputs and each fills only
@@ -200,14 +196,13 @@ class TrainEngine:
                 ent.append(dict(net="sdf", name=name, rmap=nm, cmap=km, scale=sc, A=AB(8), B=sl(w["H"], 7), bias=True, Pn=P))
                 continue
             A, A2 = AB(l), sl(w["V"], l)
-            # pipe = l: the layer-pipelined backward (csrc/train_sdf_pipe_bf16.hip) accumulates this entry itself
             if l == 0:
-                ent.append(dict(net="sdf", name=name, rmap=nm, cmap=km, scale=sc, A=A, B=whole(w["PE"]), A2=A2, B2=UB(0), bias=True, Pn=P, pipe=l))
+                ent.append(dict(net="sdf", name=name, rmap=nm, cmap=km, scale=sc, A=A, B=whole(w["PE"]), A2=A2, B2=UB(0), bias=True, Pn=P))
             elif l == 4:
-                ent.append(dict(net="sdf", name=name, rmap=nm, cmap=km[:224], scale=sc, A=A, B=sl(w["H"], 3), A2=A2, B2=UB(4), bias=True, Pn=P, pipe=l))
+                ent.append(dict(net="sdf", name=name, rmap=nm, cmap=km[:224], scale=sc, A=A, B=sl(w["H"], 3), A2=A2, B2=UB(4), bias=True, Pn=P))
                 ent.append(dict(net="sdf", name=name, rmap=nm, cmap=km[224:], scale=sc, A=A, B=whole(w["PE"]), A2=A2, B2=UB(4, 224), bias=False, Pn=P))
             else:
-                ent.append(dict(net="sdf", name=name, rmap=nm, cmap=km, scale=sc, A=A, B=sl(w["H"], l - 1), A2=A2, B2=UB(l), bias=True, Pn=P, pipe=l))
+                ent.append(dict(net="sdf", name=name, rmap=nm, cmap=km, scale=sc, A=A, B=sl(w["H"], l - 1), A2=A2, B2=UB(l), bias=True, Pn=P))
         # d W8[row 0, :] += colsum(ub_8) / scale   (u_8 = W8[0,:] / scale)
         ent.append(dict(net="sdf", name="lin8", rmap=images.ident_map(256), cmap=None, scale=1.0, A=UB(8), B=None, bias=False, Pn=P,
                         extra_row0=True))
@@ -362,13 +357,6 @@ class TrainEngine:
             fg[gname], mm[gname] = fin[lo:hi], ent[lo:hi]
         self.fin_groups = {k: (torch.from_numpy(v.view(np.uint8).copy()).to(dev), len(v), int(max(len(e["rmap"]) for e in mm[k])),
                                bool((v["accumulate"] != 0).any())) for k, v in fg.items() if len(v) and len(mm[k])}
-        # The layer-pipelined SDF backward (csrc/train_sdf_pipe_bf16.hip) is built and tested but OFF by default (VDN_SDF_PIPE=1
-        # turns it on): measured on MI355X it moves 18 % fewer bytes yet takes 743 us where rbar + fbar + the SDF group's GEMM
-        # take 524 us (steady-state lists, rocprofv3 trace), and as a persistent launch on every CU it also ends the overlap with
-        # the background network's backward.
-        self.pipe = None
-        if prec == "bf16" and os.environ.get("VDN_SDF_PIPE", "0") != "0":
-            self._build_sdf_pipe(ent[:n_sdf], dw[:n_sdf], fin[:n_sdf], vfin, ub_off)
         # weight-norm backward table
         rows, row_group = [], []
         for key, net in self.nets.items():          # "sdf" first (dict order of self.nets)
@@ -388,8 +376,6 @@ class TrainEngine:
             idx = [i for i, gk in enumerate(row_group) if k in gk]
             if idx:
                 self.wn_groups[k] = (torch.from_numpy(wn[idx].view(np.uint8).copy()).to(dev), len(idx), max(rows[i][1].shape[0] for i in idx))
-        if "sdf" in self.wn_groups:
-            self.wn_groups["sdf_pipe"] = self.wn_groups["sdf"]
         self._param_ptrs = self._ptr_key()
 
     @property
@@ -398,98 +384,6 @@ class TrainEngine:
         if getattr(self, "join_hook", None) is not None:     # the Trainer's deferred half of the backward (side stream)
             self.join_hook()
         return self._grad_flat
-
-    def _build_sdf_pipe(self, ent, dw, fin, vfin, ub_off):
-        """Tables of the layer-pipelined SDF backward (csrc/train_sdf_pipe_bf16.hip; include/vdn_render.h: VdnSdfPipeStage):
-        17 stages x `lanes` workgroups; the hidden layers' weight gradients leave the launch as 2 * lanes K splits per entry
-        (rbar part, fbar part) for vdn_dw_finalize. What stays with vdn_dw_gemm: layer 4's encoding columns, layer 8, and the
-        column sums behind the sdf row (launch group "sdf_pipe")."""
-        w, dev, P, Pp = self.w, self.dev, self.P, self.Pp
-        NL = int(os.environ.get("VDN_SDF_PIPE_LANES", "15"))
-        img = self.nets["sdf"].img
-        PS = Pp * 256
-        plane = lambda t, off_elems=0: t.data_ptr() + 2 * off_elems
-        ub = lambda l: plane(w["UB"], ub_off[l][0])
-        ab = lambda l: plane(w["AB"], 0) if l == 8 else plane(w["AB"], Pp * 288 + (7 - l) * PS)
-        H = lambda l: plane(w["H"], l * PS)
-        V = lambda l: plane(w["V"], l * PS)
-        EX = lambda l: plane(w["EX"], l * PS)
-        full, fbar = img.blobs["full"].data_ptr(), img.blobs["fbar"].data_ptr()
-        chunk_r = [0, 8, 16, 24, 31, 39, 47, 55]                     # first chunk of hidden layer l in the forward stream
-        chunk_f = {8: 0, 7: 8, 6: 16, 5: 24, 4: 32, 3: 41, 2: 49, 1: 57}   # first chunk of W_l^T in the 'fbar' stream
-        # slabs / column sums of the pipelined entries
-        pe = {e["pipe"]: i for i, e in enumerate(ent) if "pipe" in e}
-        dims = {l: (len(ent[i]["rmap"]), len(ent[i]["cmap"])) for l, i in pe.items()}
-        slab_off, cs_off, so, co = {}, {}, 0, 0
-        for l in range(8):
-            M, N = dims[l]
-            slab_off[l], cs_off[l] = so, co
-            so += 2 * NL * M * N
-            co += 2 * NL * M
-        self.pipe_slab = torch.empty(so, dtype=torch.float32, device=dev)
-        self.pipe_colsum = torch.zeros(co, dtype=torch.float32, device=dev)      # the rbar splits' rows stay zero
-        st = np.zeros(17, dtype=lib.struct_dtype("VdnSdfPipeStage"))
-        for l in range(8):                                # rbar stages
-            d = st[l]
-            M, N = dims[l]
-            d["kind"], d["nt"], d["chunk0"], d["blob"] = 0, M // 32, chunk_r[l], full
-            d["kt_lds"], d["kt_reg"] = (2, 0) if l == 0 else ((9, 2) if l == 4 else (8, 0))      # layer 4: [h part (7) | encoding part (2)]
-            d["n_dw"] = N // 32
-            d["in_stage"], d["ex_stage"], d["has_dw"], d["split"] = l - 1, -1, 1, 0
-            d["x_in"], d["in_ld"] = ub(l), ub_off[l][1]
-            d["x_out"], d["out_ld"], d["out_tile0"] = ub(l + 1), ub_off[l + 1][1], 0
-            d["reg_tile0"], d["reg_ld"] = -1, 0           # (ub_4's encoding tiles 7, 8 - also read by vdn_dw_gemm, entry cmap[224:] -
-            # and ub_0 come from the call's first launch)
-            d["S"], d["aux"], d["ex_out"], d["own"], d["own_ld"] = H(l), V(l), EX(l), V(l), 256
-            d["slab"], d["slab_m"], d["slab_n"] = self.pipe_slab.data_ptr() + 4 * slab_off[l], M, N
-        for f in range(8):                                # fbar stages W8^T .. W1^T
-            lw = 8 - f
-            d = st[8 + f]
-            d["kind"], d["chunk0"], d["blob"] = 1, chunk_f[lw], fbar
-            d["kt_lds"] = 7 if lw == 3 else (9 if lw == 8 else 8)       # W8^T: [g_feat (8) | sdf adjoint (1)]
-            d["nt"] = 7 if lw == 4 else 8
-            d["kt_reg"], d["kt_extra"] = (2, 1) if lw == 8 else (0, 0)
-            d["in_stage"], d["ex_stage"] = (-1, 7) if lw == 8 else (8 + f - 1, -1)
-            d["x_in"], d["in_ld"] = (w["d_featvec"].data_ptr(), 256) if lw == 8 else (ab(lw), 256)
-            d["x_out"], d["out_ld"], d["out_tile0"] = ab(lw - 1), 256, 0
-            d["reg_tile0"], d["reg_ld"] = -1, 0
-            if lw == 8:                                   # AB(8) = [g_feat | g_sdf / scale]: layer 8 stays with vdn_dw_gemm
-                d["reg_out"], d["reg_tile0"], d["reg_ld"], d["copy_in"] = ab(8), 8, 288, 1
-            d["S"], d["aux"], d["own"], d["own_ld"] = H(lw - 1), EX(lw - 1), H(lw - 1), 256
-            if lw <= 7:
-                M, N = dims[lw]
-                d["has_dw"], d["split"] = 1, NL
-                d["slab"], d["slab_m"], d["slab_n"] = self.pipe_slab.data_ptr() + 4 * slab_off[lw], M, N
-                d["colsum"] = self.pipe_colsum.data_ptr() + 4 * cs_off[lw]
-                d["n_dw"] = M // 32
-                assert M == 32 * d["kt_lds"] and N == 32 * d["nt"]
-        d = st[16]                                        # layer 0: d W0 += ab_0 PE^T, d b0 += ab_0
-        M, N = dims[0]
-        d["kind"], d["kt_lds"], d["nt"], d["in_stage"], d["ex_stage"], d["has_dw"], d["split"], d["n_dw"] = 2, 8, 2, 15, -1, 1, NL, 8
-        d["x_in"], d["in_ld"], d["own"], d["own_ld"] = ab(0), 256, w["PE"].data_ptr(), 64
-        d["reg_tile0"] = -1
-        d["slab"], d["slab_m"], d["slab_n"] = self.pipe_slab.data_ptr() + 4 * slab_off[0], M, N
-        d["colsum"] = self.pipe_colsum.data_ptr() + 4 * cs_off[0]
-        assert (M, N) == (256, 64)
-        stages = torch.from_numpy(st.view(np.uint8).copy()).to(dev)
-        sync = torch.zeros(2 + 17 * NL + 2 + 16 * 17 * NL, dtype=torch.int32, device=dev)      # (+ room for a diagnostic build's stamps)
-        # residual GEMM entries (renumbered workgroups) and the group's finalize table
-        res = [i for i, e in enumerate(ent) if "pipe" not in e]
-        dres = dw[res].copy()
-        wg = 0
-        for k, i in enumerate(res):
-            dres[k]["wg_begin"] = wg
-            wg += lib.call_value("vdn_dw_entry_wgs" + self.sfx, int(dw[i]["m_tiles"]), int(dw[i]["n_tiles"]), int(dw[i]["splits"]))
-        self.dw_groups["sdf_pipe"] = (torch.from_numpy(dres.view(np.uint8).copy()).to(dev), len(res), wg)
-        fp = fin.copy()
-        for l, i in pe.items():
-            fp[i]["slab"] = self.pipe_slab.data_ptr() + 4 * slab_off[l]
-            fp[i]["colsum"] = self.pipe_colsum.data_ptr() + 4 * cs_off[l] if fp[i]["colsum"] else 0
-            fp[i]["splits"] = 2 * NL
-        fp = np.concatenate([fp, vfin])
-        self.fin_groups["sdf_pipe"] = (torch.from_numpy(fp.view(np.uint8).copy()).to(dev), len(fp), int(max(len(e["rmap"]) for e in ent)),
-                                       bool((fp["accumulate"] != 0).any()))
-        self.pipe = dict(stages=stages, sync=sync, lanes=NL, n_stages=17, ub0=ub(0), ub4=ub(4), ab8=ab(8))
 
     def _ptr_key(self):
         return tuple(p.data_ptr() for net in self.nets.values() for p in net.module.parameters())
@@ -600,20 +494,10 @@ class TrainEngine:
                 w["bg_active"][1].fill_(self.Q)           # the dW GEMM's device-side row count
             # the NeRF++ background is independent of the SDF / colour path until compositing: it may run on a side stream
             # (81 920 background points = 1.25 rounds of the CUs; the tail round could overlap the SDF kernels)
-            # VDN_SDF_FIRST=1 (A/B): submit the fused SDF kernel - the critical path: colour head, compositor, loss follow it -
-            # BEFORE the background network's launch, which has slack until the compositor (the fork event is still taken in
-            # front of both): the SDF kernel's first round then gets the whole chip and the background network fills in behind it
-            sdf_first = self._side is not None and os.environ.get("VDN_SDF_FIRST", "0") == "1"
-            if sdf_first:
-                self._ev_fork.record(torch.cuda.current_stream())
-                self._sdf_forward(rays_o, rays_d)
-                self._side.wait_event(self._ev_fork)
-            else:
-                self._fork()
+            self._fork()
             lib.call("vdn_nerf_mlp_fwd" + self.sfx, n, self._side_handle(st))
             self._side_done()
-            if not sdf_first:
-                self._sdf_forward(rays_o, rays_d)
+            self._sdf_forward(rays_o, rays_d)
         else:
             self._sdf_forward(rays_o, rays_d)
         if after_sdf is not None:       # (the data-parallel Trainer reduces the eikonal sums over the ranks from here on)
@@ -916,7 +800,6 @@ class TrainEngine:
             lib.call("vdn_alpha_composite_bwd", c, st)
         if g_gradients is not None:              # `gradients` is the SDF normal itself: its adjoint joins the alpha / eikonal parts
             w["d_normals"].add_(g_gradients.reshape(self.P, 3))
-        nerf_late = False
         if r.n_outside > 0:                      # NeRF backward on the side stream, beside the heads' and the SDF backward
             nb = lib.VdnNerfBwdArgs()
             nb.blob = self.nets["nerf"].img.blobs["bwd"].data_ptr()
@@ -933,18 +816,12 @@ class TrainEngine:
                 w["d_bg_dirs"].zero_()
                 nb.rays_o, nb.rays_d, nb.z, nb.n_per_ray = rays_o.data_ptr(), rays_d.data_ptr(), w["bg_mid"].data_ptr(), self.T
                 nb.d_pts, nb.d_dirs = w["d_bg_pts"].data_ptr(), w["d_bg_dirs"].data_ptr()
-            # VDN_BWD_MAIN_FIRST=1 (A/B): the background network's backward is submitted behind the colour head's backward instead
-            # of in front of it (see nerf_late below)
-            nerf_late = self._side is not None and os.environ.get("VDN_BWD_MAIN_FIRST", "0") == "1"
-            if nerf_late:
-                self._ev_fork.record(torch.cuda.current_stream())
+            if fork_event is not None and self._side is not None:
+                self._side.wait_event(fork_event)
             else:
-                if fork_event is not None and self._side is not None:
-                    self._side.wait_event(fork_event)
-                else:
-                    self._fork()
-                lib.call("vdn_nerf_mlp_bwd" + self.sfx, nb, self._side_handle(st))
-                self._side_done()
+                self._fork()
+            lib.call("vdn_nerf_mlp_bwd" + self.sfx, nb, self._side_handle(st))
+            self._side_done()
 
         def rnet_bwd(net, g_out, out, save_h, dout, dh, d_out, module, accumulate):
             b = lib.VdnRenderNetBwdArgs()
@@ -966,30 +843,9 @@ class TrainEngine:
         # (accumulate flag covers both d_feat and d_normals; d_normals must always accumulate)
         if self.wdepth:
             rnet_bwd("vdn", w["d_vdn"], w["vdn_out"], w["vdn_h"], w["vdn_dout"], w["vdn_dh"], 96, r.depth_network, True)
-        if r.n_outside > 0 and nerf_late:
-            self._side.wait_event(self._ev_fork)
-            lib.call("vdn_nerf_mlp_bwd" + self.sfx, nb, self._side.cuda_stream)
-            self._side_done()
         if defer_rest and self._side is not None and heads_event:
             self._ev_heads.record(torch.cuda.current_stream())      # the heads' deltas (operands of the rest group) are complete
 
-        use_pipe = self.pipe is not None and not rg and os.environ.get("VDN_SDF_PIPE", "0") != "0"
-        if use_pipe:
-            # rbar chain, fbar chain and the hidden layers' weight gradients in one layer-pipelined launch
-            pa = lib.VdnSdfPipeArgs()
-            pa.stages, pa.n_stages, pa.lanes, pa.sync = self.pipe["stages"].data_ptr(), self.pipe["n_stages"], self.pipe["lanes"], self.pipe["sync"].data_ptr()
-            pa.rays_o, pa.rays_d, pa.z, pa.n_per_ray, pa.z_ld = rays_o.data_ptr(), rays_d.data_ptr(), w["mid_z"].data_ptr(), self.N, self.N
-            pa.P, pa.scale = self.P, float(r.sdf_network.scale)
-            pa.g_normals, pa.g_sdf = w["d_normals"].data_ptr(), w["d_sdf"].data_ptr()
-            pa.ub0, pa.ub4, pa.ab8 = self.pipe["ub0"], self.pipe["ub4"], self.pipe["ab8"]
-            lib.call("vdn_sdf_bwd_pipe_bf16", self._fg(pa), st)
-            if defer_rest:
-                self.weight_grads("sdf_pipe", st, gemm_event)
-                return self._grad_flat
-            self._join()
-            self.weight_grads("sdf_pipe", st)
-            self.weight_grads("rest", st)
-            return self._grad_flat
         rb = lib.VdnSdfRbarArgs()
         img = self.nets["sdf"].img
         rb.blob = img.blobs["full"].data_ptr()

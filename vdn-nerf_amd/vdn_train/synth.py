@@ -226,7 +226,7 @@ def pixel_rays(c2w, px, py, focal=FOCAL):
     return o.astype(np.float32).copy(), d.astype(np.float32).copy()
 
 
-def random_pixel_batch(seed, step, img_idx, batch, rank=0, cams=None, crop=None):
+def random_pixel_batch(seed, step, img_idx, batch, rank=0, cams=None, crop=None, focal=FOCAL):
     """512 pixels uniform over one image (poses.py:193-194), keyed by (seed, step, rank). `crop` = side of a centred
     square window to draw from (object-centric captures: the object fills most of the frame)."""
     cams = make_cameras(seed) if cams is None else cams
@@ -237,7 +237,7 @@ def random_pixel_batch(seed, step, img_idx, batch, rank=0, cams=None, crop=None)
     else:
         px = np.floor(uniform(seed, tag + "/x", (batch,)) * crop) + (W_IMG - crop) // 2
         py = np.floor(uniform(seed, tag + "/y", (batch,)) * crop) + (H - crop) // 2
-    return pixel_rays(cams[img_idx], px, py)
+    return pixel_rays(cams[img_idx], px, py, focal=focal)
 
 
 def near_far_from_sphere(rays_o, rays_d):

@@ -107,9 +107,6 @@ class Trainer:
         self._ev_ws, self._ws_pending = torch.cuda.Event(), False      # the side stream's last reader of the forward's workspaces
         self._rest_pending, self._rest_gen, self._joined = False, 0, {}
         self._jitter, self._jitter_next = None, 0
-        self._main = None
-        if self.overlap and self.engine._side is not None and os.environ.get("VDN_MAIN_PRIORITY", "0") == "1":
-            self._main = torch.cuda.Stream(device=self.dev, priority=-1)
         self.engine.join_hook = self.join
         # the networks this Trainer updates on its side stream wait for that update whenever their weight images are used
         # (dpt_models/fields.py::_HipNet._images): rendering with the renderer right after train_step needs no explicit join().
@@ -147,28 +144,9 @@ class Trainer:
         return 1.0 / (math.exp(-10 * (self.depth_iter / total_iter - 0.5)) + 1.0)
 
     # ---- one iteration of dpt_runner.py:197-259
-    def train_step(self, *args, **kwargs):
-        """One iteration (dpt_runner.py:197-259) -> device tensor [loss, color_loss, psnr, eikonal, depth_loss, mask_loss].
-        Arguments: rays_o, rays_d, near, far, true_rgb, gt_feats=None, mask=None, t_rand=None, t_rand_out=None, z_vals_inject=None.
-
-        VDN_MAIN_PRIORITY=1 (off by default) issues the step's critical chain (sampler -> SDF forward / backward -> SDF update) on a
-        HIGH-PRIORITY stream of the Trainer's own, ordered behind the caller's stream at entry and in front of it at exit: when a
-        CU frees up, the dispatcher then prefers the chain's workgroups to those of the side stream's kernels, which have slack
-        (-15 .. -40 us per step over 6 x 400 steps, -2.5 % on the object-centric scene). Off by default because streams share a
-        few hardware queues: in a process that had created several Trainers, the fourth one's priority stream landed on its side
-        stream's queue and the two halves of the step ran one after the other (1.82 ms instead of 1.57)."""
-        main = self._main
-        caller = torch.cuda.current_stream()
-        if main is None or caller == main:
-            return self._train_step(*args, **kwargs)
-        main.wait_stream(caller)
-        with torch.cuda.stream(main):
-            out = self._train_step(*args, **kwargs)
-        caller.wait_stream(main)
-        return out
-
-    def _train_step(self, rays_o, rays_d, near, far, true_rgb, gt_feats=None, mask=None, t_rand=None, t_rand_out=None,
-                    z_vals_inject=None):
+    def train_step(self, rays_o, rays_d, near, far, true_rgb, gt_feats=None, mask=None, t_rand=None, t_rand_out=None,
+                   z_vals_inject=None):
+        """One iteration (dpt_runner.py:197-259) -> device tensor [loss, color_loss, psnr, eikonal, depth_loss, mask_loss]."""
         r, eng, st = self.r, self.engine, _stream()
         B = self.B
         # the kernels take raw pointers: packed float32 rows on this device, exactly B of them. The reference's flow slices
@@ -209,7 +187,7 @@ class Trainer:
         if not late_join:
             self.join()
         elif self._ws_pending:
-            torch.cuda.current_stream().wait_event(self._ev_ws)
+            torch.cuda.current_stream().wait_event(self._ev_ws)       # (same-box A/B against the unordered arm: + 5 us per step)
             self._ws_pending = False
         depth_on = self.conf["extract_depth"] and self.iter_step > self.conf["depth_start_iter"] and gt_feats is not None
         # Plain configuration (one rank, no mask, no mask loss, no VDN head): compositor, colour-term gradient and the compositor's
