@@ -571,6 +571,117 @@ def pnf_fixture():
     return fx
 
 
+def runner_fixture():
+    """The reference RUNNER's own image loops - Runner.val_img with gen_depth_for_finetune=True (dpt_runner.py:417-491: batched render of
+    one camera, L1 / PSNR against the image, the weight-argmax depth written as depth_from_sdf/sdf_<name>.npy and as the
+    weight_max PNG) and Runner.validate_image (520-587: colour and normal images as written by cv.imwrite) - run by the reference
+    itself on CPU. dpt_runner.py is loaded by file path with its absent third-party imports stubbed (cv2: imread hands back the
+    injected arrays, imwrite records what it is given, resize is the identity at resolution level 1 and raises otherwise; trimesh,
+    pyhocon, tensorboard, icecream: empty), `dpt_models.*` bound to the reference's own modules; the Runner object is made
+    without its constructor (which parses a conf file and builds a dataset from disk) and given exactly the attributes the two
+    methods read. torch.rand inside render() pops injected jitter (one pair per batch)."""
+    import importlib.util
+    import tempfile
+    from types import SimpleNamespace
+    from vdn_train import synth
+    fx = {}
+    store, written = {}, {}
+    cv = types.ModuleType("cv2")
+    cv.imread = lambda name, flag=None: store[name].copy()
+
+    def resize(img, size, *a, **k):
+        if (img.shape[1], img.shape[0]) != tuple(size):
+            raise NotImplementedError("cv.resize stub: resolution level 1 only")
+        return img.reshape(img.shape[0], img.shape[1]) if (img.ndim == 3 and img.shape[2] == 1) else img       # cv drops a single channel
+    cv.resize = resize
+    cv.imwrite = lambda path, arr: written.__setitem__(path, np.array(arr)) or True
+    stubs = {"cv2": cv, "trimesh": types.ModuleType("trimesh"), "pyhocon": types.ModuleType("pyhocon"),
+             "torch.utils.tensorboard": types.ModuleType("torch.utils.tensorboard")}
+    stubs["pyhocon"].ConfigFactory = object
+    stubs["torch.utils.tensorboard"].SummaryWriter = object
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "dpt_models" or k.startswith("dpt_models.") or k in stubs}
+    sys.modules.update(stubs)
+    sys.modules.setdefault("mcubes", types.ModuleType("mcubes"))
+    ic = types.ModuleType("icecream")
+    ic.ic = lambda *a, **k: None
+    sys.modules.setdefault("icecream", ic)
+    pkg = types.ModuleType("dpt_models")
+    pkg.__path__ = [os.path.join(REFERENCE, "dpt_models")]
+    sys.modules["dpt_models"] = pkg
+    orig_cuda = torch.Tensor.cuda
+    try:
+        mods = {}
+        for name in ("embedder", "lie_group_helper", "fields", "renderer", "dataset", "poses"):
+            path = os.path.join(REFERENCE, "dpt_models", name + ".py")
+            spec = importlib.util.spec_from_file_location("dpt_models." + name, path)
+            mod = importlib.util.module_from_spec(spec)
+            sys.modules["dpt_models." + name] = mod
+            spec.loader.exec_module(mod)
+            assert os.path.realpath(mod.__file__).startswith(REFERENCE + os.sep), mod.__file__
+            mods[name] = mod
+        spec = importlib.util.spec_from_file_location("ref_dpt_runner", os.path.join(REFERENCE, "dpt_runner.py"))
+        rn = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(rn)
+        assert os.path.realpath(rn.__file__).startswith(REFERENCE + os.sep)
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        torch.set_default_dtype(torch.float32)
+        seed, n, H, W, BS = 13, 2, 10, 12, 50
+        states = synth.make_all_states(seed, wdepth=False, variance=0.45)
+        rend = build_reference(mods["fields"], mods["renderer"], states, False, torch.float32)
+        rng = np.random.RandomState(seed)
+        cams = synth.make_cameras(seed, n=n).astype(np.float32)
+        K = np.eye(4, dtype=np.float32)
+        K[:3, :3] = np.linalg.inv(synth.intrinsics_inv(focal=1.39 * W, h=H, w=W)).astype(np.float32)
+        bgra = rng.randint(0, 256, (n, H, W, 4)).astype(np.uint8)
+        bgra[..., 3] = (rng.rand(n, H, W) > 0.25) * 255
+        tmp = tempfile.mkdtemp(prefix="vdn_runner_fx_")
+        imgs = []
+        for i in range(n):
+            imgs.append("%s/%03d.png" % (tmp, i))
+            store[imgs[-1]] = bgra[i]
+        gen = mods["poses"].RaysGenerator(imgs, None, None, torch.tensor(cams), torch.tensor(np.stack([K] * n)), learnable=False, with_depth=False)
+        runner = object.__new__(rn.Runner)
+        runner.rays_generator, runner.renderer = gen, rend
+        runner.dataset = SimpleNamespace(near_far_from_sphere=lambda o, d: mods["dataset"].Dataset.near_far_from_sphere(None, o, d),
+                                         data_dir=tmp, img_dir="image", pose_all=torch.tensor(cams), n_images=n)
+        runner.batch_size, runner.use_mask, runner.use_white_bkgd, runner.depth_before_color = BS, False, True, False
+        runner.base_exp_dir, runner.iter_step, runner.anneal_end, runner.rgb_dims, runner.validate_resolution_level = tmp, 20000, 50000.0, 3, 1
+        idx = 1
+        n_batches = (H * W + BS - 1) // BS
+        sizes = [min(BS, H * W - b * BS) for b in range(n_batches)]
+        jit = [synth.jitter(seed, 100 + b, sizes[b]) for b in range(n_batches)]
+        tt = lambda x: torch.tensor(x, dtype=torch.float32)
+        queue = lambda: [t for a, b in jit for t in (tt(a), tt(b))]
+        with RandQueue(queue()):
+            closs, psnr, eik, _, _ = rn.Runner.val_img(runner, idx, resolution_level=1, gen_depth_for_finetune=True)
+        depth_file = os.path.join(tmp, "image", "depth_from_sdf", "sdf_%03d.npy" % idx)
+        fx["val_img/weight_depth"] = np.load(depth_file)
+        (wm_path, wm), = [(k, v) for k, v in written.items() if "weight_max" in k]
+        fx["val_img/weight_max_png"], fx["val_img/weight_max_name"] = wm, os.path.relpath(wm_path, tmp)
+        fx["val_img/color_fine_loss"], fx["val_img/psnr"] = float(closs), float(psnr)
+        fx["val_img/gradient_error"] = np.stack([np.asarray(e) for e in eik])
+        written.clear()
+        with RandQueue(queue()):
+            rn.Runner.validate_image(runner, idx, resolution_level=1)
+        for k, v in written.items():
+            sub = os.path.relpath(k, tmp).split(os.sep)[0]
+            fx["validate_image/%s" % sub], fx["validate_image/%s_name" % sub] = v, os.path.relpath(k, tmp)
+        assert {"validate_image/validations_fine", "validate_image/normals"} <= set(fx)
+        for k, v in (("seed", seed), ("variance", 0.45), ("idx", idx), ("H", H), ("W", W), ("batch_size", BS), ("iter_step", 20000), ("anneal_end", 50000.0),
+                     ("bgra", bgra), ("pose_all", cams), ("intrinsic", K), ("images", gen.images.numpy()), ("masks", gen.masks.numpy())):
+            fx[k] = v
+        for b, (a, c) in enumerate(jit):
+            fx["jitter/%d/t_rand" % b], fx["jitter/%d/t_rand_out" % b] = a, c
+        print("[runner] val_img: L1 %.5f PSNR %.3f; weight_depth %s; files %s" % (closs, psnr, fx["val_img/weight_depth"].shape,
+              [fx[k] for k in fx if k.endswith("_name")]))
+    finally:
+        torch.Tensor.cuda = orig_cuda
+        for k in [k for k in sys.modules if k == "dpt_models" or k.startswith("dpt_models.") or k in stubs]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+    return fx
+
+
 CASES = [
     # name, seed, B, wdepth, variance, cos_anneal, perturb, kwargs
     ("white_v03_c0", 1, 24, False, 0.3, 0.0, 1.0, {}),
@@ -614,6 +725,8 @@ def generate(only=None):
         out["rays"] = rays_fixture()
     if want("pnf_rays"):
         out["pnf_rays"] = pnf_fixture()
+    if want("runner"):
+        out["runner"] = runner_fixture()
     return out
 
 

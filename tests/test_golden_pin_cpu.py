@@ -34,7 +34,7 @@ def test_committed_fixtures_are_the_references_outputs():
     # `stages` holds every per-stage vector (PE, SDF 257-vector, normals, heads, NeRF, sample_pdf rows, lattice);
     # one render case covers the end-to-end dict, one variant fixture the string / bool keys (`color_mode`, `weight_norm`)
     # that once broke the comparer. The full set takes minutes: `make_golden.py --check-only`.
-    r = subprocess.run([sys.executable, GEN, "--check-only", "--only", "stages,black_v03,raygrad,white_nonormal_plain,rays,pnf_rays"],
+    r = subprocess.run([sys.executable, GEN, "--check-only", "--only", "stages,black_v03,raygrad,white_nonormal_plain,rays,pnf_rays,runner"],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     assert "all bit-identical" in r.stdout

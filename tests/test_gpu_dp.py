@@ -247,8 +247,12 @@ def test_two_ranks_keep_identical_parameters_over_overlapped_steps(fused):
         sc = tr.train_step(g(cat[0]), g(cat[1]), g(cat[2]), g(cat[3]), g(cat[4]), gt_feats=feats, t_rand=g(cat[5]), t_rand_out=g(cat[6])).cpu().numpy()
         # [loss, colour, psnr, eikonal, depth, mask]: the eikonal term is global on every rank; colour / depth are per-rank means
         r0, r1 = got[0][1][it], got[1][1][it]
-        assert abs(r0[3] - sc[3]) < 1e-3 * abs(sc[3]) and abs(r1[3] - sc[3]) < 1e-3 * abs(sc[3]), (it, r0[3], sc[3])
-        assert abs(0.5 * (r0[1] + r1[1]) - sc[1]) < 1e-3 * abs(sc[1]), (it, r0[1], r1[1], sc[1])
+        print("step %d  eikonal dp %.6f / %.6f single %.6f   colour dp %.6f single %.6f" % (it, r0[3], r1[3], sc[3], 0.5 * (r0[1] + r1[1]), sc[1]))
+        assert r0[3] == r1[3]                                              # the reported eikonal term is the GLOBAL one on every rank
+        # step 0 starts from identical parameters: summation order only; later steps follow parameters that differ in their last bits
+        tol = 1e-4 if it == 0 else 2e-2
+        assert abs(r0[3] - sc[3]) < tol * abs(sc[3]), (it, r0[3], sc[3])
+        assert abs(0.5 * (r0[1] + r1[1]) - sc[1]) < tol * abs(sc[1]), (it, r0[1], r1[1], sc[1])
         assert (sc[4] > 0) == (it > 2) and (r0[4] > 0) == (it > 2)         # the depth term enters at the 4th step, on every rank alike
     ref = tr.param_flat.cpu().numpy()
     dp = got[0][2]

@@ -16,7 +16,8 @@ wdepth = len(sys.argv) > 4 and sys.argv[4] == "wdepth"
 crop = int(sys.argv[5]) if len(sys.argv) > 5 and sys.argv[5] != "-" else None
 prec = sys.argv[6] if len(sys.argv) > 6 else "bf16"
 args = argparse.Namespace(batch=512)
-leg = bench.Leg(args, torch.device("cuda:0"), 1, 0, prec, wdepth, 64, crop=crop)
+rc = bench.real_cameras() if os.environ.get("VDN_REAL_CAMS", "0") == "1" else None      # (the rig of a scene the reference ships: bench.py real_cameras)
+leg = bench.Leg(args, torch.device("cuda:0"), 1, 0, prec, wdepth, 64, crop=crop, cams=None if rc is None else rc[0], focal=None if rc is None else rc[1])
 for i in range(700 if prec == "bf16" else 120):
     leg.step(i)
 torch.cuda.synchronize()

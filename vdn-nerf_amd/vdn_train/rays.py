@@ -83,6 +83,16 @@ class RaysGenerator:
                                                   align_corners=False, antialias=False)[0].permute(1, 2, 0)
         return (img.cpu().numpy() * 255).clip(0, 255)
 
+    def mask_at(self, idx, resolution_level=1):
+        """poses.py:258-261: mask `idx` at 1/resolution_level size, [H/l, W/l, 1] (cv.resize drops the single channel of the alpha mask,
+        the reference puts it back)."""
+        msk = self.masks[int(idx)][..., :1]
+        l = int(resolution_level)
+        if l != 1:
+            msk = torch.nn.functional.interpolate(msk.permute(2, 0, 1)[None], size=(self.H // l, self.W // l), mode="bilinear",
+                                                  align_corners=False, antialias=False)[0].permute(1, 2, 0)
+        return msk.cpu().numpy()
+
     def gen_rays_between(self, ratio, idx_0, idx_1, resolution_level=1):
         """poses.py:214-252: rays of a camera interpolated between two views - translation linearly, rotation by Slerp, both
         on the world-to-camera side as the reference does - with the first camera's intrinsics. -> rays_o, rays_v [H/l, W/l, 3].

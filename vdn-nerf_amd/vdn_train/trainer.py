@@ -247,7 +247,8 @@ class Trainer:
             self.depth_iter += 1
         if fused:
             if self._log_stream is None:
-                self._log_stream = torch.cuda.Stream(device=self.dev)
+                from vdn_hip.train import shared_stream
+                self._log_stream = shared_stream(self.dev, "log")
             ls = self._log_stream
             self._ev_comp.record(torch.cuda.current_stream())
             ls.wait_event(self._ev_comp)

@@ -9,27 +9,30 @@ import numpy as np
 import torch
 
 
-def _render_batches(renderer, rays_gen, rays_o, rays_d, batch_size, **kw):
+def _render_batches(renderer, rays_gen, rays_o, rays_d, batch_size, jitter=None, **kw):
     """render() over the rays of one image in batches -> yields (first ray, n rays, outputs). With VDN_RENDER_GRAPH=1 the
     full batches replay one captured plan (dpt_models.renderer.RenderPlan: a fifth of the host time per batch, ~3% more device
     time) and only the ragged last batch is a plain call. The outputs of a replay are overwritten by the next one: consume
-    them before advancing."""
+    them before advancing. jitter: optional list of (t_rand [n,1], t_rand_out [n,O]) per batch, injected in place of the two
+    torch.rand draws of render() (renderer.py:348,355) - how the parity tests reproduce the reference's runs."""
     n = rays_o.shape[0]
     plan = None
-    if os.environ.get("VDN_RENDER_GRAPH", "0") == "1" and n >= 2 * batch_size:
+    if os.environ.get("VDN_RENDER_GRAPH", "0") == "1" and n >= 2 * batch_size and jitter is None:
         plan = renderer.plan(batch_size, **kw)
-    for s in range(0, n, batch_size):
+    for b, s in enumerate(range(0, n, batch_size)):
         o, d = rays_o[s:s + batch_size], rays_d[s:s + batch_size]
         near, far = rays_gen.near_far_from_sphere(o, d)
         if plan is not None and o.shape[0] == batch_size:
             yield s, batch_size, plan(o, d, near, far)
+        elif jitter is not None:
+            yield s, o.shape[0], renderer.render(o, d, near, far, t_rand=jitter[b][0], t_rand_out=jitter[b][1], **kw)
         else:
             yield s, o.shape[0], renderer.render(o, d, near, far, **kw)
 
 
 @torch.no_grad()
 def render_image(renderer, rays_gen, idx, resolution_level=1, batch_size=512, cos_anneal_ratio=1.0, white_bkgd=True,
-                 gen_depth_for_finetune=False):
+                 gen_depth_for_finetune=False, jitter=None):
     """-> dict(img_fine [H,W,3] float32 in [0,1], gradient_error [n_batches], weight_depth [H,W,1] | None)."""
     rays_o, rays_d = rays_gen.gen_rays_at(idx, resolution_level=resolution_level)
     H, W, _ = rays_o.shape
@@ -39,7 +42,7 @@ def render_image(renderer, rays_gen, idx, resolution_level=1, batch_size=512, co
     rgb = torch.empty(H * W, 3, device=dev)
     depth = torch.empty(H * W, 1, device=dev) if gen_depth_for_finetune else None
     eik = []
-    for s, n, out in _render_batches(renderer, rays_gen, rays_o, rays_d, batch_size, cos_anneal_ratio=cos_anneal_ratio, background_rgb=bg):
+    for s, n, out in _render_batches(renderer, rays_gen, rays_o, rays_d, batch_size, jitter=jitter, cos_anneal_ratio=cos_anneal_ratio, background_rgb=bg):
         rgb[s:s + n] = out["color_fine"]
         eik.append(out["gradient_error"].clone())
         if gen_depth_for_finetune:                                   # dpt_runner.py:449-455
@@ -53,7 +56,7 @@ def render_image(renderer, rays_gen, idx, resolution_level=1, batch_size=512, co
 
 @torch.no_grad()
 def validate_image(renderer, rays_gen, idx, resolution_level=1, batch_size=512, cos_anneal_ratio=1.0, white_bkgd=True,
-                   depth_before_color=False, out_dir=None, iter_step=0):
+                   depth_before_color=False, out_dir=None, iter_step=0, jitter=None):
     """Runner.validate_image (dpt_runner.py:520-587): the colour image and the normal image of one camera.
     -> (img_fine [H,W,3] in 0..255, normal_img [H,W,3] in 0..255): normals = sum_i gradients_i * weights_i * inside_sphere_i
     per ray (553-557), rotated into the camera frame by inv(pose[:3,:3]) and mapped by * 128 + 128 (570-573). With `out_dir`
@@ -68,7 +71,7 @@ def validate_image(renderer, rays_gen, idx, resolution_level=1, batch_size=512, 
     rgb = torch.empty(H * W, 3, device=dev)
     nrm = torch.empty(H * W, 3, device=dev)
     n_in = renderer.n_samples + renderer.n_importance
-    for s, n, out in _render_batches(renderer, rays_gen, rays_o, rays_d, batch_size, cos_anneal_ratio=cos_anneal_ratio,
+    for s, n, out in _render_batches(renderer, rays_gen, rays_o, rays_d, batch_size, jitter=jitter, cos_anneal_ratio=cos_anneal_ratio,
                                      background_rgb=bg, depth_before_color=depth_before_color):
         rgb[s:s + n] = out["color_fine"]
         nrm[s:s + n] = (out["gradients"] * out["weights"][:, :n_in, None] * out["inside_sphere"][..., None]).sum(dim=1)
@@ -115,28 +118,31 @@ def image_metrics(img_fine, gt, mask=None):
     return float(l1), float(psnr)
 
 
+def weight_max_image(weight_depth):
+    """The runner's picture of the weight-argmax depths (dpt_runner.py:463-468): stretched between their 50th and 95th percentile."""
+    lb, ub = np.percentile(weight_depth, [50, 95])
+    return ((weight_depth - lb) / (ub - lb) * 255).clip(0, 255)
+
+
 def val_img(renderer, scene, rays_gen, idx, resolution_level=1, batch_size=512, cos_anneal_ratio=1.0, white_bkgd=True,
-            use_mask=False, gen_depth_for_finetune=False):
-    """Runner.val_img for a vdn_train.dataset.SceneData: -> (color_loss, psnr, gradient_error, img_fine); with
-    gen_depth_for_finetune also writes depth_from_sdf/sdf_<name>.npy under the scene directory."""
-    res = render_image(renderer, rays_gen, idx, resolution_level, batch_size, cos_anneal_ratio, white_bkgd, gen_depth_for_finetune)
-    step = resolution_level
-    H, W = res["img_fine"].shape[:2]
-    gt = _resize(scene.images[idx], H, W, step)
-    mask = _resize(scene.masks[idx], H, W, step)[..., :1] if use_mask else None
+            use_mask=False, gen_depth_for_finetune=False, jitter=None, out_dir=None, iter_step=0):
+    """Runner.val_img (dpt_runner.py:417-491) for a vdn_train.dataset.SceneData (or None: nothing is written into a scene
+    directory then): -> (color_loss, psnr, gradient_error, img_fine). The ground truth is the generator's `image_at` / `mask_at`
+    (poses.py:254-262: cv.resize of the loaded image) as in the reference; with gen_depth_for_finetune the weight-argmax depths
+    go to depth_from_sdf/sdf_<name>.npy under the scene directory (449-453) and, with `out_dir`, their picture to
+    weight_max/weight_max_<iter>_<idx>.png (463-468)."""
+    res = render_image(renderer, rays_gen, idx, resolution_level, batch_size, cos_anneal_ratio, white_bkgd, gen_depth_for_finetune, jitter=jitter)
+    gt = rays_gen.image_at(idx, resolution_level=resolution_level) / 255.0
+    mask = rays_gen.mask_at(idx, resolution_level=resolution_level) if use_mask else None
     l1, psnr = image_metrics(res["img_fine"], gt, mask)
     if gen_depth_for_finetune:
-        path = scene.depth_from_sdf_path(idx)
-        os.makedirs(os.path.dirname(path), exist_ok=True)
-        np.save(path, res["weight_depth"])
+        if scene is not None:
+            path = scene.depth_from_sdf_path(idx)
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            np.save(path, res["weight_depth"])
+        if out_dir is not None:
+            from PIL import Image
+            os.makedirs(os.path.join(out_dir, "weight_max"), exist_ok=True)
+            Image.fromarray(np.rint(weight_max_image(res["weight_depth"])[..., 0]).astype(np.uint8)).save(
+                os.path.join(out_dir, "weight_max", "weight_max_{}_{}.png".format(iter_step, idx)))
     return l1, psnr, res["gradient_error"], res["img_fine"]
-
-
-def _resize(img, H, W, level):
-    """Ground truth at the rendered resolution. The rendered pixel (i, j) looks through full-resolution pixel
-    (linspace(0, H-1, H//l)[i], linspace(0, W-1, W//l)[j]) (poses.py:173-175), so sample the image there (bilinear)."""
-    if level == 1:
-        return img
-    t = torch.from_numpy(np.ascontiguousarray(img)).permute(2, 0, 1)[None]
-    out = torch.nn.functional.interpolate(t, size=(H, W), mode="bilinear", align_corners=True)
-    return out[0].permute(1, 2, 0).numpy()
