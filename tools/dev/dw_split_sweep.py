@@ -10,14 +10,18 @@ import torch
 import bench
 args = argparse.Namespace(batch=512)
 dev = torch.device("cuda:0")
-settings = [(4096, 4096), (6144, 4096), (8192, 4096), (3072, 4096), (4096, 6144), (4096, 8192), (4096, 3072), (6144, 6144), (8192, 8192)]
+# (sdf, background network, heads): the three launches of the default schedule
+settings = [(6144, 4096, 4096), (6144, 4608, 4096), (6144, 5120, 4096), (6144, 5504, 4096), (6144, 4608, 2048), (6144, 4608, 2752), (6144, 4608, 1600),
+            (6144, 4608, 6144), (6144, 4096, 2048), (5632, 4608, 4096), (6656, 4608, 4096)]
 legs = {}
-for sdf, rest in settings:
-    os.environ["VDN_DW_SPLIT_PTS_SDF"], os.environ["VDN_DW_SPLIT_PTS_REST"] = str(sdf), str(rest)
+for sdf, nerf, heads in settings:
+    os.environ["VDN_DW_SPLIT_PTS_SDF"], os.environ["VDN_DW_SPLIT_PTS_NERF"], os.environ["VDN_DW_SPLIT_PTS_HEADS"] = str(sdf), str(nerf), str(heads)
+    rest = (sdf, nerf, heads)
+    sdf = rest[0]
     leg = bench.Leg(args, dev, 1, 0, "bf16", False, 48)
     for i in range(650):
         leg.step(i)
-    legs[(sdf, rest)] = leg
+    legs[rest] = leg
 torch.cuda.synchronize()
 K, R = 30, 5
 res = {k: [] for k in legs}
@@ -31,5 +35,5 @@ for r in range(R):
         res[k].append((time.time() - t0) / K * 1e6)
 for k in legs:
     eng = legs[k].trainer.engine
-    print("sdf %5d rest %5d : wall %.1f us/step (min %.1f)  WGs sdf %d rest %d" % (k[0], k[1], float(np.median(res[k])), min(res[k]),
-          eng.dw_groups["sdf"][2], eng.dw_groups["rest"][2]))
+    print("sdf %5d nerf %5d heads %5d : wall %.1f us/step (min %.1f)  WGs sdf %d nerf %d heads %d" % (k[0], k[1], k[2], float(np.median(res[k])), min(res[k]),
+          eng.dw_groups["sdf"][2], eng.dw_groups["nerf"][2], eng.dw_groups["heads"][2]))

@@ -1,15 +1,15 @@
 """profiles/<round>_* from what tools/profile_round.sh left under gpurun_out/ (dev; run from the repo root):
 python tools/dev/make_profiles.py r03"""
 import json, os, shutil, subprocess, sys
-R = sys.argv[1] if len(sys.argv) > 1 else "r04"
+R = sys.argv[1] if len(sys.argv) > 1 else "r05"
 G, P = "gpurun_out", "profiles"
 line = open("%s/%s_bench_train_bf16.json" % (G, R)).read().strip().splitlines()[-1]
 json.loads(line)
 open("%s/%s_bench_train_bf16.json" % (P, R), "w").write(line + "\n")
-for f in ("train_bf16_kernel_stats_whole_run.csv", "step_timeline_two_streams.txt"):
+for f in ("train_bf16_kernel_stats_whole_run.csv", "step_timeline_two_streams.txt", "forward_kernel_stats.csv"):
     if os.path.exists("%s/%s_%s" % (G, R, f)):          # (the two steady-state tables are copied by hand: their headers are edited)
         shutil.copy("%s/%s_%s" % (G, R, f), "%s/%s_%s" % (P, R, f))
-summ = {t: json.load(open("%s/%s_%s/summary.json" % (G, R, t))) for t in ("sdf1", "sdf1t", "step")}
+summ = {t: json.load(open("%s/%s_%s/summary.json" % (G, R, t))) for t in ("sdf1", "sdf1t", "step", "fwd")}
 
 def pick(d, key):
     ks = [k for k in d if key in k]
@@ -17,7 +17,7 @@ def pick(d, key):
     k = max(ks, key=lambda n: d[n].get("kernel_trace_us", {}).get("mean", 0) * d[n].get("kernel_trace_us", {}).get("n", 0))
     return k, d[k]
 for tag, src, key in (("counters_sdf_fwd_sdf1", "sdf1", "sdf_fwd2_kernel<1, false"), ("counters_sdf_fwd_sdf1t", "sdf1t", "sdf_fwd2_kernel<1, true"),
-                      ("counters_dw_gemm", "step", "dw_gemm_bf16")):
+                      ("counters_dw_gemm", "step", "dw_gemm_bf16"), ("counters_shade_fused", "fwd", "sdf_fwd2_kernel<2,")):
     k, v = pick(summ[src], key)
     json.dump({k: v}, open("%s/%s_%s.json" % (P, R, tag), "w"), indent=1)
 json.dump(summ["step"], open("%s/%s_counters_step.json" % (P, R), "w"), indent=1)
@@ -38,4 +38,7 @@ traffic("step", "dw_gemm_bf16", "weight-gradient GEMM in the bench step, all lau
         "whose two launches (SDF entries + the rest) are 2 x the mean per dispatch; the default schedule issues the rest as two launches "
         "(background network, heads) with the same bytes. The run includes the first ~600 steps' larger work lists (the steady state's lists "
         "are ~15 % smaller).", "traffic_dw_gemm_bf16", launches=2)
+traffic("fwd", "sdf_fwd2_kernel<2,", "the one-launch shading kernel (vdn_shade_fused_bf16: PE -> SDF MLP -> gradient sweep -> colour head -> NeuS alpha / compositing) "
+        "on the 65 536 inside samples of a 512-ray full-frame batch, inside a loop of render() calls (tools/dev/render_loop.py 60 512 0).", "traffic_shade_fused_bf16")
+json.dump(summ["fwd"], open("%s/%s_counters_forward.json" % (P, R), "w"), indent=1)
 print("profiles/%s_* written" % R)

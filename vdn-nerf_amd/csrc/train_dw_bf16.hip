@@ -27,7 +27,10 @@ namespace vdn {
 
 constexpr int kDwTileBytes = 2048;                 // 32 points x 32 features
 constexpr int kDwStageBytes = 16 * kDwTileBytes;   // 8 A tiles, then 8 B tiles
-constexpr int kDwBuf = 4;                          // stages in the ring (3 in flight while one is multiplied)
+#ifndef VDN_DW_BUF
+#define VDN_DW_BUF 4
+#endif
+constexpr int kDwBuf = VDN_DW_BUF;                 // stages in the ring (3 in flight while one is multiplied; 5 = all 160 KiB of LDS: A/B arm)
 constexpr int kDwWaves = 8;
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));

@@ -32,7 +32,9 @@ def _pts_per_split(net, precision="bf16"):
         return int(os.environ.get("VDN_DW_SPLIT_PTS_SDF" if net == "sdf" else "VDN_DW_SPLIT_PTS_REST", dflt))
     if net == "sdf":
         return int(os.environ.get("VDN_DW_SPLIT_PTS_SDF", os.environ.get("VDN_DW_SPLIT_PTS", "6144")))
-    return int(os.environ.get("VDN_DW_SPLIT_PTS_REST", str(PTS_PER_SPLIT)))
+    # the rest group runs as two launches on the default schedule: the background network's entries and the heads'
+    rest = os.environ.get("VDN_DW_SPLIT_PTS_REST", str(PTS_PER_SPLIT))
+    return int(os.environ.get("VDN_DW_SPLIT_PTS_NERF" if net == "nerf" else "VDN_DW_SPLIT_PTS_HEADS", rest))
 
 
 def _stream():
