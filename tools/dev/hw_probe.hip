@@ -1,6 +1,7 @@
 // Hardware facts the kernels' design leans on, measured rather than assumed (development probe; build: hipcc --offload-arch=gfx950 -O3
 // -o tools/dev/_build/hw_probe tools/dev/hw_probe.hip):
 //  1. global_load_lds_dwordx4 with an immediate offset: which LDS bytes and which global bytes does `offset:N` move?
+//  3. issue cycles of v_exp_f32 / v_log_f32 / v_rcp_f32 / v_add_f32 in one wave's stream (one wave per SIMD), alone and between MFMAs.
 //  2. HBM bandwidth of pure stores (plain / nt / sc1 nt), pure loads and a copy over 1 GiB: what a kernel that only writes planes can reach.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -50,6 +51,48 @@ __global__ void copy_kernel(const u32x4* a, u32x4* b, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) b[i] = a[i];
 }
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+// KIND 0: v_add_f32, 1: v_exp_f32, 2: v_log_f32, 3: v_rcp_f32 - 16 independent registers, 16 instructions per block. WITH_MFMA: one dependent
+// v_mfma_f32_32x32x16_bf16 in front of every NPER instructions (the fused SDF kernel's pattern: an accumulate chain with VALU work in its gaps)
+template <int KIND, bool WITH_MFMA, int NPER>
+__global__ __launch_bounds__(256, 1) void issue_kernel(float* out, unsigned long long* cyc, int iters) {
+    float r[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r[i] = 1.0f + 0.001f * (threadIdx.x + i);
+    f32x16 acc = {0};
+    bf16x8 a = {0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00}, b = a;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if constexpr (WITH_MFMA) {
+                if (i % NPER == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+            }
+            if constexpr (KIND == 0) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(r[i]));
+            else if constexpr (KIND == 1) asm volatile("v_exp_f32 %0, %0" : "+v"(r[i]));
+            else if constexpr (KIND == 2) asm volatile("v_log_f32 %0, %0" : "+v"(r[i]));
+            else asm volatile("v_rcp_f32 %0, %0" : "+v"(r[i]));
+        }
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    float sum = acc[0];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sum += r[i];
+    out[blockIdx.x * 256 + threadIdx.x] = sum;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = c1 - c0;
+}
+template <int KIND, bool WITH_MFMA, int NPER>
+double issue_cycles(float* out, unsigned long long* cyc) {
+    const int iters = 2000;
+    hipLaunchKernelGGL((issue_kernel<KIND, WITH_MFMA, NPER>), dim3(256), dim3(256), 0, 0, out, cyc, iters);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> c(256);
+    hipMemcpy(c.data(), cyc, 256 * 8, hipMemcpyDeviceToHost);
+    std::sort(c.begin(), c.end());
+    return (double)c[128] / iters / 16.0;          // shader cycles per VALU instruction (incl. its share of the MFMAs)
+}
+
 template <class F>
 double time_us(F&& f, int reps = 7) {
     hipEvent_t e0, e1;
@@ -83,6 +126,19 @@ int main() {
     }
     printf("  (offset:1024 with M0 = 4096, lane off 0: LDS byte 4096 + 1024 = 5120 if the offset applies to the LDS address too; global byte 1024)\n");
     printf("  (offset:-2048 with M0 = 12288, lane off 8192: LDS byte 10240 if it applies; global byte 6144)\n");
+    // ---- 3. issue cycles (s_memtime counts at 100 MHz on some parts: the ratios are what matters; the MFMA-only row calibrates)
+    {
+        float* o; unsigned long long* cy;
+        hipMalloc(&o, 256 * 256 * 4); hipMalloc(&cy, 256 * 8);
+        const char* nm[4] = {"v_add_f32", "v_exp_f32", "v_log_f32", "v_rcp_f32"};
+        double alone[4] = {issue_cycles<0, false, 1>(o, cy), issue_cycles<1, false, 1>(o, cy), issue_cycles<2, false, 1>(o, cy), issue_cycles<3, false, 1>(o, cy)};
+        double m1[4] = {issue_cycles<0, true, 1>(o, cy), issue_cycles<1, true, 1>(o, cy), issue_cycles<2, true, 1>(o, cy), issue_cycles<3, true, 1>(o, cy)};
+        double m4[4] = {issue_cycles<0, true, 4>(o, cy), issue_cycles<1, true, 4>(o, cy), issue_cycles<2, true, 4>(o, cy), issue_cycles<3, true, 4>(o, cy)};
+        printf("issue probe (one wave per SIMD; s_memtime ticks per VALU instruction):\n");
+        for (int k = 0; k < 4; ++k)
+            printf("  %-10s alone %6.2f | one dependent MFMA 32x32x16 per instruction %6.2f | one MFMA per 4 instructions %6.2f (per MFMA gap: %6.2f)\n",
+                   nm[k], alone[k], m1[k], m4[k], 4 * m4[k]);
+    }
     // ---- 2. bandwidth
     const long bytes = 1L << 30, n = bytes / 16;
     u32x4 *a, *b;
