@@ -241,7 +241,9 @@ class Leg:
         return {"kernel_ms": float(t.mean() * 1e3), "kernel_ms_median": float(np.median(t) * 1e3), "kernel_ms_min": float(t.min() * 1e3),
                 "kernel_ms_max": float(t.max() * 1e3), "points": float(rows.mean()), "points_min": float(rows.min()),
                 "points_max": float(rows.max()), "steps": n_steps, "workgroups_mean": float(np.ceil(rows / 128.0).mean()),
-                "flops": float((F_SDF + F_GRAD) * rows.mean())}
+                # (bf16 default: the colour head rides in the same launch - csrc/k_sdf_fwd2.h MODE 3 - and is counted with it)
+                "color_head_in_the_launch": bool(getattr(eng, "_color_fused", False)),
+                "flops": float((F_SDF + F_GRAD + (F_COL if getattr(eng, "_color_fused", False) else 0)) * rows.mean())}
 
     def fence(self):
         torch.cuda.synchronize()
@@ -359,9 +361,13 @@ class Leg:
         if tr_train is not None:
             tr_train *= situ["points"] / float(eng.P)      # PMC figure is for a 65 536-point launch; bytes scale with the rows
         F1 = F_SDF + F_GRAD
+        fused_col = bool(getattr(eng, "_color_fused", False))
+        F1t = F1 + (F_COL if fused_col else 0)          # the training launch: + the colour head where it rides in it
         pk = PEAK[dtype]
         fl_inf = F1 * eng.P
-        name = ("sdf_fwd_kernel<F32,1,4,false>" if dtype == "f32" else "sdf2::sdf_fwd2_kernel<1,true,4,3> (csrc/k_sdf_fwd2.h)")
+        name = ("sdf_fwd_kernel<F32,1,4,false>" if dtype == "f32" else
+                ("sdf2::sdf_fwd2_kernel<3,true,4,3> (csrc/k_sdf_fwd2.h MODE 3: + the colour head, %d FLOP/row)" % F1t if fused_col else
+                 "sdf2::sdf_fwd2_kernel<1,true,4,3> (csrc/k_sdf_fwd2.h)"))
         c2f = (F1 + F_COL + (F_VDN if self.wdepth else 0)) * eng.P
         return {"bound": "mfma",
                 "kernel": name + ": fused PE + SDF MLP + gradient sweep, training-mode launch of the timed step over its foreground "
@@ -374,14 +380,15 @@ class Leg:
                 "in_step_two_streams": dict(situ_two, frac=situ_two["flops"] / (situ_two["kernel_ms"] * 1e-3) / pk),
                 "isolated": {"what": "the step's launch repeated 4 x back to back on an idle chip, mean over %d steps' lists (rounds 1-3 quoted "
                                      "this as roofline.frac)" % n_lists,
-                             "kernel_ms": tk * 1e3, "points": rows_mean, "frac": F1 * rows_mean / tk / pk, "per_list": per_list},
+                             "kernel_ms": tk * 1e3, "points": rows_mean, "frac": F1t * rows_mean / tk / pk, "per_list": per_list},
                 "inference_launch": {"kernel_ms": tk_inf["median"] * 1e3, "kernel_ms_min": tk_inf["min"] * 1e3, "kernel_ms_max": tk_inf["max"] * 1e3,
                                      "points": eng.P, "achieved": fl_inf / tk_inf["median"] / 1e12,
                                      "frac": fl_inf / tk_inf["median"] / pk, "traffic": tr_inf, "traffic_source": src_inf,
                                      "what": "median of 20 isolated launches"},
                 "training_launch_full_rows": {"kernel_ms": tk_full["median"] * 1e3, "kernel_ms_min": tk_full["min"] * 1e3,
                                               "kernel_ms_max": tk_full["max"] * 1e3, "points": eng.P,
-                                              "achieved": fl_inf / tk_full["median"] / 1e12, "frac": fl_inf / tk_full["median"] / pk,
+                                              "achieved": F1t * eng.P / tk_full["median"] / 1e12, "frac": F1t * eng.P / tk_full["median"] / pk,
+                                              "flop_per_row": F1t,
                                               "traffic": tr_full, "what": "median of 20 isolated launches"},
                 "c2_forward": {"what": "SURVEY.md 8d C2: PE + SDF MLP + gradient sweep + colour%s head + NeuS alpha / compositing on %d points, "
                                        "as render() launches them (%d launch%s), median of 20"

@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VDN_ABI_VERSION 24
+#define VDN_ABI_VERSION 25
 
 int vdn_abi_version(void);
 
@@ -301,6 +301,16 @@ int vdn_feat_composite(const VdnCompositeArgs* args_host, void* stream);
  * network's "c2" stream; comp: as for vdn_alpha_composite_fwd with comp.N = 128 - comp.sdf / normals / color are not read and
  * comp.feat_out must be NULL (the feature channels keep their own launches). Outputs equal the three launches' up to the rounding
  * of the colour head's first layer (the normal's z component enters as an f32 term here, as a bf16 operand there). */
+/* The training step's forward of the SDF network and of the colour head in ONE launch (bf16; csrc/k_sdf_fwd2.h MODE 3):
+ * vdn_sdf_mlp_fwd_bf16(mode 1) with its training saves (sdf_host->H, V, PE, feat: as there) followed, on the feature vector kept in
+ * registers, by vdn_rendernet_fwd_bf16 of the colour network (fields.py:148-176, mode 'idr', d_out = 3) with ITS saves: col_h
+ * [4, rows, 256] hidden activations, col_small [rows, 64] the 33 small inputs, col_out [P,3] the colour - the planes
+ * VdnRenderNetArgs.save_h / save_small / out name, in the same layouts (compact rows of sdf_host's work list; col_out by dense
+ * point id). color_blob: the colour network's "c2" chunk stream (vdn_hip/images.py). The colour differs from the two launches'
+ * by <= 4e-6 (the normal's z component enters the first colour layer in f32 instead of bf16). Declines (-10, nothing launched)
+ * ray-gradient saves (U_pe) and the tail split (tail_max_rows). */
+int vdn_sdf_color_train_bf16(const VdnSdfArgs* sdf_host, const void* color_blob, int32_t squeeze_out, void* col_h, void* col_small,
+                             float* col_out, void* stream);
 int vdn_shade_fused_bf16(const VdnSdfArgs* sdf_host, const void* color_blob, int32_t squeeze_out, const VdnCompositeArgs* comp_host,
                          int32_t* ticket, void* stream);
 

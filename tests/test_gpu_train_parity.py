@@ -166,3 +166,64 @@ def test_loss_gradients_inside_the_compositor_launches_with_the_vdn_head(monkeyp
     assert torch.equal(trs[0].exp_avg, trs[1].exp_avg) and torch.equal(trs[0].exp_avg_sq, trs[1].exp_avg_sq)
     assert trs[0]._depth_adam_steps == trs[1]._depth_adam_steps > 0
     assert torch.isfinite(trs[0].param_flat).all()
+
+
+@pytest.mark.parametrize("wdepth", [False, True], ids=["womsk_white", "womsk_white_wdepth"])
+def test_colour_head_inside_the_training_forward_launch(monkeypatch, wdepth):
+    """vdn_sdf_color_train_bf16 (csrc/k_sdf_fwd2.h MODE 3: the SDF network's training forward and the colour head in ONE launch, the
+    feature vector in registers) against vdn_sdf_mlp_fwd_bf16 + vdn_rendernet_fwd_bf16 (VDN_TRAIN_COLOR_FUSED=0). The SDF side is the
+    same instruction stream: sdf, normals, the feature plane and the H / V / PE saves bit for bit. The colour head's first layer takes
+    the normal's z component in f32 instead of bf16 (the 33rd small input as a rank-1 term): colours within 2e-4, its saved
+    activations within a bf16 step or two, its small-input plane bit for bit - and a training run stays together
+    (losses 1e-4 over 8 steps; with the VDN head the depth-feature term switches on at step 4)."""
+    import torch
+    from vdn_train import synth, factory
+    from vdn_train.trainer import Trainer
+    dev = torch.device("cuda:0")
+    B, seed = 512, 7
+    cams = synth.make_cameras(seed)
+    gg = lambda x: torch.tensor(x).to(dev)
+    conf = dict(warm_up_end=10, end_iter=300, anneal_end=40)
+    if wdepth:
+        conf.update(extract_depth=True, depth_start_iter=3)
+    feats = gg(synth.uniform(seed, "cf/feats", (B, 96)).astype("float32")) if wdepth else None
+    trs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("VDN_TRAIN_COLOR_FUSED", fused)
+        torch.manual_seed(0)
+        trs.append(Trainer(factory.build_renderer(wdepth=wdepth, device=dev, precision="bf16"), B, dev, conf=conf))
+    for it in range(8):
+        o, d = synth.random_pixel_batch(seed, it, it % 40, B, cams=cams)
+        near, far = synth.near_far_from_sphere(o, d)
+        t1, t2 = synth.jitter(seed, it, B)
+        args = [gg(o), gg(d), gg(near), gg(far), gg(synth.target_colors(o, d, 0.5))]
+        sc = []
+        for fused, tr in zip(("1", "0"), trs):
+            monkeypatch.setenv("VDN_TRAIN_COLOR_FUSED", fused)
+            sc.append(tr.train_step(*args, gt_feats=feats, t_rand=gg(t1), t_rand_out=gg(t2)).clone())
+            assert bool(tr.engine._color_fused) == (fused == "1")
+        if it == 0:
+            # same parameters: compare what the two forwards left in the workspaces
+            wa, wb = trs[0].engine.w, trs[1].engine.w
+            torch.cuda.synchronize()
+            n = int(wa["fg_active"][1].item())
+            assert n == int(wb["fg_active"][1].item()) and 0 < n <= trs[0].engine.P
+            rows = n // 32 * 32                 # (whole 32-row blocks of the list: the planes are tile-blocked, the rows behind the list undefined)
+            for k in ("sdf", "normals"):
+                assert torch.equal(wa[k], wb[k]), k
+            for k in ("feat", "PE", "col_small"):
+                assert torch.equal(wa[k][:rows], wb[k][:rows]), k
+            for k in ("H", "V"):
+                assert torch.equal(wa[k][:, :rows], wb[k][:, :rows]), k
+            idx = wa["fg_active"][0][:n].long()
+            dc = (wa["col_out"][idx] - wb["col_out"][idx]).abs().max().item()
+            assert dc < 2e-4, dc
+            ha, hb = wa["col_h"][:, :rows].float(), wb["col_h"][:, :rows].float()
+            diff = (ha - hb).abs()
+            # (every pre-activation of the first layer moves by the rounding of one input: a tenth of the activations land on the
+            # neighbouring bf16 value, and the layers behind inherit it)
+            assert (diff > 0).float().mean().item() < 0.3 and (diff <= 0.02 * hb.abs() + 2e-3).all()
+        a, b = sc[0].cpu().numpy(), sc[1].cpu().numpy()
+        assert abs(a[0] - b[0]) < 1e-4 * abs(b[0]) + 1e-6, (it, a.tolist(), b.tolist())
+    pa, pb = trs[0].param_flat, trs[1].param_flat
+    assert torch.isfinite(pa).all() and (pa - pb).norm().item() < 1e-3 * pb.norm().item()

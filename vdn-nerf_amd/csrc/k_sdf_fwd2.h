@@ -97,12 +97,13 @@ constexpr int tile_stores(int c) {
     if (c < 0 || c >= PG::total) return 0;
     const LayerDesc d = PG::layer(PG::layer_of(c));
     const int t = PG::tile_of(c);
-    constexpr bool TS = SAVE && MODE == 1;       // the training saves (MODE 2: SAVE = the feature plane is written, for the VDN head)
+    constexpr bool TS = SAVE && (MODE == 1 || MODE == 3);       // the training saves (MODE 2: SAVE = the feature plane is written, for the VDN head)
     switch (d.kind) {      // (two 16-byte stores per plane tile: BF16::kTileOps)
         case HID: return TS ? 2 : 0;                                             // H plane tile
-        case LAST: return t < 8 ? (MODE == 1 ? (SAVE ? 4 : 2) : (MODE == 2 && SAVE ? 2 : 0)) : 0;   // feature tile (+ V[7] tile)
+        case LAST: return t < 8 ? ((MODE == 1 || MODE == 3) ? (SAVE ? 4 : 2) : (MODE == 2 && SAVE ? 2 : 0)) : 0;   // feature tile (+ V[7] tile)
         case SWEEP: return TS ? 2 : 0;                                           // V[l]
         case SWEEP_SKIP: return (TS && t < 7) ? 2 : 0;
+        case COL0: case COLH: return MODE == 3 ? 2 : 0;                          // MODE 3: the colour head's saved activations
         default: return 0;
     }
 }
@@ -363,6 +364,9 @@ constexpr int pair_begin(int gi, int GA) { return gi >= GA ? 8 : gi * 8 / GA; }
 // UPS (MODE 0, ray form with 64 samples per ray): the first up-sampling round (renderer.py:147-191 on the coarse samples)
 // behind the pass - a 128-point workgroup is two rays, whose z / sdf rows go through LDS to upsample_row (k_ray_rows.h),
 // vdn_upsample_round's work without its launch.
+// MODE 3 (round 5, the training step's forward: fields.py:72-108 + 148-176 in one launch): MODE 1 with the training saves AND the colour
+// head on the feature vector kept in registers, its hidden activations / small inputs / output saved for the backward (the planes
+// rendernet_fwd_kernel writes); no compositing (the step's rows are a compacted work list: a workgroup is not a ray).
 // MODE 2 (the north-star kernel of the inference path, reference renderer.py:239-315 in one launch): MODE 1 with the feature
 // vector kept in registers, then the colour head on the same 32 points per wave, then - a 128-point workgroup being exactly one
 // ray of 128 samples - the ray's NeuS alpha, background blend, transmittance scan and weighted sums (k_composite_row.h) by wave 0
@@ -372,6 +376,9 @@ struct ShadeExtra {
     int* ticket;                // [1] arrival counter, zero before the first launch (the last ray leaves it zero)
     int squeeze_out;            // fields.py:170-171
     int warm_bytes, warm_bytes2;    // all modes: bytes of the weight stream(s) the first round of workgroups pulls into L2 up front (0 = off; vdn_common.h: warm_l2)
+    void* col_h;                // MODE 3: [4, rows, 256] the colour head's saved hidden activations (PT32 planes, compact rows)
+    void* col_small;            // MODE 3: [rows, 64] its 33 small inputs (points, PE4(view), normal) as the weight-gradient GEMM reads them
+    float* col_out;             // MODE 3: [P,3] the sampled colour (dense point id)
     CompositeArgs cm;           // sdf / normals / color are not read (the samples come through LDS)
 };
 
@@ -379,8 +386,10 @@ template <int MODE, bool SAVE, int NSLOT, int DEPTH, int VID = 0, bool UPS = fal
 __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kernel(SdfArgs a, UpsampleArgs up, ShadeExtra ex) {
     static_assert(!UPS || MODE == 0, "the up-sampling round follows the sdf-only pass");
     using PG = Prog<MODE>;
-    constexpr bool TS = SAVE && MODE == 1;          // training saves (H, V, PE planes)
-    constexpr bool FEAT = MODE == 1 || (MODE == 2 && SAVE);     // the feature plane goes to HBM
+    static_assert(MODE != 3 || SAVE, "MODE 3 is the training forward");
+    constexpr bool TS = SAVE && (MODE == 1 || MODE == 3);          // training saves (H, V, PE planes)
+    constexpr bool FEAT = MODE == 1 || MODE == 3 || (MODE == 2 && SAVE);     // the feature plane goes to HBM
+    constexpr bool COL = MODE >= 2;                 // the colour head follows the sweep
     using P = BF16;
     using ST = unsigned short;
     static_assert(NSLOT >= DEPTH + 1, "ring: the chunk being read, the one being opened and DEPTH-1 in flight");
@@ -389,7 +398,7 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
     constexpr int kLdsTotal = MODE >= 1 ? 160 * 1024 : kRing + kW8;
     constexpr int NLDS = MODE >= 1 ? ((kLdsTotal - kRing - kW8) / (kWaves * 1024) < kSTiles ? (kLdsTotal - kRing - kW8) / (kWaves * 1024) : kSTiles) : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    Pipe<NSLOT, MODE == 2 ? PG::sdf_total : (1 << 30)> pp;
+    Pipe<NSLOT, MODE >= 2 ? PG::sdf_total : (1 << 30)> pp;
     pp.g = a.blob;
     pp.g2 = ex.color_blob;
     pp.lds = smem;
@@ -429,7 +438,7 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
         sdf_idx = r * a.sdf_ld + sidx;
 #pragma unroll
         for (int d = 0; d < 3; ++d) xin[d] = (a.rays_o[r * 3 + d] + a.rays_d[r * 3 + d] * z) * a.scale;
-        if constexpr (MODE == 2) {
+        if constexpr (COL) {
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
                 dir[d] = a.rays_d[r * 3 + d];
@@ -448,9 +457,9 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     char* const wdump = smem + pp.wave * (VDN_SDF2_DMA_IMM ? kG * 1024 : 1024);       // (this wave's own first DMA piece of ring slot 0: vdn_common.h)
     warm_l2_issue(a.blob, ex.warm_bytes, wr.n_wg, MODE == 0 ? 512 : 256, wdump);
-    warm_l2_issue(MODE == 2 ? ex.color_blob : nullptr, MODE == 2 ? ex.warm_bytes2 : 0, wr.n_wg, 256, wdump);
+    warm_l2_issue(COL ? ex.color_blob : nullptr, COL ? ex.warm_bytes2 : 0, wr.n_wg, 256, wdump);
     // (and the kernel's own code: vdn_common.h; MODE 2 is the inference launch and is never cold)
-    constexpr int kCode = MODE == 0 ? kWarmCodeSdfFwd2Mode0 : (MODE == 1 ? (SAVE ? kWarmCodeSdfFwd2Save : kWarmCodeSdfFwd2) : 0);
+    constexpr int kCode = MODE == 0 ? kWarmCodeSdfFwd2Mode0 : (MODE == 1 ? (SAVE ? kWarmCodeSdfFwd2Save : kWarmCodeSdfFwd2) : (MODE == 3 ? kWarmCodeSdfFwd3 : 0));
     warm_code_issue(ex.warm_bytes > 0 ? kCode : 0, wr.n_wg, MODE == 0 ? 512 : 256, wdump);
 
     typename P::template Act<9> X, Y;
@@ -584,7 +593,7 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
                                 o[2] = pack_bf16x2(acc_prev[4 * q], acc_prev[4 * q + 1]);
                                 o[3] = pack_bf16x2(acc_prev[4 * q + 2], acc_prev[4 * q + 3]);
                                 if constexpr (FEAT) plane_store16(feat + prow + T * 1024 + 512 * (q >> 1), o);
-                                if constexpr (MODE == 2) F.r[T * 2 + (q >> 1)] = __builtin_bit_cast(bf16x8, o);      // (the piece IS the B fragment)
+                                if constexpr (COL) F.r[T * 2 + (q >> 1)] = __builtin_bit_cast(bf16x8, o);      // (the piece IS the B fragment)
                             }
                             const f32x4 w = *(reinterpret_cast<const f32x4*>(pp.template slot<CP + 1>() + kTail) + (8 * T + 2 * q + h));
                             if constexpr (q == 0) sq_v7 = SS.template get<PG::s_tile0(7) + T>();
@@ -663,6 +672,8 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
                     u32x4 cur = __builtin_bit_cast(u32x4, D.r[T * 2 + (pr >> 2)]);
                     cur[pr & 3] = pk;
                     D.r[T * 2 + (pr >> 2)] = __builtin_bit_cast(bf16x8, cur);
+                    if constexpr (MODE == 3 && (pr & 3) == 3)          // the saved plane piece k = pr >> 2 = this k-step's whole B fragment (as the H planes)
+                        plane_store16(reinterpret_cast<ST*>(ex.col_h) + L.l * PS + prow + T * 1024 + 512 * (pr >> 2), cur);
                 });
             } else if constexpr (L.kind == COLOUT) {
                 // rows 0..2 of the output tile = registers 0..2 of the h = 0 lanes (fields.py:166-171)
@@ -718,7 +729,7 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
             acc_prev = acc_cur;
             if constexpr (sweep_tile) sq_prev = sq_next;
             if constexpr ((L.kind == SWEEP_SKIP && T == 8) || (L.kind == SWEEP_PE && T == 1)) pe_backward(L.kind == SWEEP_SKIP);
-            if constexpr (MODE == 2 && L.kind == SWEEP_PE && T == 1) {
+            if constexpr (COL && L.kind == SWEEP_PE && T == 1) {
                 // the normal is complete: the colour head's small input tile [points (3), PE4(view) (27), normal x, y] (fields.py:154;
                 // k order of the "c2" stream), z component kept in f32
                 float small[32], pe[27];
@@ -731,6 +742,16 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
                 small[31] = n[1] * a.scale;
                 nz = n[2] * a.scale;
                 F.set(8, vals_tile<32>(small, h, 0));
+                if constexpr (MODE == 3) {
+                    // the colour head's 33 small inputs as rendernet_fwd_kernel saves them ([rows, 64]: the weight-gradient GEMM's operand).
+                    // Uncounted vector-memory operations only make a counted wait return later (as the U_pe stores above)
+                    float s33[33];
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) s33[i] = small[i];
+                    s33[32] = nz;
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt) P::store_tile(reinterpret_cast<ST*>(ex.col_small), p, 64, kt, h, vals_tile<33>(s33, h, kt), true);
+                }
             }
         } else {
             // drain: the last chunk's tile (MODE 0: nothing is pending, the sdf row was stored above)
@@ -742,6 +763,10 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
         if (ok && h == 0) {
 #pragma unroll
             for (int d = 0; d < 3; ++d) a.normals[pd * 3 + d] = n[d] * a.scale;
+            if constexpr (MODE == 3) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) ex.col_out[pd * 3 + d] = col[d];
+            }
         }
     }
     if constexpr (MODE == 2) {
@@ -833,9 +858,9 @@ int launch(const VdnSdfArgs* args, hipStream_t stream, const VdnUpsampleArgs* up
     ShadeExtra exv = ex != nullptr ? *ex : ShadeExtra{};
     // (a training step's launches find the stream cold: the saving launch always, the others when the caller says so; a render()
     // loop keeps its few MB of weights in L2 / MALL, where the warm-up would only cost its 3-5 us)
-    const bool cold = (SAVE && MODE == 1) || args->cold_start != 0;
+    const bool cold = (SAVE && (MODE == 1 || MODE == 3)) || args->cold_start != 0;
     exv.warm_bytes = (warm && cold) ? Prog<MODE>::sdf_total * kStride : 0;
-    exv.warm_bytes2 = (warm && cold && MODE == 2) ? (Prog<MODE>::total - Prog<MODE>::sdf_total) * kStride : 0;
+    exv.warm_bytes2 = (warm && cold && MODE >= 2) ? (Prog<MODE>::total - Prog<MODE>::sdf_total) * kStride : 0;
     hipLaunchKernelGGL((sdf_fwd2_kernel<MODE, SAVE, NSLOT, DEPTH, VID, UPS>), dim3(grid), dim3(kWaves * 64), lds, stream, *args,
                        up != nullptr ? *up : VdnUpsampleArgs{}, exv);
     return (int)hipGetLastError();

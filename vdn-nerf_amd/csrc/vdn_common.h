@@ -177,6 +177,7 @@ VDN_DEV void warm_code_issue(int bytes, long n_wg, int resident, char* lds_dump)
 // mangled names the constant applies to (tests/test_boundary_cpu.py: constant + 4 KiB <= the smallest matching symbol's size)
 constexpr int kWarmCodeSdfFwd2Save = 120 * 1024;      // symbol: sdf_fwd2_kernelILi1ELb1E
 constexpr int kWarmCodeSdfFwd2 = 102 * 1024;          // symbol: sdf_fwd2_kernelILi1ELb0E
+constexpr int kWarmCodeSdfFwd3 = 140 * 1024;          // symbol: sdf_fwd2_kernelILi3ELb1E
 constexpr int kWarmCodeSdfFwd2Mode0 = 46 * 1024;      // symbol: sdf_fwd2_kernelILi0E
 constexpr int kWarmCodeNerfFwd2 = 46 * 1024;          // symbol: nerf_fwd2_kernelILb.ELb1E
 constexpr int kWarmCodeNerfBwd = 78 * 1024;           // symbol: nerf_bwd_kernelINS_4BF16E

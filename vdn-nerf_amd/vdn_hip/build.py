@@ -26,7 +26,8 @@ PER_FILE_FLAGS = {"rays.hip": ["-ffp-contract=off"], "train_rays.hip": ["-ffp-co
                   # k_sdf_fwd2.h: no SLP packing of the epilogue into v_pk_*_f32, MFMA accumulators in arch VGPRs
                   "sdf_bf16.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                   "shade_bf16.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1"],
-                  "sdf_tail_bf16.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+                  "sdf_tail_bf16.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+                  "train_sdf_color_bf16.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _sources():

@@ -452,6 +452,16 @@ class TrainEngine:
         # without a background pass (n_outside = 0) render_core does not blend with inside_sphere (renderer.py:289): every
         # foreground sample counts, nothing may be skipped
         self._fg_compact = bool(skip_far) and O > 0 and os.environ.get("VDN_FG_COMPACT", "1") != "0"
+        # VDN_TRAIN_COLOR_FUSED=1 (bf16; OFF by default): the colour head rides in the SDF kernel's launch (csrc/k_sdf_fwd2.h MODE 3: the
+        # feature vector stays in registers, the head's saved planes are written from there) - one launch and one trip of the
+        # feature plane less, and measured SLOWER in the step: same-box A/B, three alternating runs, 1 141 / 1 138 / 1 121 us against
+        # 1 113 / 1 123 / 1 122 with the two launches. The 128-row workgroups of the SDF kernel run whole rounds (two on the bench
+        # scene's ~36 K rows), each 11 us longer with the head's 33 chunk steps, while rendernet_fwd's 288 workgroups share the
+        # chip with the background network at no such price; and the join with the side stream's update of the head's weights
+        # has to move in front of the SDF kernel. Not with ray gradients (U_pe), the depth_before_color input, or the tail split.
+        self._color_fused = (self.precision == "bf16" and not self.dbc and not ray_grads and "c2" in self.nets["color"].img.blobs
+                             and r.color_network.conf["d_out"] == 3 and os.environ.get("VDN_TRAIN_COLOR_FUSED", "0") == "1"
+                             and not self._tail_wanted())
         from dpt_models.renderer import background_active, bg_compaction
         self._bg_compact = O > 0 and bg_compaction()
         fused_prep = self._bg_compact and os.environ.get("VDN_FUSED_PREP", "1") != "0"
@@ -516,9 +526,10 @@ class TrainEngine:
             self._fork()
             lib.call("vdn_nerf_mlp_fwd" + self.sfx, n, self._side_handle(st))
             self._side_done()
-            self._sdf_forward(rays_o, rays_d)
-        else:
-            self._sdf_forward(rays_o, rays_d)
+        if self._color_fused and before_heads is not None:
+            before_heads()                  # (the fused launch reads the colour head's weight image, which the side stream updates)
+            before_heads = None
+        self._sdf_forward(rays_o, rays_d)
         if after_sdf is not None:       # (the data-parallel Trainer reduces the eikonal sums over the ranks from here on)
             after_sdf(self)
 
@@ -543,7 +554,8 @@ class TrainEngine:
                 self._ev_join2.record(self._side2)
             else:
                 rnet("vdn", w["vdn_out"], w["vdn_h"], w["vdn_small"], 96, r.depth_network)
-        rnet("color", w["col_out"], w["col_h"], w["col_small"], 3, r.color_network)
+        if not self._color_fused:
+            rnet("color", w["col_out"], w["col_h"], w["col_small"], 3, r.color_network)
         if vdn_beside:
             torch.cuda.current_stream().wait_event(self._ev_join2)
 
@@ -604,6 +616,12 @@ class TrainEngine:
             torch.cuda.current_stream().wait_event(self._ev_join)
             self._pending = False
 
+    def _tail_wanted(self):
+        """The tail split of the fused SDF forward (csrc/k_sdf_fwd1_split.h): on where there is no side stream, off with one."""
+        tail_default = "1" if self._side is None else "0"
+        return (self.precision == "bf16" and self._fg_compact and os.environ.get("VDN_SDF_TAIL", tail_default) != "0"
+                and not getattr(self, "_ray_grads", False))
+
     def _sdf_forward(self, rays_o, rays_d):
         """The fused SDF kernel (PE -> 9 layers -> sdf / feature + gradient sweep) with the training-mode saves, on the
         section mid-points currently in the workspace. Separate so that bench.py can time exactly this launch."""
@@ -627,9 +645,8 @@ class TrainEngine:
         # Default: only on the one-stream schedule. The tail kernel buys latency with CU time (32 rows per 45 us against 128 per
         # 80): it shortens the launch when the second round's CUs would idle (-37 us per step on one stream), but on the default
         # two-stream schedule those CUs run the background network and the extra CU time costs +7 .. +20 us (same-box A/B).
-        tail_default = "1" if self._side is None else "0"
-        tail = (self.precision == "bf16" and self._fg_compact and os.environ.get("VDN_SDF_TAIL", tail_default) != "0"
-                and not getattr(self, "_ray_grads", False))
+        tail = self._tail_wanted()
+        fused = getattr(self, "_color_fused", False) and not tail
         if tail:
             row0 = int(os.environ.get("VDN_SDF_TAIL_ROW0", str(128 * torch.cuda.get_device_properties(self.dev).multi_processor_count)))
             tail = self.P > row0
@@ -637,6 +654,11 @@ class TrainEngine:
                 s.tail_row0, s.tail_max_rows = row0, int(os.environ.get("VDN_SDF_TAIL_MAX", "8192"))
 
         def launch():
+            if fused:
+                cimg = self.nets["color"].img
+                lib.call("vdn_sdf_color_train_bf16", self._fg(s), lib.ptr(cimg.blobs["c2"]), int(r.color_network.squeeze_out),
+                         lib.ptr(w["col_h"]), lib.ptr(w["col_small"]), lib.ptr(w["col_out"]), _stream())
+                return
             lib.call("vdn_sdf_mlp_fwd" + self.sfx, 1, self._fg(s), _stream())
             if tail:
                 lib.call("vdn_sdf_fwd_tail_bf16", s, _stream())
