@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VDN_ABI_VERSION 25
+#define VDN_ABI_VERSION 26
 
 int vdn_abi_version(void);
 
@@ -301,6 +301,15 @@ int vdn_feat_composite(const VdnCompositeArgs* args_host, void* stream);
  * network's "c2" stream; comp: as for vdn_alpha_composite_fwd with comp.N = 128 - comp.sdf / normals / color are not read and
  * comp.feat_out must be NULL (the feature channels keep their own launches). Outputs equal the three launches' up to the rounding
  * of the colour head's first layer (the normal's z component enters as an f32 term here, as a bf16 operand there). */
+/* renderer.py:239-315 in ONE launch on the exact-fp32 kernels (csrc/k_shade_f32.h; the counterpart of vdn_shade_fused_bf16 on the path
+ * that holds the reference's 1e-4): vdn_sdf_mlp_fwd_f32(mode 1) + vdn_rendernet_fwd_f32 (colour head, d_out = 3) +
+ * vdn_alpha_composite_fwd + the eikonal reduction, for rays of exactly 128 inside samples (one workgroup per ray), with the very
+ * argument blocks of those calls: sdf_host (its sdf / feat / normals / S buffers are required: what passes between the stages goes
+ * through them), color_host (feat / normals / z / rays must be sdf_host's, out = the sampled colour [P,3]), comp_host (sdf / normals /
+ * color must be those buffers). Same device code as the separate launches: bit-identical outputs. ticket: [1] int32, zero before
+ * the first launch. -10 = shape not covered (make the separate calls). */
+int vdn_shade_fused_f32(const VdnSdfArgs* sdf_host, const VdnRenderNetArgs* color_host, const VdnCompositeArgs* comp_host,
+                        int32_t* ticket, void* stream);
 /* The training step's forward of the SDF network and of the colour head in ONE launch (bf16; csrc/k_sdf_fwd2.h MODE 3):
  * vdn_sdf_mlp_fwd_bf16(mode 1) with its training saves (sdf_host->H, V, PE, feat: as there) followed, on the feature vector kept in
  * registers, by vdn_rendernet_fwd_bf16 of the colour network (fields.py:148-176, mode 'idr', d_out = 3) with ITS saves: col_h

@@ -105,7 +105,7 @@ def test_fused_shading_with_a_vdn_head(B):
 
 
 def test_fused_shading_declines_what_it_does_not_cover():
-    """depth_before_color, other sample counts, fp32: the separate launches run (and the entry point itself answers -10 for N != 128)."""
+    """depth_before_color, other sample counts, mixed precisions: the separate launches run (and the entry point itself answers -10 for N != 128)."""
     from vdn_train import synth, factory
     from vdn_hip import lib
     dev = torch.device("cuda:0")
@@ -113,7 +113,9 @@ def test_fused_shading_declines_what_it_does_not_cover():
                                precision="bf16", depth_before_color=True)
     assert not r._fused_shading(128, depth_before_color=True)       # the colour head would read the VDN head's output
     r = factory.build_renderer(device=dev, states=synth.make_all_states(0), precision="fp32")
-    assert not r._fused_shading(128)
+    assert r._fused_shading(128)                         # (the fp32 path has its own one-launch kernel since round 5: vdn_shade_fused_f32)
+    r.color_network.precision = "bf16"
+    assert not r._fused_shading(128)                     # one precision per launch
     r = factory.build_renderer(device=dev, states=synth.make_all_states(0), precision="bf16", n_importance=0)
     assert not r._fused_shading(64)
     batch, kw = _batch(8, dev)
@@ -155,3 +157,29 @@ def test_persistent_background_outputs_and_jitter_blocks():
     torch.manual_seed(11)
     z2 = _render(r1, a, True)["z_vals"]
     assert torch.equal(z1, z2) and not torch.equal(z1, z1b)
+
+
+@pytest.mark.parametrize("B,wdepth", [(1, False), (37, False), (512, False), (96, True)])
+def test_fp32_fused_shading_equals_the_separate_launches_bit_for_bit(B, wdepth):
+    """vdn_shade_fused_f32 (csrc/k_shade_f32.h): renderer.py:239-315 in ONE launch on the exact-fp32 kernels - the SDF network's body,
+    the colour head's body and the compositor's body back to back in the workgroup that owns the ray, the eikonal term by the ray
+    that finishes last. The same device code as vdn_sdf_mlp_fwd_f32 + vdn_rendernet_fwd_f32 + vdn_alpha_composite_fwd + the eikonal
+    reduce: EVERY output of render() bit for bit, twice in a row (the arrival counter is left at zero), with a VDN head (its two
+    launches follow) and without. The reference's golden cases run through this launch by default
+    (tests/test_gpu_parity.py::test_render_vs_reference_golden: the 1e-4 bar on the kernel north_star names)."""
+    from vdn_train import synth, factory
+    dev = torch.device("cuda:0")
+    rend = factory.build_renderer(wdepth=wdepth, device=dev, states=synth.make_all_states(0, wdepth=wdepth, variance=0.4), precision="fp32")
+    assert rend._fused_shading(128) and rend.shade_launches() == (3 if wdepth else 1)
+    batch, kw = _batch(B, dev)
+    ref = _render(rend, batch, False, **kw)
+    out = _render(rend, batch, True, **kw)
+    again = _render(rend, batch, True, **kw)
+    assert set(out) == set(ref)
+    for k, v in ref.items():
+        if v is None:
+            assert out[k] is None
+            continue
+        assert torch.equal(out[k], v), k
+        assert torch.equal(again[k], v), k
+    assert torch.isfinite(out["color_fine"]).all() and float(out["weight_sum"].max()) > 0.5

@@ -12,11 +12,10 @@ namespace vdn {
 
 // EX: extra feature tiles behind the 10 standard input tiles (3 = the 96 VDN channels of depth_before_color, renderer.py:247-248)
 template <class P, int NT_OUT, int EX = 0>   // NT_OUT 1: d_out <= 4 (colour); 3: d_out = 96 (VDN head)
-__global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_fwd_kernel(RenderNetArgs a) {
+VDN_DEV void rendernet_fwd_body(const RenderNetArgs& a, char* smem) {
     using ST = typename P::store_t;
     constexpr int kSlot = P::stride(10 + EX);
     constexpr int kNSlot = 3 * kSlot > 160 * 1024 ? 2 : 3;      // the 13-k-tile f32 chunks are 56 KiB: two ring slots
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     WStream<P::kWaves, kSlot, kNSlot> ws;
     ws.init(a.blob, smem, 32 + NT_OUT);
     const int lane = ws.lane, c = lane & 31, h = lane >> 5;
@@ -95,6 +94,12 @@ __global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_f
             F32::store_tile(a.out, pd, 96, nt, h, o, ok);      // network outputs feed the per-ray kernels: always f32
         }
     });
+}
+
+template <class P, int NT_OUT, int EX = 0>
+__global__ __launch_bounds__(P::kWaves * 64, P::kMinWavesPerEU) void rendernet_fwd_kernel(RenderNetArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    rendernet_fwd_body<P, NT_OUT, EX>(a, smem);
 }
 
 template <class P>

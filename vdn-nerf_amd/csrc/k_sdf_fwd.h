@@ -12,11 +12,11 @@ namespace vdn {
 // MODE 0: sdf only; 1: sdf + feature + normals (+ training saves). NW = waves per workgroup (32 points each):
 // small launches use fewer waves per workgroup so that the grid still covers the 256 CUs.
 // DERIVE (bf16 training launch only): softplus' is not stored but re-derived from the saved activations.
+// (the body is a device function so that the fp32 one-launch shading kernel - k_shade_f32.h - can run it in front of the colour head)
 template <class P, int MODE, int NW, bool DERIVE = false>
-__global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(SdfArgs a) {
+VDN_DEV void sdf_fwd_body(const SdfArgs& a, char* smem) {
     using ST = typename P::store_t;
     constexpr int kSlot = P::stride(9);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifndef VDN_NSLOT
 #define VDN_NSLOT 3
 #endif
@@ -200,6 +200,12 @@ __global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(Sdf
             for (int d = 0; d < 3; ++d) a.normals[pd * 3 + d] = n[d] * a.scale;
         }
     }
+}
+
+template <class P, int MODE, int NW, bool DERIVE = false>
+__global__ __launch_bounds__(NW * 64, P::kMinWavesPerEU) void sdf_fwd_kernel(SdfArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    sdf_fwd_body<P, MODE, NW, DERIVE>(a, smem);
 }
 
 template <class P, int MODE, int NW, bool DERIVE = false>

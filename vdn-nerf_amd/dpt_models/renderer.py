@@ -405,14 +405,29 @@ class NeuSRenderer:
             sdf, normals = f32(B * N), f32(B * N, 3)
             sa.sdf, sa.normals = sdf.data_ptr(), normals.data_ptr()
             feat = None
-            if self.depth_network is not None:       # the VDN head reads the feature plane: the fused kernel also writes it out
-                feat = torch.empty(B * N, 256, dtype=torch.bfloat16, device=dev)
-                sa.feat = feat.data_ptr()
             ticket = self.__dict__.get("_shade_ticket")
             if ticket is None or ticket.device != dev:
                 ticket = self.__dict__["_shade_ticket"] = torch.zeros(1, dtype=torch.int32, device=dev)
             cn = self.color_network
-            lib.call("vdn_shade_fused_bf16", sa, lib.ptr(cn._images().blobs["c2"]), int(cn.squeeze_out), a, lib.ptr(ticket), st)
+            if sn.precision == "bf16":
+                if self.depth_network is not None:       # the VDN head reads the feature plane: the fused kernel also writes it out
+                    feat = torch.empty(B * N, 256, dtype=torch.bfloat16, device=dev)
+                    sa.feat = feat.data_ptr()
+                lib.call("vdn_shade_fused_bf16", sa, lib.ptr(cn._images().blobs["c2"]), int(cn.squeeze_out), a, lib.ptr(ticket), st)
+            else:
+                # the exact-fp32 kernels (csrc/k_shade_f32.h): the same three stages back to back in the ray's workgroup, handing the
+                # feature vector, the normal and the colour over through these buffers
+                sa.w8row = sn._images().weff_view("lin8").data_ptr()
+                feat, S = f32(B * N, 256), f32(8, B * N, 256)
+                sa.feat, sa.S = feat.data_ptr(), S.data_ptr()
+                sampled_color = f32(B * N, 3)
+                ca = lib.VdnRenderNetArgs()
+                ca.blob = cn._images().blobs["fwd"].data_ptr()
+                ca.rays_o, ca.rays_d, ca.z, ca.n_per_ray = sa.rays_o, sa.rays_d, sa.z, N
+                ca.normals, ca.feat, ca.out = sa.normals, sa.feat, sampled_color.data_ptr()
+                ca.P, ca.d_out, ca.squeeze_out = B * N, 3, int(cn.squeeze_out)
+                a.sdf, a.normals, a.color = sa.sdf, sa.normals, ca.out
+                lib.call("vdn_shade_fused_f32", sa, ca, a, lib.ptr(ticket), st)
             if self.depth_network is not None:
                 # renderer.py:245-249, 306-308: the 96 VDN channels keep their own launches - the head on the feature plane and the
                 # normals the fused kernel wrote, then their weighted sums with the weights it composited
@@ -443,12 +458,12 @@ class NeuSRenderer:
         }
 
     def _fused_shading(self, N, depth_before_color=False):
-        """True where vdn_shade_fused_bf16 covers the configuration: bf16 kernels, rays of exactly 128 inside samples (one
-        workgroup per ray), the shipped 'idr' colour head (d_feature 256, d_out 3); a VDN head's 96 channels keep their own two
-        launches behind it. VDN_SHADE_FUSED=0 forces the separate launches (SDF / colour / compositor / eikonal reduce)."""
+        """True where vdn_shade_fused_bf16 / vdn_shade_fused_f32 cover the configuration: rays of exactly 128 inside samples (one
+        workgroup per ray), the shipped 'idr' colour head (d_feature 256, d_out 3), both networks in one precision; a VDN head's 96
+        channels keep their own two launches behind it. VDN_SHADE_FUSED=0 forces the separate launches (SDF / colour / compositor / eikonal reduce)."""
         cn, sn = self.color_network, self.sdf_network
         return (os.environ.get("VDN_SHADE_FUSED", "1") != "0" and N == 128 and not depth_before_color
-                and sn.precision == "bf16" and cn.precision == "bf16" and cn.conf.get("mode") == "idr"
+                and sn.precision == cn.precision and sn.precision in ("bf16", "fp32") and cn.conf.get("mode") == "idr"
                 and cn.conf.get("d_feature") == 256 and cn.conf.get("d_out") == 3)
 
     def shade_launches(self):
