@@ -6,8 +6,12 @@ shipped architecture.
   python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, or spawned here)
 
 One JSON line on rank 0 with the driver's contract plus
-  roofline      the fused SDF kernel as the timed step launches it (HIP events on the launch stream), beside its
-                inference launch; traffic = PMC bytes from the committed profile of the same launch;
+  roofline      the fused SDF kernel as the timed step launches it (HIP events on the launch stream, in situ; `schedule` says on which
+                schedule - the one-stream one of the committed kernel trace - with that schedule's own step time), beside its inference
+                launch; traffic = PMC bytes from the committed profile of the same launch;
+  roofline_in_step_two_streams   the same bracket on the DEFAULT schedule, the one `ms_per_step` is measured on;
+  runner_flow   what an unchanged dpt_runner.py executes: render() + loss.backward() + torch.optim.Adam through the drop-in classes;
+  real_cameras  the step on a camera rig the reference ships (tests/golden/pnf_rays.npz);
   parity_path   the SAME step on the fp32 kernels (the path that holds the 1e-4 tolerance), driver-timed in this run;
   wdepth        the womsk_white_wdepth step (VDN head + depth-feature loss);
   all_samples_evaluated  the step with the zero-weight work lists off;

@@ -37,6 +37,11 @@ if len(sys.argv) > 3:
                   j["config"]["background_points_total"], j["ms_per_step"]))
         fg = wl["foreground"]
         k = [v for n, v in by.items() if "sdf_fwd2_kernel<1, true" in n]
+        k3 = [v for n, v in by.items() if "sdf_fwd2_kernel<3, true" in n]        # VDN_TRAIN_COLOR_FUSED=1: + the colour head, 542 720 FLOP/row more
+        if k3 and not k:
+            us3 = sum(k3[0]) / steps
+            print("# fused SDF + colour forward of the step: 2 509 824 FLOP/row x %.0f rows / %.1f us sdf_fwd2_kernel<3,true> = %.1f TFLOP/s = %.3f of the "
+                  "2.5 PFLOP/s bf16 MFMA peak" % (fg, us3, 2509824.0 * fg / us3 / 1e6, 2509824.0 * fg / us3 / 1e6 / 2500.0))
         tail = [v for n, v in by.items() if "sdf_fwd1_split_kernel<true>" in n]
         if k:
             us = sum(k[0]) / steps
