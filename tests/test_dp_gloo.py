@@ -67,11 +67,11 @@ def _worker(rank, port, q, wdepth):
     sizes = np.cumsum([0] + [p.numel() for _, p in named])
     sb = int(sizes[next(i for i, n in enumerate(names) if n.startswith("sdf."))])
     se = int(sizes[names.index("variance") + 1])
-    h_nerf = coll.begin([flat[:sb]], side=True)
-    h_sdf = coll.begin([flat[sb:se]])
-    coll.finish(h_sdf, tag="grad_sdf")
-    h_heads = coll.begin([flat[se:]], side=True)
-    coll.finish(h_nerf + h_heads, tag="grad_rest")
+    # (in the order the Trainer's host thread issues them: each slice summed in place, in the stream that made it)
+    assert coll.instream
+    coll.sum_now([flat[:sb]], side=True, tag="grad_nerf")
+    coll.sum_now([flat[sb:se]], tag="grad_sdf")
+    coll.sum_now([flat[se:]], side=True, tag="grad_heads")
     if rank == 0:
         q.put((flat.numpy(), float(eik)))
     dist.destroy_process_group()

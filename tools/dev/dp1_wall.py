@@ -13,7 +13,8 @@ B, seed = 512, 0
 cams = synth.make_cameras(seed)
 gg = lambda x: torch.tensor(x).to(dev)
 torch.manual_seed(0)
-tr = Trainer(factory.build_renderer(device=dev, precision="bf16"), B, dev, collectives=True)
+OFF = os.environ.get("DP1_OFF") == "1"           # the same step without collectives: the denominator of the ratio
+tr = Trainer(factory.build_renderer(device=dev, precision="bf16"), B, dev, collectives=not OFF)
 batches = []
 for it in range(23):
     o, d = synth.random_pixel_batch(seed, it, it % 40, B, cams=cams)
@@ -27,7 +28,7 @@ for r in range(6):
     for i in range(60):
         tr.train_step(*batches[i % 23])
     torch.cuda.synchronize(); res.append((time.time() - t0) / 60 * 1e6)
-tr.coll.timing = True
+tr.coll.timing = not OFF
 for i in range(40):
     tr.train_step(*batches[i % 23])
 torch.cuda.synchronize()

@@ -49,6 +49,15 @@ class Collectives:
         whole_world = group is None or (dist.is_initialized() and group is dist.group.WORLD)
         if self.enabled and side_group is None and whole_world and os.environ.get("VDN_DP_SIDE_GROUP", "1") != "0":
             self.side_group = dist.new_group(ranks=None)
+        # The gradient slices are summed IN the stream that made them (sum_now: torch.distributed's blocking form enqueues the
+        # RCCL kernel on the current stream - no hop to the backend's stream and back, i.e. two marker packets and two queue
+        # switches less per slice, on chains that wait for the sum at once anyway). The two small sums that DO overlap other
+        # work (begin / finish: the foreground count under the SDF kernel, the logged eikonal pair) stay on the backend's
+        # stream. One-rank RCCL group, same box, 3 alternating runs (profiles/r05_dp_one_rank_instream_ab.log): the step
+        # without collectives 1 137 - 1 149 us, through the backend's stream 1 192 - 1 221, in-stream 1 174 - 1 190; a third
+        # communicator for the small sums (1 215 - 1 227) and the small sums in-stream too (no different) are not kept.
+        # VDN_DP_INSTREAM=0: every sum through begin / finish.
+        self.instream = self.enabled and os.environ.get("VDN_DP_INSTREAM", "1") != "0"
         self.timing = False         # bench.py: HIP events around finish() -> exposed wait per tag
         self._timed = {}
 
@@ -59,6 +68,26 @@ class Collectives:
             return []
         grp = self.side_group if side else self.group
         return [dist.all_reduce(t, group=grp, async_op=True) for t in tensors if t.numel()]
+
+    def sum_now(self, tensors, side=False, tag=None):
+        """Sum each tensor over the ranks in place, ordered in torch's current stream like a kernel launch (RCCL: the collective's
+        kernel is enqueued on that stream; gloo: the host blocks until it is done). With `timing` on the call is bracketed by
+        two events like finish()."""
+        if not self.enabled:
+            return
+        if not self.instream:
+            return self.finish(self.begin(tensors, side=side), tag=tag)
+        grp = self.side_group if side else self.group
+        ts = [t for t in tensors if t.numel()]
+        timed = self.timing and tag is not None and ts
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        for t in ts:
+            dist.all_reduce(t, group=grp)
+        if timed:
+            e1.record()
+            self._timed.setdefault(tag, []).append((e0, e1))
 
     def finish(self, handles, tag=None):
         """Order the current stream behind the collectives started by begin(). With `timing` on, the stream's wait is bracketed

@@ -293,7 +293,7 @@ class Trainer:
             keep = {"rest": lambda b: True, "nerf": lambda b: b < sdf_begin, "heads": lambda b: b >= sdf_begin}[part]
             nets = [k for k in rest_nets if part == "rest" or (k == "nerf") == (part == "nerf")]
             on_side = stream != st            # (without a side stream these slices share the caller's stream and the main group)
-            self.coll.finish(self.coll.begin([grad[b:e] for b, e in self._slices_rest if keep(b)], side=on_side), tag="grad_" + part)
+            self.coll.sum_now([grad[b:e] for b, e in self._slices_rest if keep(b)], side=on_side, tag="grad_" + part)
             rr = [r_ for r_ in self._rest_ranges if keep(r_[0])]
             if rr:
                 adam(rr, main_step, stream)
@@ -304,7 +304,7 @@ class Trainer:
                 images.refresh_together([eng.nets[k].img for k in nets], stream, self._img_cache.setdefault(part, {}))
 
         def update_sdf(stream):
-            self.coll.finish(self.coll.begin([grad[b:e] for b, e in self._sdf_ranges]), tag="grad_sdf")
+            self.coll.sum_now([grad[b:e] for b, e in self._sdf_ranges], tag="grad_sdf")
             adam(self._sdf_ranges, main_step, stream)
             images.refresh_together([eng.nets["sdf"].img], stream, self._img_cache.setdefault("sdf", {}))
 
