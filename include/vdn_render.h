@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VDN_ABI_VERSION 26
+#define VDN_ABI_VERSION 27
 
 int vdn_abi_version(void);
 
@@ -691,6 +691,10 @@ typedef struct {
     const float* mid_z;        /* [B,N] */
     int32_t B, N;
     float radius;
+    int32_t complement;        /* nonzero: list the samples the test REJECTS instead (!(|p| < radius)): the two lists of one
+                                * (rays, mid_z, radius) partition the B*N samples. render() under grad evaluates the SDF network
+                                * with the training saves on the first and without them on the second, which only has to deliver
+                                * `gradients` (dpt_models/renderer.py::_RenderCoreFn) */
     int32_t* active_idx;       /* [B*N] out */
     int32_t* n_active;         /* [1] out */
     int32_t* ray_counts;       /* [B] scratch */

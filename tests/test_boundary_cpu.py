@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) >= 10
     for name in declared:
         assert hasattr(l, name), name
-    assert l.vdn_abi_version() == int(re.search(r"#define\s+VDN_ABI_VERSION\s+(\d+)", text).group(1)) == 26
+    assert l.vdn_abi_version() == int(re.search(r"#define\s+VDN_ABI_VERSION\s+(\d+)", text).group(1)) == 27
 
 
 def test_struct_layouts_are_c_layouts():

@@ -431,7 +431,9 @@ def test_gradients_cdf_and_s_val_outputs_are_attached(golden):
     w2 = synth.uniform(5, "aux/w2", (B, 128)).astype(np.float32) - 0.5
 
     def extra(out, tt):
-        return (out["gradients"] * tt(w1)).sum() * 0.01 + (out["cdf_fine"] * tt(w2)).sum() * 0.05 + out["s_val"].sum() * 3.0
+        # (s_val, weight_sum and weight_max are outputs of the autograd node: their adjoints are folded in by its backward)
+        return ((out["gradients"] * tt(w1)).sum() * 0.01 + (out["cdf_fine"] * tt(w2)).sum() * 0.05 + out["s_val"].sum() * 3.0
+                + out["weight_max"].sum() * 0.3 + (out["weight_sum"] ** 2).sum() * 0.2)
 
     st = synth.make_all_states(int(fx["seed"]), wdepth=False, variance=float(fx["variance"]))
     rend = factory.build_renderer(wdepth=False, device=dev, states=st)

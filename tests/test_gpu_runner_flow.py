@@ -171,3 +171,62 @@ def test_adam_groups_with_depth_before_color_and_a_step_without_depth_targets():
     assert tr._depth_adam_steps == 3          # iterations 2, 3, 5
     steps = {int(v["step"]) for v in tr.state_dict()["optimizer"]["state"].values()}
     assert steps == {6, 3}
+
+
+@pytest.mark.parametrize("precision,wdepth", [("fp32", False), ("bf16", False), ("bf16", True)])
+def test_render_under_grad_on_the_work_list_equals_every_sample(precision, wdepth):
+    """render() under grad runs the training launches on the foreground work list and an inference launch of the SDF network on
+    the list's complement (dpt_models/renderer.py::_RenderCoreFn): EVERY output - `gradients` and `cdf_fine` of the skipped
+    samples included - bit for bit what the evaluation of every sample returns (VDN_RENDER_FG_COMPACT=0); parameter gradients of
+    the reference's loss differ by the summation order of the weight-gradient GEMM only; and a loss that does reach the skipped
+    samples' saves (on `gradients` / `cdf_fine`) gets the same gradients through the re-run forward."""
+    import os
+    from vdn_train import synth, factory
+    dev = torch.device("cuda:0")
+    B, seed = 192, 2
+    cams = synth.make_cameras(seed)
+    o, d = synth.random_pixel_batch(seed, 1, 3, B, cams=cams)
+    near, far = synth.near_far_from_sphere(o, d)
+    t1, t2 = synth.jitter(seed, 0, B)
+    tt = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32, device=dev)
+    true_rgb = tt(synth.target_colors(o, d))
+    gt = tt(synth.uniform(seed, "rf/gt", (B, 96)))
+    w1 = tt(synth.uniform(seed, "rf/w1", (B, 128, 3)) - 0.5)
+    w2 = tt(synth.uniform(seed, "rf/w2", (B, 128)) - 0.5)
+
+    def run(compact, aux_loss):
+        os.environ["VDN_RENDER_FG_COMPACT"] = "1" if compact else "0"
+        try:
+            rend = factory.build_renderer(wdepth=wdepth, device=dev, states=synth.make_all_states(seed, wdepth=wdepth, variance=0.4),
+                                          precision=precision)
+            out = rend.render(tt(o), tt(d), tt(near), tt(far), background_rgb=torch.ones(1, 3, device=dev), cos_anneal_ratio=0.7,
+                              t_rand=tt(t1), t_rand_out=tt(t2))
+            loss = (out["color_fine"] - true_rgb).abs().sum() / B + 0.1 * out["gradient_error"]
+            loss = loss + F.binary_cross_entropy(out["weight_sum"].clip(1e-3, 1.0 - 1e-3), torch.ones(B, 1, device=dev)) * 0.1
+            if wdepth:
+                loss = loss + 0.3 * (out["render_feats"] - gt).abs().sum() / B
+            if aux_loss:
+                loss = loss + (out["gradients"] * w1).sum() * 0.01 + (out["cdf_fine"] * w2).sum() * 0.05
+            loss.backward()
+            grads = torch.cat([(torch.zeros_like(p) if p.grad is None else p.grad).reshape(-1) for p in rend._all_parameters()])
+            eng = next(iter(rend.__dict__["_engines"].values()))
+            n_listed = int(eng.w["fg_active"][1])
+            return {k: v.detach().clone() for k, v in out.items() if v is not None}, grads, n_listed, float(loss)
+        finally:
+            del os.environ["VDN_RENDER_FG_COMPACT"]
+
+    for aux_loss in (False, True):
+        ref, g_ref, n_ref, l_ref = run(False, aux_loss)
+        out, g, n, l = run(True, aux_loss)
+        assert n_ref == B * 128
+        if aux_loss:
+            assert n == B * 128                       # the backward re-ran the forward on every sample
+        else:
+            assert 0 < n < B * 128                    # the scene does skip samples
+        assert set(out) == set(ref)
+        for k in ref:
+            assert torch.equal(out[k], ref[k]), k
+        assert l == l_ref
+        tol = 2e-5 if precision == "fp32" else 2e-3
+        assert float((g - g_ref).abs().max()) <= tol * float(g_ref.abs().max()), (aux_loss, float((g - g_ref).abs().max()), float(g_ref.abs().max()))
+        assert float(g_ref.abs().max()) > 0

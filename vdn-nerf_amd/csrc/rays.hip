@@ -328,6 +328,7 @@ struct ActiveJob {
     int B, N, T;            // T samples listed per ray; samples s >= N are always active (background mode)
     float radius;           // background: active iff !(norm < 1); foreground (T == N): active iff norm < radius
     bool background;
+    bool complement;        // foreground only: list what the test rejects
     int32_t* active_idx;
     int32_t* n_active;
     int32_t* ray_counts;
@@ -338,7 +339,7 @@ VDN_DEV bool sample_active(const ActiveJob& a, int r, int s, const float (&o)[3]
     const float mz = a.mid_z[(long)r * a.N + s];
     const float x = o[0] + d[0] * mz, y = o[1] + d[1] * mz, w = o[2] + d[2] * mz;
     const float pn = sqrtf(x * x + y * y + w * w);
-    return a.background ? !(pn < 1.0f) : pn < a.radius;
+    return a.background ? !(pn < 1.0f) : (pn < a.radius) != a.complement;
 }
 
 template <bool FILL>
@@ -382,14 +383,14 @@ static int launch_active(const ActiveJob& j, void* stream) {
 extern "C" int vdn_background_active(const VdnBackgroundActiveArgs* a, void* stream) {
     if (!a || a->B <= 0 || a->N < 0 || a->T < a->N || !a->rays_o || !a->rays_d || (a->N > 0 && !a->mid_z) ||
         !a->active_idx || !a->n_active || !a->ray_counts) return -1;
-    const ActiveJob j = {a->rays_o, a->rays_d, a->mid_z, a->B, a->N, a->T, 1.0f, true, a->active_idx, a->n_active, a->ray_counts};
+    const ActiveJob j = {a->rays_o, a->rays_d, a->mid_z, a->B, a->N, a->T, 1.0f, true, false, a->active_idx, a->n_active, a->ray_counts};
     return launch_active(j, stream);
 }
 
 extern "C" int vdn_foreground_active(const VdnForegroundActiveArgs* a, void* stream) {
     if (!a || a->B <= 0 || a->N <= 0 || !a->rays_o || !a->rays_d || !a->mid_z || !(a->radius > 0.0f) ||
         !a->active_idx || !a->n_active || !a->ray_counts) return -1;
-    const ActiveJob j = {a->rays_o, a->rays_d, a->mid_z, a->B, a->N, a->N, a->radius, false, a->active_idx, a->n_active, a->ray_counts};
+    const ActiveJob j = {a->rays_o, a->rays_d, a->mid_z, a->B, a->N, a->N, a->radius, false, a->complement != 0, a->active_idx, a->n_active, a->ray_counts};
     return launch_active(j, stream);
 }
 
@@ -451,8 +452,8 @@ __global__ __launch_bounds__(kRayWaves * 64) void train_prep_kernel(TrainPrepArg
         if (PASS == 1 && (which == 1) != second) continue;
         if (which == 0 && a.fg_active_idx == nullptr) continue;
         const ActiveJob j = which == 0
-            ? ActiveJob{a.rays_o, a.rays_d, a.mid_z, a.B, a.N, a.N, a.fg_radius, false, a.fg_active_idx, a.fg_n_active, a.fg_ray_counts}
-            : ActiveJob{a.rays_o, a.rays_d, a.mid_z, a.B, a.N, a.T, 1.0f, true, a.bg_active_idx, a.bg_n_active, a.bg_ray_counts};
+            ? ActiveJob{a.rays_o, a.rays_d, a.mid_z, a.B, a.N, a.N, a.fg_radius, false, false, a.fg_active_idx, a.fg_n_active, a.fg_ray_counts}
+            : ActiveJob{a.rays_o, a.rays_d, a.mid_z, a.B, a.N, a.T, 1.0f, true, false, a.bg_active_idx, a.bg_n_active, a.bg_ray_counts};
         int base = 0;
         if (PASS == 1) {
             int acc = 0;

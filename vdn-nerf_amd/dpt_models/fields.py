@@ -72,11 +72,21 @@ class _HipNet(nn.Module):
         # version counters do not move). It leaves a hook here that orders torch's current stream behind that update, so
         # render() / validate_image right after train_step never read half-rebuilt images. (An event wait; free once done.
         # join=False: the Trainer's own forward, which places that wait itself - right in front of the first launch that needs it.)
-        hook = self.__dict__.get("_stream_join") if join else None
+        if join:
+            self._join_trainer()
+        st = self._image_state()
+        st.refresh(_stream())
+        return st
+
+    def _join_trainer(self):
+        hook = self.__dict__.get("_stream_join")
         if hook is not None:
             hook = hook()             # (a weakref.WeakMethod: the network does not keep its Trainer alive, and copies / pickles of
             if hook is not None:      # the module carry no Trainer - __getstate__ below)
                 hook()
+
+    def _image_state(self):
+        """The weight-image object of this network (created on first use; NOT refreshed: _images() does that)."""
         dev = next(self.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("%s lives on %s; move it to the MI355X with .to('cuda') (no CPU path)"
@@ -86,7 +96,6 @@ class _HipNet(nn.Module):
         if st is None or st.device != dev or st.fmt != fmt:
             st = images.NetImages(self._matrices(), self._streams(), dev, fmt)
             self.__dict__["_img"] = st
-        st.refresh(_stream())
         return st
 
 

@@ -100,27 +100,59 @@ class _RenderCoreFn(torch.autograd.Function):
         # and d loss / d z, d z_out (render() chains the latter to near / far)
         ctx.ray_grads = any(ctx.needs_input_grad[1:5])
         ctx.set_materialize_grads(False)          # unused outputs (cdf_fine, gradients ...) arrive as None, not as zero tensors
-        w = engine.forward(rays_o, rays_d, z, z_out, bgc, car, ray_grads=ctx.ray_grads)
+        # Without ray gradients the step takes the Trainer's foreground work list (vdn_hip/train.py: skip_far): inside samples
+        # beyond the relaxed sphere enter every output but `gradients` / `cdf_fine` through exact zeros, so the training launch,
+        # the heads, the backward and the weight-gradient GEMM cover the listed samples only, and an inference launch on the
+        # list's complement delivers `sdf` / `normals` there (rest_normals). Same outputs bit for bit; parameter gradients differ
+        # by the dW summation order. backward() below re-runs the forward on every sample in the one case that needs the saves
+        # everywhere: a loss on `gradients` or `cdf_fine` (the reference's own loss uses neither, dpt_runner.py:215-243).
+        ctx.skipped = not ctx.ray_grads and os.environ.get("VDN_RENDER_FG_COMPACT", "1") != "0"
+        ctx.fwd_args = (bgc, car)
+        w = engine.forward(rays_o, rays_d, z, z_out, bgc, car, ray_grads=ctx.ray_grads, skip_far=ctx.skipped, rest_normals=ctx.skipped)
+        ctx.skipped = ctx.skipped and engine._fg_compact
         ctx.engine, ctx.generation, ctx.n_params = engine, engine.generation, len(params)
-        color, weights, eik = w["color"].clone(), w["weights"].clone(), w["eik"][0].clone()
-        feats = w["feat_out"].clone() if w["feat_out"] is not None else color.new_zeros(0)
+        c = engine.outputs_clone()                # one copy: the engine's buffers are rewritten by the next forward
+        color, weights, eik = c["color"], c["weights"], c["eik"][0]
+        feats = c["feat_out"] if "feat_out" in c else color.new_zeros(0)
         # cdf_fine and gradients stay attached as in the reference (renderer.py:426-439; its own loss never uses them)
-        cdf, normals = w["cdf"].clone(), w["normals"].view(engine.B, engine.N, 3).clone()
-        aux = (w["inside"].clone(), w["s_val"].clone(),
-               (w["bg_mid"] if engine.r.n_outside > 0 else w["mid_z"]).clone(), w["eik"][1:3].clone())
+        cdf, normals = c["cdf"], c["normals"].view(engine.B, engine.N, 3)
+        aux = (c["inside"], c["bg_mid"] if engine.r.n_outside > 0 else c["mid_z"], c["eik"][1:3])
         ctx.mark_non_differentiable(*aux)
-        return (color, feats, weights, eik, cdf, normals) + aux
+        # s_val = 1 / inv_s for every ray (renderer.py:324, 420: a function of the variance alone) and the two reductions of
+        # `weights` (renderer.py:309, 431) are outputs of this node as well: their adjoints are folded in by backward() below
+        # instead of nine small torch launches per forward
+        ctx.save_for_backward(weights, rays_o, rays_d, z, z_out)
+        return (color, feats, weights, eik, cdf, normals, c["s_val"], c["wsum"], c["wmax"]) + aux
 
     @staticmethod
-    def backward(ctx, g_color, g_feats, g_weights, g_eik, g_cdf, g_normals, *unused):
+    def backward(ctx, g_color, g_feats, g_weights, g_eik, g_cdf, g_normals, g_sval, g_wsum, g_wmax, *unused):
         eng = ctx.engine
         if eng.generation != ctx.generation:
             raise RuntimeError("NeuSRenderer.render was called again before this result's backward(): the training "
                                "engine keeps the activations of the latest forward only")
+        weights, rays_o, rays_d, z, z_out = ctx.saved_tensors
+        if ctx.skipped and (g_cdf is not None or g_normals is not None):
+            # adjoints on `cdf_fine` / `gradients` reach the samples the work list skipped: the saves are needed everywhere
+            eng.forward(rays_o, rays_d, z, z_out, ctx.fwd_args[0], ctx.fwd_args[1])
+            eng.generation = ctx.generation
+        if g_wsum is not None:                    # weight_sum = weights.sum(-1, keepdim=True)
+            g_weights = g_wsum.expand_as(weights) if g_weights is None else g_weights + g_wsum
+        if g_wmax is not None:                    # weight_max = weights.max(-1, keepdim=True)[0]: to the (first) arg max
+            hot = torch.zeros_like(weights).scatter_(1, weights.argmax(dim=-1, keepdim=True), g_wmax)
+            g_weights = hot if g_weights is None else g_weights + hot
+        if g_weights is not None:
+            g_weights = g_weights.contiguous()
         g_feats = g_feats if (g_feats is not None and g_feats.numel() > 0) else None
         eng.backward(g_color, g_feats, g_weights, g_eik, g_cdf=g_cdf, g_gradients=g_normals)
         flat = eng.param_grads(clone=True)        # clones: the engine's buffers are reused by the next step
         assert len(flat) == ctx.n_params
+        if g_sval is not None:
+            # s_val[b] = 1 / clip(exp(10 var), 1e-6, 1e6): d / d var = -10 s_val where the clip passes
+            var = eng.r.deviation_network.variance
+            i = next(k for k, p in enumerate(eng.params) if p is var)
+            inv_s = torch.exp(var.detach() * 10.0)
+            passes = ((inv_s > 1e-6) & (inv_s < 1e6)).to(inv_s.dtype)
+            flat[i] = flat[i] + (g_sval.sum() * (-10.0) * passes / inv_s).reshape(flat[i].shape)
         rays = (None,) * 4
         if ctx.ray_grads:
             w = eng.w
@@ -307,6 +339,16 @@ class NeuSRenderer:
         differentiable = torch.is_grad_enabled() and (attached is not None or any(p.requires_grad for p in params))
         # inference with the background work list: the last round's merge rides in vdn_train_prep (as in the training engine)
         defer = (not differentiable) and O > 0 and bg_compaction()
+        if differentiable:
+            # an optimizer step changed every network at once: ONE weight-norm launch and ONE image-build launch for all of
+            # them here instead of two per network as each is first used (vdn_hip/images.py::refresh_together)
+            nets = [m for m in (self.nerf, self.sdf_network, self.color_network, self.depth_network) if m is not None]
+            for m in nets:
+                m._join_trainer()
+            stale = [im for im in (m._image_state() for m in nets) if im.stale()]
+            if len(stale) > 1:
+                from vdn_hip import images as _images
+                _images.refresh_together(stale, st, self.__dict__.setdefault("_img_tables", {}))
         z, z_out = self._sample(rays_o, rays_d, near, far, perturb, t_rand, t_rand_out, z_vals_inject, defer_last_merge=defer)
         if differentiable:
             if attached is not None:
@@ -527,22 +569,16 @@ class NeuSRenderer:
             if bgc.numel() != 3:
                 raise ValueError("background_rgb must have 3 values")
         z = z.contiguous()
-        color, feats, weights, eik, cdf, normals, inside, s_val, z_ret, eik_terms = _RenderCoreFn.apply(
+        color, feats, weights, eik, cdf, normals, s_val, wsum, wmax, inside, z_ret, eik_terms = _RenderCoreFn.apply(
             eng, rays_o, rays_d, z, z_out, bgc, float(cos_anneal_ratio), *params)
         self.last_eikonal_terms = eik_terms
-        var = self.deviation_network.variance
-        if var.requires_grad:
-            # s_val = mean over the samples of 1 / inv_s (renderer.py:324, 420): a function of the variance parameter alone
-            inv_s = torch.exp(var * 10.0).clip(1e-6, 1e6)
-            s_graph = (1.0 / inv_s).reshape(1, 1).expand(B, 1)
-            s_val = s_val + (s_graph - s_graph.detach())
         return {
             "render_feats": feats if self.depth_network is not None else None,
             "color_fine": color,
             "s_val": s_val,
             "cdf_fine": cdf,
-            "weight_sum": weights.sum(dim=-1, keepdim=True),
-            "weight_max": torch.max(weights, dim=-1, keepdim=True)[0],
+            "weight_sum": wsum,
+            "weight_max": wmax,
             "gradients": normals,
             "weights": weights,
             "z_vals": z_ret,

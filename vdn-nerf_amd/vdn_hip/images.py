@@ -204,6 +204,10 @@ class NetImages:
             self._tables_key = ptr_key
             self._key = None
 
+    def stale(self):
+        self._ensure_tables()
+        return tuple(t._version for t in self._params()) != self._key
+
     def refresh(self, stream):
         """Re-materialise W_eff and all chunk images if any parameter changed (in place or rebound)."""
         self._ensure_tables()

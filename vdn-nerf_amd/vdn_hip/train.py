@@ -132,11 +132,22 @@ class TrainEngine:
         self.Pp, self.Qp = Pp, Qp
         w = self.w = {}
         # ---- forward saves
-        w["dists"], w["mid_z"] = f(B, N), f(B, N)
+        w["dists"] = f(B, N)
         # dense per-point outputs are zero-initialised: points a work list skips keep finite values, and the compositor only
         # ever multiplies those by exact zeros (include/vdn_render.h: vdn_foreground_active / vdn_background_active)
         fz = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
-        w["sdf"], w["feat"], w["normals"] = fz(P), fs(Pp, 256), fz(P, 3)
+        # what render()'s autograd node hands out (it must copy: these buffers are rewritten by the next forward) lies in ONE
+        # allocation, so that copy is one launch instead of ten (outputs_clone)
+        slots, n_out = {}, 0
+        for name, shape in (("color", (B, 3)), ("weights", (B, T)), ("eik", (3,)), ("feat_out", (B, 96) if self.wdepth else None),
+                            ("cdf", (B, N)), ("normals", (P, 3)), ("inside", (B, N)), ("s_val", (B, 1)),
+                            ("bg_mid", (B, T) if O > 0 else None), ("mid_z", (B, N)), ("wsum", (B, 1)), ("wmax", (B, 1))):
+            if shape is not None:
+                slots[name] = (n_out, shape)
+                n_out += (int(np.prod(shape)) + 63) // 64 * 64
+        self._out_arena, self._out_slots = fz(n_out), slots
+        out = lambda name: self._out_arena[slots[name][0]:slots[name][0] + int(np.prod(slots[name][1]))].view(slots[name][1])
+        w["sdf"], w["feat"], w["normals"], w["mid_z"] = fz(P), fs(Pp, 256), out("normals"), out("mid_z")
         w["fg_active"] = (torch.zeros(P, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev),
                           torch.zeros(B, dtype=torch.int32, device=dev))
         w["H"], w["V"], w["PE"] = fs(8, Pp, 256), fs(8, Pp, 256), fs(Pp, 64)
@@ -148,17 +159,17 @@ class TrainEngine:
         if self.dbc:
             w["col_extra"] = fs(Pp, 96)
         if O > 0:
-            w["z_feed"], w["bg_dists"], w["bg_mid"] = f(B, T), f(B, T), f(B, T)
+            w["z_feed"], w["bg_dists"], w["bg_mid"] = f(B, T), f(B, T), out("bg_mid")
             # zero-initialised: points the active list skips keep finite values (the compositor multiplies them by zero)
             w["bg_density"], w["bg_rgb"] = torch.zeros(Q, device=dev), torch.zeros(Q, 3, device=dev)
             w["bg_feat"] = torch.zeros(Q, 96, device=dev) if self.wdepth else None
             w["bg_active"] = (torch.zeros(Q, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev),
                               torch.zeros(B, dtype=torch.int32, device=dev))
             w["nf_h"], w["nf_pe"], w["nf_feature"], w["nf_vpe"], w["nf_hv"] = fs(8, Qp, 256), fs(Qp, 96), fs(Qp, 256), fs(Qp, 32), fs(Qp, 128)
-        w["weights"], w["alpha"], w["cdf"], w["inside"] = f(B, T), f(B, T), f(B, N), f(B, N)
-        w["color"], w["wsum"], w["wmax"], w["s_val"] = f(B, 3), f(B, 1), f(B, 1), f(B, 1)
-        w["eik_partial"], w["eik"] = f(B, 2), f(3)
-        w["feat_out"] = f(B, 96) if self.wdepth else None
+        w["weights"], w["alpha"], w["cdf"], w["inside"] = out("weights"), f(B, T), out("cdf"), out("inside")
+        w["color"], w["wsum"], w["wmax"], w["s_val"] = out("color"), out("wsum"), out("wmax"), out("s_val")
+        w["eik_partial"], w["eik"] = f(B, 2), out("eik")
+        w["feat_out"] = out("feat_out") if self.wdepth else None
         # ---- backward intermediates
         w["d_sdf"], w["d_normals"], w["d_color"], w["d_featvec"] = f(P), f(P, 3), f(P, 3), fs(Pp, 256)
         w["d_vdn"] = f(P, 96) if self.wdepth else None
@@ -421,12 +432,15 @@ class TrainEngine:
         return w
 
     def forward(self, rays_o, rays_d, z, z_out, background_rgb, cos_anneal_ratio, skip_far=False, ray_grads=False, pending_merge=None,
-                after_sdf=None, fuse_loss=None, before_heads=None):
+                after_sdf=None, fuse_loss=None, before_heads=None, rest_normals=False):
         """Differentiable part of render() at detached z [B,N] (+ z_out [B,O]); returns the output tensors.
         skip_far (the Trainer's hot loop): inside samples beyond the relaxed sphere (|p| >= 1.2: inside_sphere = 0 and
         relax_inside_sphere = 0, renderer.py:284-286) enter the loss only through exact zeros, so the SDF / colour / VDN
         networks skip them; `normals` / `sdf` are then only valid at the listed points (render() never sets it: it returns
         `gradients` for every sample).
+        rest_normals (render() under grad, with skip_far): the samples the work list skips still get their `sdf` and `normals`
+        (render() returns `gradients` for every sample, and `cdf_fine` is made from them) from an inference launch of the SDF
+        network on the list's complement - no saves, no colour / VDN head, no backward there.
         fuse_loss (the Trainer's plain configuration): dict(true_rgb, g_color, igr_weight, grad_scale) - the compositor, the
         colour term's gradient and the compositor's adjoint run as ONE launch (vdn_composite_train); backward() then starts at
         the heads. With the VDN head and the dict's gt_feats / g_feats / depth_weight: vdn_composite_fwd_train here and
@@ -525,6 +539,8 @@ class TrainEngine:
             # (81 920 background points = 1.25 rounds of the CUs; the tail round could overlap the SDF kernels)
             self._fork()
             lib.call("vdn_nerf_mlp_fwd" + self.sfx, n, self._side_handle(st))
+            if rest_normals and self._fg_compact:
+                self._sdf_rest(rays_o, rays_d, self._side_handle(st))     # (beside the training launch on the listed samples)
             self._side_done()
         if self._color_fused and before_heads is not None:
             before_heads()                  # (the fused launch reads the colour head's weight image, which the side stream updates)
@@ -621,6 +637,33 @@ class TrainEngine:
         tail_default = "1" if self._side is None else "0"
         return (self.precision == "bf16" and self._fg_compact and os.environ.get("VDN_SDF_TAIL", tail_default) != "0"
                 and not getattr(self, "_ray_grads", False))
+
+    def _sdf_rest(self, rays_o, rays_d, stream):
+        """`sdf` and `normals` of the inside samples the foreground work list skips: the list's complement (vdn_foreground_active,
+        complement = 1) through the SDF kernel's inference form (mode 1 without saves; its feature plane goes to a backward
+        intermediate that is free during the forward)."""
+        w, N = self.w, self.N
+        if "fg_rest" not in w:
+            w["fg_rest"] = (torch.zeros(self.P, dtype=torch.int32, device=self.dev), torch.zeros(1, dtype=torch.int32, device=self.dev),
+                            torch.zeros(self.B, dtype=torch.int32, device=self.dev))
+        fa = lib.VdnForegroundActiveArgs()
+        fa.rays_o, fa.rays_d, fa.mid_z, fa.B, fa.N, fa.radius = rays_o.data_ptr(), rays_d.data_ptr(), w["mid_z"].data_ptr(), self.B, N, 1.2
+        fa.complement = 1
+        fa.active_idx, fa.n_active, fa.ray_counts = (t.data_ptr() for t in w["fg_rest"])
+        lib.call("vdn_foreground_active", fa, stream)
+        s = lib.VdnSdfArgs()
+        img = self.nets["sdf"].img
+        s.blob = img.blobs["full"].data_ptr()
+        s.rays_o, s.rays_d, s.z, s.n_per_ray, s.z_ld, s.sdf_ld = rays_o.data_ptr(), rays_d.data_ptr(), w["mid_z"].data_ptr(), N, N, N
+        s.P, s.scale = self.P, float(self.r.sdf_network.scale)
+        s.sdf, s.feat, s.normals = w["sdf"].data_ptr(), w["d_featvec"].data_ptr(), w["normals"].data_ptr()
+        s.w8row = img.weff_view("lin8").data_ptr()
+        if "S" in w:              # (the fp32 kernel keeps softplus' in a plane between its forward pass and its sweep)
+            if "S_rest" not in w:
+                w["S_rest"] = torch.empty_like(w["S"])
+            s.S = w["S_rest"].data_ptr()
+        s.active_idx, s.n_active = w["fg_rest"][0].data_ptr(), w["fg_rest"][1].data_ptr()
+        lib.call("vdn_sdf_mlp_fwd" + self.sfx, 1, s, stream)
 
     def _sdf_forward(self, rays_o, rays_d):
         """The fused SDF kernel (PE -> 9 layers -> sdf / feature + gradient sweep) with the training-mode saves, on the
@@ -938,8 +981,31 @@ class TrainEngine:
         # gradients now sit in self._grad_flat (views per parameter in self.grad_views)
         return self._grad_flat
 
+    def outputs_clone(self):
+        """A copy of everything the latest forward hands to the caller (one device copy) -> {name: tensor}."""
+        a = self._out_arena.clone()
+        return {k: a[o:o + int(np.prod(sh))].view(sh) for k, (o, sh) in self._out_slots.items()}
+
     def param_grads(self, clone=True):
         """Per-parameter gradients in renderer._all_parameters() order."""
         if getattr(self, "join_hook", None) is not None:     # the Trainer's deferred half of the backward (side stream)
             self.join_hook()
-        return [self.grad_views[id(p)].clone() if clone else self.grad_views[id(p)] for p in self.params]
+        if not clone:
+            return [self.grad_views[id(p)] for p in self.params]
+        # ONE multi-tensor copy into fresh views of one new allocation (a clone per parameter is 67 - 77 copy launches of 3 us
+        # each on the step's stream: 250 us of the unchanged runner's 2.1 ms step). The views are new tensors nothing else
+        # refers to, so autograd's AccumulateGrad adopts them as .grad without another copy; their allocation belongs to this
+        # backward alone - the engine's own buffer is reused by the next step. Every view starts on a 256-byte boundary:
+        # torch.optim's multi-tensor kernels fall back to scalar loads on lists with a misaligned member (packed offsets
+        # cost the runner's Adam step + 60 us).
+        if self.__dict__.get("_clone_slots") is None:
+            slots, off = [], 0
+            for p in self.params:
+                slots.append((off, p.numel(), p.shape))
+                off += (p.numel() + 63) // 64 * 64
+            self._clone_slots, self._clone_total = slots, off
+            self._grad_list = [self.grad_views[id(p)] for p in self.params]
+        flat = torch.empty(self._clone_total, dtype=torch.float32, device=self._grad_flat.device)
+        out = [flat[o:o + n].view(sh) for o, n, sh in self._clone_slots]
+        torch._foreach_copy_(out, self._grad_list)
+        return out
