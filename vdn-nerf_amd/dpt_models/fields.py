@@ -22,8 +22,7 @@ def _require_gpu(t, what):
         raise ValueError("%s: expected float32, got %s" % (what, t.dtype))
 
 
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
+_stream = lib.stream_handle          # the HIP handle of torch's current stream
 
 
 class _WNLinear(nn.Module):
@@ -87,7 +86,7 @@ class _HipNet(nn.Module):
 
     def _image_state(self):
         """The weight-image object of this network (created on first use; NOT refreshed: _images() does that)."""
-        dev = next(self.parameters()).device
+        dev = lib.first_param(self).device
         if dev.type != "cuda":
             raise RuntimeError("%s lives on %s; move it to the MI355X with .to('cuda') (no CPU path)"
                                % (type(self).__name__, dev))

@@ -345,15 +345,24 @@ class NeuSRenderer:
             nets = [m for m in (self.nerf, self.sdf_network, self.color_network, self.depth_network) if m is not None]
             for m in nets:
                 m._join_trainer()
-            stale = [im for im in (m._image_state() for m in nets) if im.stale()]
+            from vdn_hip import images as _images
+            ims = [m._image_state() for m in nets]
+            stale = [im for im in ims if im.stale()]
             if len(stale) > 1:
-                from vdn_hip import images as _images
                 _images.refresh_together(stale, st, self.__dict__.setdefault("_img_tables", {}))
+            elif stale:
+                stale[0].refresh(st)
+            # ... and nothing changes a parameter before this call returns: the dozen _images() calls below (each sampler pass,
+            # each network of the engine) skip their own staleness test (a walk over the parameters' versions and addresses)
+            _images.trust(ims)
+            try:
+                z, z_out = self._sample(rays_o, rays_d, near, far, perturb, t_rand, t_rand_out, z_vals_inject, defer_last_merge=defer)
+                if attached is not None:
+                    rays_o, rays_d, z, z_out = self._attach_rays(attached, near, far, z, z_out)
+                return self._render_train(rays_o, rays_d, z, z_out, background_rgb, cos_anneal_ratio, params)
+            finally:
+                _images.trust(None)
         z, z_out = self._sample(rays_o, rays_d, near, far, perturb, t_rand, t_rand_out, z_vals_inject, defer_last_merge=defer)
-        if differentiable:
-            if attached is not None:
-                rays_o, rays_d, z, z_out = self._attach_rays(attached, near, far, z, z_out)
-            return self._render_train(rays_o, rays_d, z, z_out, background_rgb, cos_anneal_ratio, params)
         bg_density = bg_rgb = bg_feat = bg_dists = bg_mid = None
         if O > 0 and bg_compaction():
             # z_feed (renderer.py:390-391), both section sets and the background work list in two launches (vdn_train_prep)
@@ -524,7 +533,7 @@ class NeuSRenderer:
         ps = []
         for m in (self.nerf, self.sdf_network, self.deviation_network, self.color_network, self.depth_network):
             if m is not None:
-                ps += list(m.parameters())
+                lib.module_params(m, ps)
         return ps
 
     def _attach_rays(self, attached, near_d, far_d, z, z_out):

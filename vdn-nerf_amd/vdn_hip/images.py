@@ -210,6 +210,8 @@ class NetImages:
 
     def refresh(self, stream):
         """Re-materialise W_eff and all chunk images if any parameter changed (in place or rebound)."""
+        if _TRUSTED is not None and id(self) in _TRUSTED:
+            return False
         self._ensure_tables()
         key = tuple(t._version for t in self._params())
         if key == self._key:
@@ -218,6 +220,16 @@ class NetImages:
         lib.call("vdn_build_images", lib.ptr(self.chunk_table), self._n_ch, stream)
         self._key = key
         return True
+
+
+_TRUSTED = None
+
+
+def trust(images):
+    """render() under grad has just tested / refreshed these image sets and changes no parameter until it returns: their
+    refresh() is a no-op until trust(None)."""
+    global _TRUSTED
+    _TRUSTED = None if images is None else {id(im) for im in images}
 
 
 def refresh_together(images, stream, cache):

@@ -128,3 +128,47 @@ def call_value(fn_name, *args):
 def ptr(t):
     """Device pointer of a torch tensor (or None)."""
     return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+# ---- host-side helpers on the launch path (each is called tens of times per step) -------------------------------------
+import torch  # noqa: E402
+
+try:
+    _raw_stream, _get_device = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice
+except AttributeError:          # (an interpreter without the private accessors: the public, slower route)
+    _raw_stream = _get_device = None
+
+
+def stream_handle():
+    """The HIP stream handle of torch's current stream on the current device (torch.cuda.current_stream().cuda_stream costs
+    ~10 us of Python per call; the step asks 17 times)."""
+    if _raw_stream is None:
+        return torch.cuda.current_stream().cuda_stream
+    return _raw_stream(_get_device())
+
+
+def module_params(m, out=None):
+    """list(m.parameters()) for modules that share no parameters - the same pre-order walk without named_members' generators and
+    de-duplication set (8 us -> 1 us per module; render() walks all networks several times per call)."""
+    if out is None:
+        out = []
+    for q in m._parameters.values():
+        if q is not None:
+            out.append(q)
+    for c in m._modules.values():
+        if c is not None:
+            module_params(c, out)
+    return out
+
+
+def first_param(m):
+    """next(m.parameters()) without the generators."""
+    for q in m._parameters.values():
+        if q is not None:
+            return q
+    for c in m._modules.values():
+        if c is not None:
+            q = first_param(c)
+            if q is not None:
+                return q
+    return None

@@ -8,8 +8,7 @@ import torch
 from vdn_hip import lib
 
 
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
+_stream = lib.stream_handle          # the HIP handle of torch's current stream
 
 
 class RaysGenerator:

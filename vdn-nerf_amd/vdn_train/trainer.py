@@ -32,8 +32,7 @@ DEFAULT_TRAIN_CONF = dict(learning_rate=5e-4, learning_rate_alpha=0.05, end_iter
                           igr_weight=0.1, mask_weight=0.0, use_white_bkgd=True, extract_depth=False, depth_start_iter=5000)
 
 
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
+_stream = lib.stream_handle          # the HIP handle of torch's current stream
 
 
 class Trainer:
