@@ -10,7 +10,8 @@ One JSON line on rank 0 with the driver's contract plus
                 schedule - the one-stream one of the committed kernel trace - with that schedule's own step time), beside its inference
                 launch; traffic = PMC bytes from the committed profile of the same launch;
   roofline_in_step_two_streams   the same bracket on the DEFAULT schedule, the one `ms_per_step` is measured on;
-  runner_flow   what an unchanged dpt_runner.py executes: render() + loss.backward() + torch.optim.Adam through the drop-in classes;
+  runner_flow   what an unchanged dpt_runner.py executes: render() + loss.backward() + torch.optim.Adam through the drop-in classes,
+                and its image loops' render() with autograd on;
   real_cameras  the step on a camera rig the reference ships (tests/golden/pnf_rays.npz);
   parity_path   the SAME step on the fp32 kernels (the path that holds the 1e-4 tolerance), driver-timed in this run;
   wdepth        the womsk_white_wdepth step (VDN head + depth-feature loss);
@@ -460,7 +461,22 @@ def runner_flow(args, dev, precision, steps, warmup=5):
         torch.cuda.synchronize()
         regions.append(time.time() - t0)
     med = float(np.median(regions))
+    # the runner's image loops (dpt_runner.py:439-445, 540-546) call render() on 512-ray chunks with autograd ON and never call
+    # backward: the forward of the step above, node and saves included
+    fwd = []
+    while len(fwd) < 5 or (sum(fwd) < 0.5 and len(fwd) < 200):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for i in range(steps):
+            b = batches[i % len(batches)]
+            out = rend.render(b[0], b[1], b[2], b[3], background_rgb=bg, cos_anneal_ratio=0.5)
+            keep = out["color_fine"].detach()
+            del out
+        torch.cuda.synchronize()
+        fwd.append(time.time() - t0)
+    fmed = float(np.median(fwd))
     return {"rays_per_s": B * steps / med, "ms_per_step": med / steps * 1e3, "regions": len(regions), "final_loss": float(loss.item()),
+            "image_loop_rays_per_s": B * steps / fmed, "image_loop_ms_per_batch": fmed / steps * 1e3,
             "dtype": "f32" if precision == "fp32" else "bf16"}
 
 
@@ -624,7 +640,9 @@ def main():
         # what an unchanged dpt_runner.py executes: render() + loss.backward() + torch.optim.Adam through the drop-in classes
         if world == 1:
             extras["runner_flow"] = {"what": "render() under grad -> torch loss -> loss.backward() -> torch.optim.Adam.step() through the drop-in "
-                                             "classes (dpt_runner.py:214-257), 512 rays per step, default jitter",
+                                             "classes (dpt_runner.py:214-257), 512 rays per step, default jitter; image_loop_*: "
+                                             "render() with autograd on and no backward, the runner's validate_image / val_img chunks "
+                                             "(dpt_runner.py:439-445)",
                                      "bf16": runner_flow(args, dev, "bf16", K), "fp32": runner_flow(args, dev, "fp32", max(4, K // 4))}
             torch.cuda.empty_cache()
         rc = real_cameras()
