@@ -34,9 +34,12 @@ __device__ inline unsigned short f32_to_bf16_rn(float f) {
     return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
 
-// one block per chunk
+// kImgSplit blocks per chunk (a chunk is 1 - 1.2 K 16-byte items behind two dependent index loads each: one 256-thread block per
+// chunk left the launch latency-bound at ~280 blocks - 15.9 us for the SDF network's 4 MB of images)
+constexpr int kImgSplit = 4;
 __global__ void build_images_kernel(const ChunkDesc* descs) {
     const ChunkDesc d = descs[blockIdx.x];
+    const int tid = blockIdx.y * blockDim.x + threadIdx.x, nthr = gridDim.y * blockDim.x;
     const int kt = d.k_pad / 32;
     const int kt0 = d.kt_count > 0 ? d.kt_begin : 0;
     const int ktn = d.kt_count > 0 ? d.kt_count : kt;
@@ -49,7 +52,7 @@ __global__ void build_images_kernel(const ChunkDesc* descs) {
         // [kt*4 groups][64 lanes][4] f32, then 32 bias floats, zero pad to 1 KiB
         float* out = reinterpret_cast<float*>(d.dst) + (long)kt0 * 1024;
         const int n4 = ktn * 4 * 64;
-        for (int idx = threadIdx.x; idx < n4; idx += blockDim.x) {
+        for (int idx = tid; idx < n4; idx += nthr) {
             const int g = idx >> 6, lane = idx & 63, i = lane & 31, h = lane >> 5;
             float4 o;
             o.x = val(i, 8 * g + 4 * h + 0);
@@ -59,7 +62,7 @@ __global__ void build_images_kernel(const ChunkDesc* descs) {
             reinterpret_cast<float4*>(out)[idx] = o;
         }
         float* b = reinterpret_cast<float*>(d.dst) + (long)kt * 1024;
-        for (int i = threadIdx.x; i < 256 && d.write_bias; i += blockDim.x) {
+        for (int i = tid; i < 256 && d.write_bias; i += nthr) {
             float bv = 0.0f;
             if (i < 32 && d.bias != nullptr) {
                 const int r = d.nmap[d.n0 + i];
@@ -72,7 +75,7 @@ __global__ void build_images_kernel(const ChunkDesc* descs) {
         // then 32 f32 bias, zero pad to 1 KiB
         unsigned short* out = reinterpret_cast<unsigned short*>(d.dst) + (long)kt0 * 1024;
         const int n8 = ktn * 2 * 64;
-        for (int idx = threadIdx.x; idx < n8; idx += blockDim.x) {
+        for (int idx = tid; idx < n8; idx += nthr) {
             const int s = idx >> 6, lane = idx & 63, i = lane & 31, h = lane >> 5;
             unsigned short o[8];
 #pragma unroll
@@ -85,7 +88,7 @@ __global__ void build_images_kernel(const ChunkDesc* descs) {
             reinterpret_cast<uint4*>(out)[idx] = pk;
         }
         float* b = reinterpret_cast<float*>(d.dst + (long)kt * 2048);
-        for (int i = threadIdx.x; i < 256 && d.write_bias; i += blockDim.x) {
+        for (int i = tid; i < 256 && d.write_bias; i += nthr) {
             float bv = 0.0f;
             if (i < 32 && d.bias != nullptr) {
                 const int r = d.nmap[d.n0 + i];
@@ -97,7 +100,7 @@ __global__ void build_images_kernel(const ChunkDesc* descs) {
     if (d.tail != nullptr && d.write_bias) {
         float* t = reinterpret_cast<float*>(d.dst + d.tail_off);
         const long ts = d.tail_stride > 1 ? d.tail_stride : 1;
-        for (int i = threadIdx.x; i < d.tail_n; i += blockDim.x) t[i] = d.tail[i * ts];
+        for (int i = tid; i < d.tail_n; i += nthr) t[i] = d.tail[i * ts];
     }
 }
 
@@ -140,6 +143,6 @@ extern "C" int vdn_weightnorm_materialize(const VdnWeightNormDesc* descs_dev, in
 
 extern "C" int vdn_build_images(const VdnChunkDesc* descs_dev, int n_chunks, void* stream) {
     if (descs_dev == nullptr || n_chunks <= 0) return -1;
-    hipLaunchKernelGGL(vdn::build_images_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, descs_dev);
+    hipLaunchKernelGGL(vdn::build_images_kernel, dim3(n_chunks, vdn::kImgSplit), dim3(256), 0, (hipStream_t)stream, descs_dev);
     return (int)hipGetLastError();
 }
