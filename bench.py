@@ -545,14 +545,16 @@ def main():
     res = head.measure(W, K)
     extras = {}
     if world > 1:
-        # K more steps with HIP events around every collective's wait (dp.Collectives.finish): how long each stream actually
-        # stood waiting for RCCL - the EXPOSED part of the eikonal reduce and of the three gradient slices - per step, rank 0's
-        # view. (Kept out of the timed regions above: `value` carries no event records.)
+        # K more steps with HIP events around every collective (dp.Collectives.sum_now / finish): how long each stream actually
+        # spent in or waiting for RCCL - the three in-stream gradient slices and the exposed part of the two small overlapped
+        # sums - per step, rank 0's view. (Kept out of the timed regions above: `value` carries no event records.)
         head.trainer.coll.timing = True
         head.region(W + K, K)
         head.trainer.coll.timing = False
-        extras["allreduce_exposed_ms"] = dict(head.trainer.coll.exposed_ms(), note="per call: stream wait bracketed by HIP events; "
-                                              "grad_sdf and eikonal sit on the critical path, grad_nerf / grad_heads on the side stream")
+        extras["allreduce_exposed_ms"] = dict(head.trainer.coll.exposed_ms(), note="per call, bracketed by HIP events on the issuing stream: "
+                                              "the gradient slices are summed IN that stream (the bracket is the collective itself: "
+                                              "grad_sdf on the critical path, grad_nerf / grad_heads on the side stream); fg_count and "
+                                              "eikonal overlap other work and the bracket is only the stream's wait for them")
     if not args.headline_only:
         # The same K steps with every sample evaluated, as the reference does: the default path skips samples that enter the loss
         # only through exact zeros ("Work lists") - identical results, reported side by side for transparency.
