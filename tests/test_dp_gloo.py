@@ -48,6 +48,8 @@ def _worker(rank, port, q, wdepth):
     out = _render(nets, b)
     nd = torch.stack([out["eik_num"].detach(), out["eik_den"].detach()])
     local_num = nd[0].clone()
+    if wdepth:                                              # (one of the two cases takes round 4's form of the gradient sums:
+        os.environ["VDN_DP_INSTREAM"] = "0"                 # every sum through begin / finish on the backend's stream)
     coll = dp.Collectives(WORLD)                            # the Trainer's own collectives object (vdn_train/trainer.py:97)
     assert coll.enabled and coll.side_group is not coll.group
     coll.finish(coll.begin([nd]), tag="eikonal")            # in place: global (num, den)
@@ -68,7 +70,7 @@ def _worker(rank, port, q, wdepth):
     sb = int(sizes[next(i for i, n in enumerate(names) if n.startswith("sdf."))])
     se = int(sizes[names.index("variance") + 1])
     # (in the order the Trainer's host thread issues them: each slice summed in place, in the stream that made it)
-    assert coll.instream
+    assert coll.instream == (not wdepth)
     coll.sum_now([flat[:sb]], side=True, tag="grad_nerf")
     coll.sum_now([flat[sb:se]], tag="grad_sdf")
     coll.sum_now([flat[se:]], side=True, tag="grad_heads")
