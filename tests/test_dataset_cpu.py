@@ -27,6 +27,55 @@ def test_projection_matrix_decomposition_recovers_camera(scale):
         assert intr.shape == (4, 4) and pose.dtype == np.float32 and abs(np.linalg.det(pose[:3, :3]) - 1) < 1e-5
 
 
+def test_opencv_restatement_properties():
+    """oracle/opencv_decompose.py restates cv2.decomposeProjectionMatrix (OpenCV 4.5.2, absent here): M = K R, K upper-triangular
+    with its first two diagonal entries positive, R a proper rotation, the returned position in P's null space - for P of either
+    sign and type, and for left blocks that need each of the routine's three 180-degree fixes."""
+    from oracle import opencv_decompose as cvd
+    rng = np.random.default_rng(11)
+    cams = synth.make_cameras(3)
+    cases = [s * (_K(skew=0.7) @ np.linalg.inv(c)[:3, :4]) for c in cams[:4] for s in (1.0, -2.5)]
+    for flip in (np.diag([-1.0, -1.0, 1.0]), np.diag([-1.0, 1.0, -1.0]), np.diag([1.0, -1.0, -1.0])):       # K with negative entries
+        cases.append((_K() @ flip) @ np.linalg.inv(cams[1])[:3, :4])
+    cases += [rng.standard_normal((3, 4)) for _ in range(8)]
+    for P in cases:
+        for dt, tol in ((np.float64, 1e-12), (np.float32, 2e-6)):
+            K, R, t = cvd.decompose_projection_matrix(P.astype(dt))
+            assert K.dtype == R.dtype == t.dtype == dt and t.shape == (4, 1)
+            scale = np.abs(P[:, :3]).max()
+            assert np.abs(K.astype(np.float64) @ R.astype(np.float64) - P[:, :3]).max() < tol * 10 * scale
+            assert K[1, 0] == 0 and K[2, 0] == 0 and K[2, 1] == 0 and K[0, 0] > 0 and K[1, 1] > 0
+            assert np.abs(R.astype(np.float64) @ R.astype(np.float64).T - np.eye(3)).max() < tol * 10
+            assert abs(np.linalg.det(R.astype(np.float64)) - 1.0) < tol * 10
+            assert np.sign(K[2, 2]) == np.sign(np.linalg.det(P[:, :3]))          # the last diagonal entry keeps det(M)'s sign
+            assert np.abs(P @ t.astype(np.float64)).max() < tol * 10 * np.abs(P).max()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_load_K_Rt_from_P_equals_the_opencv_route(dtype):
+    """dataset.py:14-35 = cv.decomposeProjectionMatrix + IDR's post-processing, on the restated OpenCV routine, against this
+    package's load_K_Rt_from_P (scipy RQ + explicit signs) on what the reference feeds it: P = (world_mat @ scale_mat)[:3, :4] of
+    DTU-style cameras (dataset.py:84-90: float32; positive scale, skewed and unskewed K, off-centre principal points)."""
+    from oracle import opencv_decompose as cvd
+    cams = synth.make_cameras(5)
+    scale_mat = np.diag([1.7, 1.7, 1.7, 1.0])
+    scale_mat[:3, 3] = [0.2, -0.1, 0.05]
+    n = 0
+    for c2w in cams[:8]:
+        for K in (_K(), _K(skew=0.7), _K(f=2892.3, w=1600, h=1200), _K(f=20.0, w=16, h=12)):
+            world = np.eye(4)
+            world[:3, :4] = K @ np.linalg.inv(c2w)[:3, :4]
+            P = (world @ scale_mat)[:3, :4].astype(dtype)
+            ref_intr, ref_pose = cvd.load_K_Rt_from_P_reference(P)
+            intr, pose = dataset.load_K_Rt_from_P(P)
+            tol = 1e-9 if dtype == np.float64 else 3e-6              # (float32: OpenCV hands K, R, t back rounded to P's type)
+            assert np.abs(intr - ref_intr).max() <= tol * np.abs(ref_intr).max()
+            assert np.abs(pose.astype(np.float64) - ref_pose.astype(np.float64)).max() <= max(tol, 2e-6)
+            assert intr.dtype == ref_intr.dtype == np.float64 and pose.dtype == ref_pose.dtype == np.float32
+            n += 1
+    assert n == 32
+
+
 def _write_scene(root, rgba, with_depth, n=3, H=12, W=16):
     from PIL import Image
     rng = np.random.default_rng(5)
@@ -170,6 +219,6 @@ def test_scene_files_decode_to_the_reference_constructor_arrays(tmp_path, rgba):
     assert np.array_equal(sc.images, fx[tag + "__images"]) and np.array_equal(sc.masks, fx[tag + "__masks"])
     if rgba:
         assert np.abs(sc.depth_feats - fx["rgba__depth_feats"]).max() <= 1e-7
-    # cameras: K [R|t] written, decomposed back (load_K_Rt_from_P itself is pinned by construction only: OpenCV is absent)
+    # cameras: K [R|t] written, decomposed back (load_K_Rt_from_P against OpenCV's restated routine: test_load_K_Rt_from_P_equals_the_opencv_route)
     np.testing.assert_allclose(sc.pose_all, fx["pose_all"], atol=3e-6)
     np.testing.assert_allclose(sc.intrinsics_all[:, :3, :3], fx["intrinsics_all"][:, :3, :3], rtol=1e-5, atol=1e-4)
