@@ -563,7 +563,7 @@ class TrainEngine:
         vdn_beside = self.wdepth and self._side2 is not None and not self.dbc     # (depth_before_color: the colour head reads the VDN output)
         if self.wdepth:
             if vdn_beside:
-                self._ev_fork2.record(torch.cuda.current_stream())
+                self._ev_fork2.record(lib.current_stream())
                 self._side2.wait_event(self._ev_fork2)
                 rnet("vdn", w["vdn_out"], w["vdn_h"], w["vdn_small"], 96, r.depth_network, stream=self._side2.cuda_stream)
                 self._ev_join2.record(self._side2)
@@ -572,7 +572,7 @@ class TrainEngine:
         if not self._color_fused:
             rnet("color", w["col_out"], w["col_h"], w["col_small"], 3, r.color_network)
         if vdn_beside:
-            torch.cuda.current_stream().wait_event(self._ev_join2)
+            lib.current_stream().wait_event(self._ev_join2)
 
         c = self._composite_common(lib.VdnCompositeArgs(), rays_o, rays_d, background_rgb, cos_anneal_ratio)
         c.weights, c.alpha_out, c.cdf, c.inside_sphere = w["weights"].data_ptr(), w["alpha"].data_ptr(), w["cdf"].data_ptr(), w["inside"].data_ptr()
@@ -615,7 +615,7 @@ class TrainEngine:
     # ---- optional side stream for the background network (VDN_SIDE_STREAM=1; default: everything on the caller's stream)
     def _fork(self):
         if self._side is not None:
-            self._ev_fork.record(torch.cuda.current_stream())
+            self._ev_fork.record(lib.current_stream())
             self._side.wait_event(self._ev_fork)
 
     def _side_handle(self, main_handle):
@@ -628,7 +628,7 @@ class TrainEngine:
 
     def _join(self):
         if self._side is not None and self._pending:
-            torch.cuda.current_stream().wait_event(self._ev_join)
+            lib.current_stream().wait_event(self._ev_join)
             self._pending = False
 
     def _tail_wanted(self):
@@ -791,7 +791,7 @@ class TrainEngine:
             tab, n, wgs = self.dw_groups[group]
             lib.call("vdn_dw_gemm" + self.sfx, lib.ptr(tab), n, wgs, stream)
         if gemm_event is not None:
-            gemm_event.record(event_stream if event_stream is not None else torch.cuda.current_stream())
+            gemm_event.record(event_stream if event_stream is not None else lib.current_stream())
         if group in self.fin_groups:
             tab, n, max_m, phase1 = self.fin_groups[group]
             lib.call("vdn_dw_finalize", lib.ptr(tab), n, max_m, 0, stream)
@@ -904,6 +904,13 @@ class TrainEngine:
             else:
                 self._fork()
             lib.call("vdn_nerf_mlp_bwd" + self.sfx, nb, self._side_handle(st))
+            # render()'s autograd node (no deferred half): the background network's weight gradients follow its backward on the side
+            # stream, beside the heads' and the SDF network's backward on the caller's, instead of waiting in one GEMM launch for
+            # all groups behind everything else (the Trainer's schedule, DESIGN.md 3d, minus its deferral past the step's end)
+            split_dw = (not defer_rest and self._side is not None and not rg and os.environ.get("VDN_BWD_SPLIT_DW", "1") != "0"
+                        and all(k in self.dw_groups for k in ("sdf", "heads", "nerf")))
+            if split_dw:
+                self.weight_grads("nerf", self._side.cuda_stream)
             self._side_done()
 
         def rnet_bwd(net, g_out, out, save_h, dout, dh, d_out, module, accumulate):
@@ -927,7 +934,7 @@ class TrainEngine:
         if self.wdepth:
             rnet_bwd("vdn", w["d_vdn"], w["vdn_out"], w["vdn_h"], w["vdn_dout"], w["vdn_dh"], 96, r.depth_network, True)
         if defer_rest and self._side is not None and heads_event:
-            self._ev_heads.record(torch.cuda.current_stream())      # the heads' deltas (operands of the rest group) are complete
+            self._ev_heads.record(lib.current_stream())      # the heads' deltas (operands of the rest group) are complete
 
         rb = lib.VdnSdfRbarArgs()
         img = self.nets["sdf"].img
@@ -960,13 +967,18 @@ class TrainEngine:
                 raise ValueError("defer_rest is the Trainer's path: no ray gradients there")
             self.weight_grads("sdf", st, gemm_event)
             return self._grad_flat
-        self._join()
-        self._launch_dw()
-        lib.call("vdn_dw_finalize", lib.ptr(self.fin_table), self.n_fin, self.fin_max_M, 0, st)
-        if self.fin_has_phase1:
-            lib.call("vdn_dw_finalize", lib.ptr(self.fin_table), self.n_fin, self.fin_max_M, 1, st)
-        if self.n_wn:
-            lib.call("vdn_weightnorm_bwd", lib.ptr(self.wn_table), self.n_wn, self.wn_max_rows, st)
+        if r.n_outside > 0 and split_dw:
+            self.weight_grads("sdf", st)
+            self.weight_grads("heads", st)
+            self._join()
+        else:
+            self._join()
+            self._launch_dw()
+            lib.call("vdn_dw_finalize", lib.ptr(self.fin_table), self.n_fin, self.fin_max_M, 0, st)
+            if self.fin_has_phase1:
+                lib.call("vdn_dw_finalize", lib.ptr(self.fin_table), self.n_fin, self.fin_max_M, 1, st)
+            if self.n_wn:
+                lib.call("vdn_weightnorm_bwd", lib.ptr(self.wn_table), self.n_wn, self.wn_max_rows, st)
         if rg:
             ra = lib.VdnRayAdjointArgs()
             ra.rays_d, ra.mid_z = rays_d.data_ptr(), w["mid_z"].data_ptr()

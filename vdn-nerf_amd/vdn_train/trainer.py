@@ -186,7 +186,7 @@ class Trainer:
         if not late_join:
             self.join()
         elif self._ws_pending:
-            torch.cuda.current_stream().wait_event(self._ev_ws)       # (same-box A/B against the unordered arm: + 5 us per step)
+            lib.current_stream().wait_event(self._ev_ws)       # (same-box A/B against the unordered arm: + 5 us per step)
             self._ws_pending = False
         depth_on = self.conf["extract_depth"] and self.iter_step > self.conf["depth_start_iter"] and gt_feats is not None
         # Plain configuration (one rank, no mask, no mask loss, no VDN head): compositor, colour-term gradient and the compositor's
@@ -249,7 +249,7 @@ class Trainer:
                 from vdn_hip.train import shared_stream
                 self._log_stream = shared_stream(self.dev, "log")
             ls = self._log_stream
-            self._ev_comp.record(torch.cuda.current_stream())
+            self._ev_comp.record(lib.current_stream())
             ls.wait_event(self._ev_comp)
             if fused_wd:
                 # (the kernel rewrites the gradients with the values the compositor's launches made: into copies, since the
@@ -330,7 +330,7 @@ class Trainer:
             # take 55 us alone. Measured (same box, 3 alternating runs each): 1.410 ms / step against 1.427 with one GEMM for both
             # halves behind the SDF GEMM; deferring the background half too (its next forward has slack) costs 1.48 - its GEMM
             # then starves the sampler's 256-workgroup SDF passes (150 us for an 18-us pass)
-            self._ev_tail.record(torch.cuda.current_stream())
+            self._ev_tail.record(lib.current_stream())
             eng.side_weight_grads("heads", after=self._ev_tail, gemm_event=self._ev_ws)
             self._ws_pending = True
             with torch.cuda.stream(side):
@@ -358,7 +358,7 @@ class Trainer:
                         self._rest_gen += 1
                     self._rest_pending = True
         if fused:
-            torch.cuda.current_stream().wait_event(self._ev_log)      # the scalars (long done) are ordered in front of what follows
+            lib.current_stream().wait_event(self._ev_log)      # the scalars (long done) are ordered in front of what follows
         self.iter_step += 1
         return self.scalars        # device tensor [loss, color_loss, psnr, eikonal, depth_loss, mask_loss]; no host sync here
 
@@ -377,7 +377,7 @@ class Trainer:
         # path, and the forward asks once per network: tools/dev/gap_probe.py), while a single flag cleared by a wait on one
         # stream would leave a step issued on another stream unordered.
         if self._rest_pending:
-            cur = torch.cuda.current_stream()
+            cur = lib.current_stream()
             if self._joined.get(cur.cuda_stream) != self._rest_gen or os.environ.get("VDN_EVENT_TRIM", "1") == "0":
                 cur.wait_event(self._ev_rest)
                 self._joined[cur.cuda_stream] = self._rest_gen
