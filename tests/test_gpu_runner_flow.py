@@ -230,3 +230,33 @@ def test_render_under_grad_on_the_work_list_equals_every_sample(precision, wdept
         tol = 2e-5 if precision == "fp32" else 2e-3
         assert float((g - g_ref).abs().max()) <= tol * float(g_ref.abs().max()), (aux_loss, float((g - g_ref).abs().max()), float(g_ref.abs().max()))
         assert float(g_ref.abs().max()) > 0
+
+
+def test_engines_of_alternating_batch_sizes_stay_alive():
+    """The runner alternates between its training batch and the (ragged) chunks of its image loops: the training engines of the
+    three most recently used batch sizes are kept, a fourth size evicts the least recently used one, and results do not depend on
+    what was rendered in between."""
+    from vdn_train import synth, factory
+    dev = torch.device("cuda:0")
+    rend = factory.build_renderer(device=dev, states=synth.make_all_states(1, variance=0.4), precision="bf16")
+    cams = synth.make_cameras(1)
+    tt = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32, device=dev)
+
+    def run(B):
+        o, d = synth.random_pixel_batch(1, 0, 2, B, cams=cams)
+        near, far = synth.near_far_from_sphere(o, d)
+        t1, t2 = synth.jitter(1, 0, B)
+        out = rend.render(tt(o), tt(d), tt(near), tt(far), background_rgb=torch.ones(1, 3, device=dev), cos_anneal_ratio=1.0,
+                          t_rand=tt(t1), t_rand_out=tt(t2))
+        return out["color_fine"].detach().clone()
+
+    first = run(64)
+    eng64 = rend.__dict__["_engines"][next(k for k in rend.__dict__["_engines"] if k[0] == 64)]
+    run(37)
+    again = run(64)
+    engines = rend.__dict__["_engines"]
+    assert sorted(k[0] for k in engines) == [37, 64] and any(e is eng64 for e in engines.values())
+    assert torch.equal(first, again)
+    run(20)
+    run(11)                                                   # a fourth size: 37, the least recently used, goes
+    assert sorted(k[0] for k in rend.__dict__["_engines"]) == [11, 20, 64]

@@ -567,11 +567,20 @@ class NeuSRenderer:
         from vdn_hip.train import TrainEngine
         B, dev = rays_o.shape[0], rays_o.device
         engines = self.__dict__.setdefault("_engines", {})
-        key = (B, dev, tuple(p.data_ptr() for p in params))
-        eng = engines.get(key)
+        pkey = (dev, tuple(p.data_ptr() for p in params))
+        key = (B,) + pkey
+        eng = engines.pop(key, None)
         if eng is None:
-            engines.clear()                      # one live engine: its workspaces are GBs at B = 512
-            eng = engines[key] = TrainEngine(self, B, dev)
+            # An engine is built for one batch size (its workspaces are a few GB at B = 512, of 288). The runner alternates between
+            # its training batch and the chunks of its image loops, whose last chunk per image is ragged (dpt_runner.py:439-445):
+            # the three most recently used sizes stay alive instead of being rebuilt twice per image. Engines of re-allocated
+            # parameters go at once.
+            for k in [k for k in engines if k[1:] != pkey]:
+                del engines[k]
+            while len(engines) >= 3:
+                del engines[next(iter(engines))]             # (dicts keep insertion order: the least recently used one)
+            eng = TrainEngine(self, B, dev)
+        engines[key] = eng                                   # (re-inserted: most recently used)
         bgc = None
         if background_rgb is not None:
             bgc = background_rgb.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
