@@ -416,7 +416,7 @@ class Leg:
                 "traffic": traffic, "kernel_ms": tdw * 1e3, "tflops": dw_flops / tdw / 1e12}
 
 
-def runner_flow(args, dev, precision, steps, warmup=5):
+def runner_flow(args, dev, precision, steps, warmup=5, wdepth=False):
     """What an UNCHANGED dpt_runner.py executes on the drop-in classes (dpt_runner.py:117-144, 197-257): networks from the conf's
     kwargs, torch.optim.Adam over .parameters(), per iteration render() under grad (one autograd node) -> the runner's torch
     loss -> zero_grad -> loss.backward() -> optimizer.step(); the jitter from torch.rand inside render(). The path of
@@ -424,7 +424,7 @@ def runner_flow(args, dev, precision, steps, warmup=5):
     import torch.nn.functional as F
     from vdn_train import synth, factory
     seed = 0
-    rend = factory.build_renderer(wdepth=False, device=dev, states=synth.make_all_states(seed), precision=precision)
+    rend = factory.build_renderer(wdepth=wdepth, device=dev, states=synth.make_all_states(seed, wdepth=wdepth), precision=precision)
     params = rend._all_parameters()
     opt = torch.optim.Adam(params, lr=5e-4)
     cams = synth.make_cameras(seed)
@@ -436,6 +436,7 @@ def runner_flow(args, dev, precision, steps, warmup=5):
         near, far = synth.near_far_from_sphere(o, d)
         batches.append((g(o), g(d), g(near), g(far), g(synth.target_colors(o, d))))
     bg = torch.ones([1, 3], device=dev)
+    gt_feats = torch.rand(B, 96, device=dev) if wdepth else None
 
     def step(i):
         rays_o, rays_d, near, far, true_rgb = batches[i % len(batches)]
@@ -446,6 +447,9 @@ def runner_flow(args, dev, precision, steps, warmup=5):
         color_fine_loss = F.l1_loss(color_error, torch.zeros_like(color_error), reduction="sum") / mask_sum
         mask_loss = F.binary_cross_entropy(out["weight_sum"].clip(1e-3, 1.0 - 1e-3), mask)
         loss = color_fine_loss + out["gradient_error"] * 0.1 + mask_loss * 0.0
+        if wdepth:          # womsk_white_wdepth behind depth_start_iter (dpt_runner.py:239-243)
+            depth_feat_error = (out["render_feats"] - gt_feats) * mask
+            loss = loss + F.l1_loss(depth_feat_error, torch.zeros_like(depth_feat_error), reduction="sum") / mask_sum * 0.5
         opt.zero_grad()
         loss.backward()
         opt.step()
@@ -644,8 +648,10 @@ def main():
             extras["runner_flow"] = {"what": "render() under grad -> torch loss -> loss.backward() -> torch.optim.Adam.step() through the drop-in "
                                              "classes (dpt_runner.py:214-257), 512 rays per step, default jitter; image_loop_*: "
                                              "render() with autograd on and no backward, the runner's validate_image / val_img chunks "
-                                             "(dpt_runner.py:439-445)",
-                                     "bf16": runner_flow(args, dev, "bf16", K), "fp32": runner_flow(args, dev, "fp32", max(4, K // 4))}
+                                             "(dpt_runner.py:439-445); bf16_wdepth: womsk_white_wdepth (VDN head + the depth-feature loss, "
+                                             "dpt_runner.py:239-243)",
+                                     "bf16": runner_flow(args, dev, "bf16", K), "fp32": runner_flow(args, dev, "fp32", max(4, K // 4)),
+                                     "bf16_wdepth": runner_flow(args, dev, "bf16", K, wdepth=True)}
             torch.cuda.empty_cache()
         rc = real_cameras()
         if rc is not None and args.crop is None:
