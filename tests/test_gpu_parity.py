@@ -977,3 +977,45 @@ def test_fused_sampler_rounds_equal_the_two_launch_rounds(monkeypatch):
             if v is not None:
                 assert torch.equal(v, b[k]), k
     assert torch.isfinite(outs["1"][0]["z_vals"]).all()
+
+
+@pytest.mark.parametrize("B,N,radius", [(1, 128, 1.2), (37, 128, 1.2), (512, 128, 1.2), (65, 64, 0.9), (300, 130, 5.0), (300, 130, 1e-3)])
+def test_foreground_list_and_its_complement_partition_the_samples(dev, B, N, radius):
+    """vdn_foreground_active and its `complement` form (include/vdn_render.h; render() under grad evaluates the SDF network with
+    saves on the first list and without on the second): dense ids ascending in both, disjoint, together every sample of every
+    ray, and the listed ones are exactly those whose mid-point lies within `radius` by the compositor's own float expression -
+    ragged sizes, the empty list (radius 5: everything inside; 1e-3: nothing) and NaN depths included (a NaN norm fails `<`: it
+    belongs to the complement)."""
+    from vdn_hip import lib
+    rng = np.random.default_rng(B * 1000 + N)
+    o = rng.standard_normal((B, 3)).astype(np.float32) * 1.5
+    d = rng.standard_normal((B, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    mid = np.sort(rng.uniform(0.0, 4.0, (B, N)).astype(np.float32), axis=1)
+    if B > 1:
+        mid[B // 2, N // 3] = np.nan
+    to, td, tm = (torch.tensor(x).to(dev) for x in (o, d, mid))
+    lists = []
+    for comp in (0, 1):
+        idx = torch.full((B * N,), -1, dtype=torch.int32, device=dev)
+        n = torch.zeros(1, dtype=torch.int32, device=dev)
+        cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+        a = lib.VdnForegroundActiveArgs()
+        a.rays_o, a.rays_d, a.mid_z, a.B, a.N, a.radius, a.complement = to.data_ptr(), td.data_ptr(), tm.data_ptr(), B, N, radius, comp
+        a.active_idx, a.n_active, a.ray_counts = idx.data_ptr(), n.data_ptr(), cnt.data_ptr()
+        lib.call("vdn_foreground_active", a, torch.cuda.current_stream().cuda_stream)
+        k = int(n.item())
+        got = idx.cpu().numpy()
+        assert (got[k:] == -1).all()                           # nothing written behind the count
+        lists.append(got[:k])
+    fg, rest = lists
+    assert len(fg) + len(rest) == B * N
+    assert (np.diff(fg) > 0).all() and (np.diff(rest) > 0).all()
+    assert np.array_equal(np.sort(np.concatenate([fg, rest])), np.arange(B * N))
+    # the compositor's expression, operation for operation in float32 (no contraction)
+    x = o[:, None, 0] + d[:, None, 0] * mid
+    y = o[:, None, 1] + d[:, None, 1] * mid
+    w = o[:, None, 2] + d[:, None, 2] * mid
+    pn = np.sqrt(((x * x).astype(np.float32) + (y * y).astype(np.float32)).astype(np.float32) + (w * w).astype(np.float32), dtype=np.float32)
+    want = np.flatnonzero((pn < np.float32(radius)).reshape(-1))
+    assert np.array_equal(fg, want.astype(np.int32))
