@@ -260,3 +260,51 @@ def test_engines_of_alternating_batch_sizes_stay_alive():
     run(20)
     run(11)                                                   # a fourth size: 37, the least recently used, goes
     assert sorted(k[0] for k in rend.__dict__["_engines"]) == [11, 20, 64]
+
+
+@pytest.mark.parametrize("kind", ["all_listed", "none_listed", "single_ray"])
+def test_render_under_grad_with_an_empty_list_or_an_empty_complement(kind):
+    """The edges of the autograd node's work list: rays through the centre (every inside sample within the relaxed sphere: the
+    complement launch has no rows), rays that pass the sphere at a distance (no sample listed: the training launches, the
+    backward and the GEMM's SDF entries have no rows) and a batch of one ray - outputs bit for bit those of the evaluation of every
+    sample, finite gradients equal to its to the GEMM's summation order."""
+    import os
+    from vdn_train import synth, factory
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(7)
+    B = 1 if kind == "single_ray" else 8
+    d = rng.standard_normal((B, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    if kind == "none_listed":
+        perp = np.cross(d, np.array([0.3, -0.5, 0.8], np.float32))
+        perp /= np.linalg.norm(perp, axis=1, keepdims=True)
+        o = (perp * 2.5 - d * 3.0).astype(np.float32)          # closest approach 2.5 from the origin
+    else:
+        o = (-d * 3.0 + rng.standard_normal((B, 3)).astype(np.float32) * (0.01 if kind == "all_listed" else 0.3)).astype(np.float32)
+    near, far = synth.near_far_from_sphere(o, d)
+    tt = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32, device=dev)
+    t1, t2 = synth.jitter(3, 0, B)
+
+    def run(compact):
+        os.environ["VDN_RENDER_FG_COMPACT"] = compact
+        try:
+            rend = factory.build_renderer(device=dev, states=synth.make_all_states(3, variance=0.4), precision="bf16")
+            out = rend.render(tt(o), tt(d), tt(near), tt(far), background_rgb=torch.ones(1, 3, device=dev), cos_anneal_ratio=0.3,
+                              t_rand=tt(t1), t_rand_out=tt(t2))
+            ((out["color_fine"] - 0.3).abs().sum() / B + 0.1 * out["gradient_error"]).backward()
+            eng = next(iter(rend.__dict__["_engines"].values()))
+            grads = torch.cat([(torch.zeros_like(p) if p.grad is None else p.grad).reshape(-1) for p in rend._all_parameters()])
+            return {k: v.detach().clone() for k, v in out.items() if v is not None}, grads, int(eng.w["fg_active"][1])
+        finally:
+            del os.environ["VDN_RENDER_FG_COMPACT"]
+
+    ref, g_ref, _ = run("0")
+    out, g, n = run("1")
+    if kind == "all_listed":
+        assert n == B * 128
+    if kind == "none_listed":
+        assert n == 0
+    for k in ref:
+        assert torch.equal(out[k], ref[k]), k
+    assert torch.isfinite(g).all() and torch.isfinite(g_ref).all()
+    assert float((g - g_ref).abs().max()) <= 2e-3 * float(g_ref.abs().max()) + 1e-12
