@@ -262,8 +262,9 @@ def test_engines_of_alternating_batch_sizes_stay_alive():
     assert sorted(k[0] for k in rend.__dict__["_engines"]) == [11, 20, 64]
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
 @pytest.mark.parametrize("kind", ["all_listed", "none_listed", "single_ray"])
-def test_render_under_grad_with_an_empty_list_or_an_empty_complement(kind):
+def test_render_under_grad_with_an_empty_list_or_an_empty_complement(kind, precision):
     """The edges of the autograd node's work list: rays through the centre (every inside sample within the relaxed sphere: the
     complement launch has no rows), rays that pass the sphere at a distance (no sample listed: the training launches, the
     backward and the GEMM's SDF entries have no rows) and a batch of one ray - outputs bit for bit those of the evaluation of every
@@ -288,7 +289,7 @@ def test_render_under_grad_with_an_empty_list_or_an_empty_complement(kind):
     def run(compact):
         os.environ["VDN_RENDER_FG_COMPACT"] = compact
         try:
-            rend = factory.build_renderer(device=dev, states=synth.make_all_states(3, variance=0.4), precision="bf16")
+            rend = factory.build_renderer(device=dev, states=synth.make_all_states(3, variance=0.4), precision=precision)
             out = rend.render(tt(o), tt(d), tt(near), tt(far), background_rgb=torch.ones(1, 3, device=dev), cos_anneal_ratio=0.3,
                               t_rand=tt(t1), t_rand_out=tt(t2))
             ((out["color_fine"] - 0.3).abs().sum() / B + 0.1 * out["gradient_error"]).backward()
@@ -307,4 +308,4 @@ def test_render_under_grad_with_an_empty_list_or_an_empty_complement(kind):
     for k in ref:
         assert torch.equal(out[k], ref[k]), k
     assert torch.isfinite(g).all() and torch.isfinite(g_ref).all()
-    assert float((g - g_ref).abs().max()) <= 2e-3 * float(g_ref.abs().max()) + 1e-12
+    assert float((g - g_ref).abs().max()) <= (2e-3 if precision == "bf16" else 2e-5) * float(g_ref.abs().max()) + 1e-12
