@@ -59,6 +59,25 @@ static void append_layer(std::vector<char>& blob, const LayerSpec& L, int stride
     }
 }
 
+// the 16x16x32 image of a chunk stream (k_sdf_fwd2.h, shape 1): a permutation of each chunk's 16-byte fragment units -
+// new fragment 2T + fh, lane r16 + 16 q  <-  old fragment 2T + (q >> 1), lane phi(fh, r16) + 32 (q & 1),
+// phi(fh, 4 q' + i) = 16 (q' >> 1) + 8 fh + 4 (q' & 1) + i; bias block and tail unchanged
+static std::vector<char> to_s16(const std::vector<char>& blob, int stride, const std::vector<int>& kts) {
+    std::vector<char> out = blob;
+    for (size_t ch = 0; ch < kts.size(); ++ch) {
+        const char* src = blob.data() + ch * stride;
+        char* dst = out.data() + ch * stride;
+        for (int T = 0; T < kts[ch]; ++T)
+            for (int fh = 0; fh < 2; ++fh)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int r16 = lane & 15, q = lane >> 4, qq = r16 >> 2, i = r16 & 3;
+                    const int phi = 16 * (qq >> 1) + 8 * fh + 4 * (qq & 1) + i;
+                    memcpy(dst + ((2 * T + fh) * 64 + lane) * 16, src + ((2 * T + (q >> 1)) * 64 + phi + 32 * (q & 1)) * 16, 16);
+                }
+    }
+    return out;
+}
+
 int main(int argc, char** argv) {
     const int P = argc > 1 ? atoi(argv[1]) : 65536;
     const int rounds = argc > 2 ? atoi(argv[2]) : 10;
@@ -116,6 +135,17 @@ int main(int argc, char** argv) {
         LayerSpec L2 = L; L2.scale = fw[l].sc / 255.0f;                              // v2 sweeps 255 sigma
         append_layer(b_full2, L2, stride, lin[8].w.data());
     }
+    // k-tiles per chunk of the v2 streams, in stream order
+    std::vector<int> kt_sdf2, kt_full2;
+    {
+        const int fk[9] = {2, 8, 8, 8, 9, 8, 8, 8, 8}, fn[8] = {8, 8, 8, 7, 8, 8, 8, 8};
+        for (int l = 0; l < 8; ++l) for (int t = 0; t < fn[l]; ++t) { kt_sdf2.push_back(fk[l]); kt_full2.push_back(fk[l]); }
+        kt_sdf2.push_back(8);
+        for (int t = 0; t < 9; ++t) kt_full2.push_back(8);
+        for (int l = 7; l >= 0; --l) for (int t = 0; t < fk[l]; ++t) kt_full2.push_back(fn[l]);
+    }
+    if (kt_sdf2.size() * stride != b_sdf2.size() || kt_full2.size() * stride != b_full2.size()) { printf("chunk table mismatch\n"); return 1; }
+    const std::vector<char> b_sdf2x = to_s16(b_sdf2, stride, kt_sdf2), b_full2x = to_s16(b_full2, stride, kt_full2);
     printf("streams: sdf %zu full %zu sdf2 %zu full2 %zu chunks\n", b_sdf.size() / stride, b_full.size() / stride, b_sdf2.size() / stride, b_full2.size() / stride);
 
     // inputs: points in the unit ball region
@@ -128,6 +158,8 @@ int main(int argc, char** argv) {
     char* d_full = (char*)dev(b_full.data(), b_full.size());
     char* d_sdf2 = (char*)dev(b_sdf2.data(), b_sdf2.size());
     char* d_full2 = (char*)dev(b_full2.data(), b_full2.size());
+    char* d_sdf2x = (char*)dev(b_sdf2x.data(), b_sdf2x.size());
+    char* d_full2x = (char*)dev(b_full2x.data(), b_full2x.size());
     float* d_pts = (float*)dev(pts.data(), pts.size() * 4);
     const size_t Pp = ((size_t)P + 127) / 128 * 128;
     float* d_out_sdf = (float*)dev(nullptr, Pp * 4);
@@ -151,8 +183,9 @@ int main(int argc, char** argv) {
     const double F1 = 1967104.0 * P, F0 = 918016.0 * P;
     auto with = [&](const char* blob, void* H, void* V, void* PE) { VdnSdfArgs a = A; a.blob = blob; a.H = H; a.V = V; a.PE = PE; return a; };
 #define V2(TAG, M, S) vs.push_back({std::string("v2 mode") + #M + (S ? " training saves " : " ") + #TAG, [&] { \
-        VdnSdfArgs a = M == 0 ? with(d_sdf2, nullptr, nullptr, nullptr) : (S ? with(d_full2, d_H, d_V, d_PE) : with(d_full2, nullptr, nullptr, nullptr)); \
-        if (std::string(#TAG).rfind("st_", 0) == 0) a.PE = d_PE; \
+        const bool x16 = std::string(#TAG).find("s16") != std::string::npos; \
+        VdnSdfArgs a = M == 0 ? with(x16 ? d_sdf2x : d_sdf2, nullptr, nullptr, nullptr) : (S ? with(x16 ? d_full2x : d_full2, d_H, d_V, d_PE) : with(x16 ? d_full2x : d_full2, nullptr, nullptr, nullptr)); \
+        if (std::string(#TAG).rfind("st_", 0) == 0 && !S) a.PE = d_PE; \
         sdf2_launch_##TAG(&a, st); }, M == 0 ? F0 : F1});
 #include "sdf2_variants.inc"
 #undef V2

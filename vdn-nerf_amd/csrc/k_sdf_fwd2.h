@@ -40,6 +40,10 @@ namespace sdf2 {
 #ifndef VDN_SDF2_ABL
 #define VDN_SDF2_ABL 0   // timing-only ablations (development harness), bit mask: 1 no epilogue math, 2 no MFMA, 4 no weight DMA, 8 no chunk barrier
 #endif
+#ifndef VDN_SDF2_S16
+#define VDN_SDF2_S16 0   // MFMA shape of the chunk steps: 0 = v_mfma_f32_32x32x16_bf16, 1 = v_mfma_f32_16x16x32_bf16 (same 32-point x 32-feature tile per wave)
+#endif
+constexpr bool kS16 = VDN_SDF2_S16 != 0;
 constexpr int kStride = 20480;          // BF16::stride(9)
 constexpr int kTail = 9 * 2048 + 1024;  // row 0 of W8 (f32 x 256) in every chunk's tail (vdn_hip/images.py: SDF_TAIL_OFF)
 constexpr int kWaves = 4;
@@ -49,6 +53,54 @@ constexpr int kGroup = VDN_SDF2_GROUP;  // MFMAs per scheduling group (the epilo
 constexpr float kC1 = 144.26950408889634f;    // 100 log2(e)
 constexpr float kVSave = kC1 / 255.0f;        // 255 sigma u -> saved V plane (100 log2(e) v)
 constexpr int kSTiles = 63;             // softplus' tiles per point block: 8 + 8 + 8 + 7 + 8 + 8 + 8 + 8
+
+// ---- the two MFMA shapes ------------------------------------------------------------------------------------------
+// Shape 0 (32x32x16): lane = c + 32 h owns point c; accumulator register t = feature (t&3) + 8 (t>>2) + 4 h (vdn_common.h).
+// Shape 1 (16x16x32, round 6: the shape on which the chip holds the higher clock - MI355X_MICROARCH.md, DVFS give-back item 7):
+// the wave's 32 x 32 tile is four 16 x 16 accumulators [ph][fh] (point half, feature half); lane = c16 + 16 q owns points c16 and
+// c16 + 16, and LOGICAL accumulator register t = 8 ph + 4 fh + i is MFMA row 4 q + i of feature half fh. The weight image
+// ("sdf2x" / "full2x" / "c2x", vdn_hip/images.py) assigns MFMA row 4 q + i of half fh to feature 16 (q>>1) + 8 fh + 4 (q&1) + i, so
+// that registers 8 ph .. 8 ph + 7 of lane (c16, q) are - as in shape 0 - one 16-byte unit of the PT32 plane layout
+// (mlp_engine.h): unit (k = q>>1, h = q&1) of point 16 ph + c16, and the B fragment of k-step T for point half ph IS tile T's
+// packed unit. Planes, bias blocks and tails are the same bytes in both shapes; the A fragments are a permutation of 16-byte units.
+// Per-point scalar work (encoding, its adjoint, outputs) stays on the "home" lanes of shape 0 (lane c + 32 h); operands cross
+// between the two lane geometries through a wave-private LDS scratch, three times per launch.
+#if VDN_SDF2_S16
+struct AccT {
+    f32x4 v[4];         // [2 ph + fh]
+    VDN_DEV float operator[](int t) const { return v[t >> 2][t & 3]; }
+    VDN_DEV void fill(const f32x4 (&bias)[4], bool with_bias) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) v[g] = with_bias ? bias[g & 1] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    // fragment s of a chunk = (k-step s >> 1 of 32 inputs, feature half s & 1), against both point halves
+    template <int S, class ActT>
+    VDN_DEV void mfma(const bf16x8& a, const ActT& X) {
+        v[S & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, X.r[S & ~1], v[S & 1], 0, 0, 0);
+        v[2 + (S & 1)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, X.r[(S & ~1) + 1], v[2 + (S & 1)], 0, 0, 0);
+    }
+    VDN_DEV void add(const AccT& o) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) v[g] += o.v[g];
+    }
+};
+#else
+struct AccT {
+    f32x16 w;
+    VDN_DEV float operator[](int t) const { return w[t]; }
+    VDN_DEV void fill(const f32x4 (&bias)[4], bool with_bias) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) w[t] = with_bias ? bias[t >> 2][t & 3] : 0.0f;
+    }
+    template <int S, class ActT>
+    VDN_DEV void mfma(const bf16x8& a, const ActT& X) { w = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, X.r[S], w, 0, 0, 0); }
+    VDN_DEV void add(const AccT& o) { w += o.w; }
+};
+#endif
+// accumulator registers 4 g .. 4 g + 3 of this lane are features 4 quad_of(g) .. + 3 of the tile's natural order
+VDN_DEV int quad_of(int g, int lane) { return kS16 ? 4 * (lane >> 5) + 2 * (g & 1) + ((lane >> 4) & 1) : 2 * g + (lane >> 5); }
+// the point half a logical register pair belongs to
+constexpr int ph_of_pair(int pr) { return kS16 ? pr >> 2 : 0; }
 
 // ---- compile-time program of the chunk stream -------------------------------------------------------------------
 // COL0 / COLH / COLOUT (MODE 2): the colour head behind the sweep (fields.py:148-176): first layer [feature (8 tiles) | points,
@@ -194,12 +246,11 @@ struct Pipe {
         const bf16x8* wa = reinterpret_cast<const bf16x8*>(w) + lane;
 #pragma unroll
         for (int s = 0; s < (kPre < 2 * KT ? kPre : 2 * KT); ++s) fr[s] = wa[s * 64];
-        if constexpr (BIAS) {
-            const f32x4* b = reinterpret_cast<const f32x4*>(w + KT * 2048);
-            const int h = lane >> 5;
+        if constexpr (BIAS) load_bias(reinterpret_cast<const f32x4*>(w + KT * 2048));
+    }
+    VDN_DEV void load_bias(const f32x4* b) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bias[q] = b[2 * q + h];
-        }
+        for (int g = 0; g < (kS16 ? 2 : 4); ++g) bias[g] = b[quad_of(g, lane)];
     }
 };
 
@@ -207,7 +258,7 @@ struct Pipe {
 // group gi of NG (kGroup MFMAs per group). Group 0 certifies chunk C+1; the DMA pieces of chunk C+DEPTH follow one per
 // group; the tail reads the opening fragments of chunk C+1.
 template <int MODE, bool SAVE, int NSLOT, int DEPTH, int C, class PipeT, class ActT, class Group>
-VDN_DEV f32x16 chunk_step(PipeT& pp, const ActT& X, Group&& group) {
+VDN_DEV AccT chunk_step(PipeT& pp, const ActT& X, Group&& group) {
     using PG = Prog<MODE>;
     constexpr int KT = PG::kt_of(C);
     constexpr bool BIAS = PG::bias_of(C);
@@ -218,19 +269,11 @@ VDN_DEV f32x16 chunk_step(PipeT& pp, const ActT& X, Group&& group) {
     const bf16x8* wa = reinterpret_cast<const bf16x8*>(pp.template slot<C>()) + pp.lane;
     const bf16x8* wn = reinterpret_cast<const bf16x8*>(pp.template slot<C + 1>()) + pp.lane;
     bf16x8 fr[NS];
-    f32x16 acc;
+    AccT acc;
     constexpr int PF = kPre < NS ? kPre : NS;                       // fragments of this chunk read by the previous step
     constexpr int PFN = kPre < 2 * KTN ? kPre : 2 * KTN;            // fragments of the next chunk this step reads
     static_for<PF>([&](auto s_c) VDN_INL { fr[decltype(s_c)::value] = pp.fr[decltype(s_c)::value]; });
-    if constexpr (BIAS) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            acc[4 * q + 0] = pp.bias[q][0]; acc[4 * q + 1] = pp.bias[q][1]; acc[4 * q + 2] = pp.bias[q][2]; acc[4 * q + 3] = pp.bias[q][3];
-        }
-    } else {
-#pragma unroll
-        for (int t = 0; t < 16; ++t) acc[t] = 0.0f;
-    }
+    acc.fill(pp.bias, BIAS);
     __builtin_amdgcn_sched_barrier(0);
     static_for<NG>([&](auto g_c) VDN_INL {
         constexpr int gi = decltype(g_c)::value;
@@ -240,7 +283,7 @@ VDN_DEV f32x16 chunk_step(PipeT& pp, const ActT& X, Group&& group) {
 #if VDN_SDF2_ABL & 2
             { const bf16x8 keep = fr[s]; asm volatile("" ::"v"(keep)); }
 #else
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[s], X.r[s], acc, 0, 0, 0);
+            acc.template mfma<s>(fr[s], X);
 #endif
         });
         if constexpr (gi == 0 && HAS_NEXT) {
@@ -271,9 +314,7 @@ VDN_DEV f32x16 chunk_step(PipeT& pp, const ActT& X, Group&& group) {
                 static_for<(PFN > PF ? PFN - PF : 0)>([&](auto e_c) VDN_INL { pp.fr[PF + decltype(e_c)::value] = wn[(PF + decltype(e_c)::value) * 64]; });
         });
         if constexpr (gi == NG - 1 && HAS_NEXT && KTN > 0 && PG::bias_of(C + 1)) {
-            const f32x4* b = reinterpret_cast<const f32x4*>(pp.template slot<C + 1>() + KTN * 2048);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) pp.bias[q] = b[2 * q + (pp.lane >> 5)];
+            pp.load_bias(reinterpret_cast<const f32x4*>(pp.template slot<C + 1>() + KTN * 2048));
         }
         group(g_c, std::integral_constant<int, NG>{});
         __builtin_amdgcn_sched_barrier(0);
@@ -422,6 +463,8 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
 #endif
     const bool ok = wr.ok;
     const long p = wr.row, pd = wr.point;
+    const int c16 = lane & 15, q4 = lane >> 4;      // shape 1: this lane's column of both 16-point halves, and its row quad
+    (void)c16; (void)q4;
 
     float xin[3];
     float px[3] = {0.0f, 0.0f, 0.0f}, dir[3] = {0.0f, 0.0f, 0.0f};     // MODE 2: the point and the view direction (the colour head's inputs)
@@ -451,6 +494,19 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
     ST* feat = reinterpret_cast<ST*>(a.feat);
     const long PS = P::plane(a.P, 256);
     const long prow = (p >> 5) * (32L * 256) + h * 256 + (p & 31) * 8;       // PT32 offset of this lane's 16-byte pieces (mlp_engine.h)
+    // shape 1: the lane's unit (k = q4 >> 1, h = q4 & 1) of its two points, rows clamped as work_row clamps them
+    long prow2[2] = {0, 0};
+    if constexpr (kS16) {
+        const long n_rows = a.active_idx != nullptr ? (long)*a.n_active : (long)a.P;
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            const long raw = ((long)blockIdx.x * kWaves + pp.wave) * 32 + 16 * ph + c16;
+            const long r = raw < n_rows ? raw : (n_rows > 0 ? n_rows - 1 : 0);
+            prow2[ph] = (r >> 5) * (32L * 256) + (q4 >> 1) * 512 + (q4 & 1) * 256 + (r & 31) * 8;
+        }
+    }
+    // element offset of 16-byte piece k of tile T in a [*, 256] PT32 plane: shape 0 k = the tile's k-step, shape 1 k = the point half
+    auto piece = [&](int T, int k) VDN_INL -> long { return kS16 ? prow2[k] + T * 1024 : prow + T * 1024 + 512 * k; };
     const float inv_scale = 1.0f / a.scale;
     // the input loads above have to be back first: the compiler waits for them with vmcnt(0), which would also wait for younger
     // warm-up loads; behind this wait the stream arrives in L2 while the encoding below is computed from registers
@@ -468,6 +524,23 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
     float col[3] = {0.0f, 0.0f, 0.0f};      // MODE 2: the sampled colour of this lane's point
     SStore<NLDS> SS;
     SS.lds = smem + kRing + kW8 + pp.wave * (NLDS * 1024) + lane * 16;
+    // shape 1: wave-private scratch for the crossings between home lanes and tile lanes. MODE >= 1: the wave's S region (not yet /
+    // no longer holding softplus' tiles when used); MODE 0: a piece of the ring's last slot, which no DMA touches before step 0
+    static_assert(!kS16 || MODE == 0 || NLDS * 1024 >= 32 * 272, "exchange scratch");
+    static_assert(!kS16 || NSLOT - 1 >= DEPTH, "the last ring slot is free at the start");
+    char* const xch = MODE >= 1 ? smem + kRing + kW8 + pp.wave * (NLDS * 1024) : smem + (NSLOT - 1) * kStride + pp.wave * 4096;
+    // NF fragments in home-lane form (unit (s, h, c) = lane c + 32 h of fragment s) -> the same units in tile-lane form:
+    // fragment 2 T + ph of lane (c16, q4) = unit (s = 2 T + (q4 >> 1), h = q4 & 1, c = 16 ph + c16)
+    auto to_tile_lanes = [&](bf16x8* fr, auto nf_c) VDN_INL {
+        constexpr int NF = decltype(nf_c)::value;
+#pragma unroll
+        for (int s = 0; s < NF; ++s) *reinterpret_cast<bf16x8*>(xch + s * 1024 + lane * 16) = fr[s];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < NF; ++s)
+            fr[s] = *reinterpret_cast<const bf16x8*>(xch + ((s & ~1) + (q4 >> 1)) * 1024 + (q4 & 1) * 512 + (16 * (s & 1) + c16) * 16);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
 
     // positional encoding in scaled units: X tiles 0,1 (layer 0) and a copy for the skip input of layer 4 (tiles 7,8):
     // tile 8 of X is not touched by anything else, tile 7's copy waits in registers
@@ -493,6 +566,7 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
                 for (int kt = 0; kt < 2; ++kt) P::store_tile(reinterpret_cast<ST*>(a.PE), p, 64, kt, h, vals_tile<64>(pe, h, kt), true);
             }
         }
+        if constexpr (kS16) to_tile_lanes(&X.r[0], std::integral_constant<int, 4>{});
         pe7[0] = X.r[0]; pe7[1] = X.r[1];
         X.r[16] = X.r[2]; X.r[17] = X.r[3];
     }
@@ -505,18 +579,41 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
     asm volatile("" ::: "memory");
     pp.template prefetch<0, 2, true>();
 
-    f32x16 acc_prev;            // accumulator of the previous chunk's tile (its epilogue runs under this chunk's MFMAs)
+    AccT acc_prev;              // accumulator of the previous chunk's tile (its epilogue runs under this chunk's MFMAs)
     u32x4 sq_prev;              // 255 sigma of the previous chunk's tile: read by the sweep's epilogue, built by a hidden layer's
     u32x4 sq_v7;                // 255 sigma_7 tile while v7 is formed
     unsigned hold0 = 0, hold1 = 0;  // a pair's values waiting for their partners (one 4-value pack / one 16-byte store)
     unsigned fhold0 = 0, fhold1 = 0, vhold0 = 0, vhold1 = 0;    // first halves of 16-byte plane pieces (feature / V)
     f32x4 w8hold;               // W8 row 0 at the features of the pair being worked on
-    float sdf_dot = 0.0f;       // this lane's half of  W8[0,:] . g8  (f32)
-    f32x16 UPE[2];              // d sdf / d(PE) tiles (W4^T rows 7,8 and W0^T)
+    float sdf_dot[2] = {0.0f, 0.0f};    // this lane's part of  W8[0,:] . g8  (f32), per point half (shape 0: [0] only)
+    float nz2[2] = {0.0f, 0.0f};        // shape 1: nz of the lane's two points
+    AccT UPE[2];                // d sdf / d(PE) tiles (W4^T rows 7,8 and W0^T)
     float n[3] = {0.0f, 0.0f, 0.0f};
     auto pe_backward = [&](bool first) VDN_INL {      // n += J_PE^T u  (transpose Jacobian of the encoding)
         float u[39];
-        tiles_vals<39, 2>(UPE, h, u);
+#if VDN_SDF2_S16
+        {   // tile lanes -> home lanes through the scratch: f32 [32 points][68] (272-byte rows: the b128 reads of 32 rows spread over the banks)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(xch + (16 * (g >> 1) + c16) * 272 + (32 * t + 4 * quad_of(g, lane)) * 4) = UPE[t].v[g];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                const f32x4 r = *reinterpret_cast<const f32x4*>(xch + c * 272 + i * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (4 * i + j < 39) u[4 * i + j < 39 ? 4 * i + j : 0] = r[j];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+#else
+        {
+            const f32x16 upe[2] = {UPE[0].w, UPE[1].w};
+            tiles_vals<39, 2>(upe, h, u);
+        }
+#endif
         // u = u_4[PE part] + u_0 for the ray adjoint (VdnSdfArgs.U_pe); vector-memory operations the wait counts do not
         // know of are harmless: they only make a counted wait return later
         if (a.U_pe != nullptr && ok && h == 0) {
@@ -552,8 +649,8 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
                     if constexpr (L.l == 7) {
                         // the sdf row of the last layer in f32 on the VALU, from the unrounded activations: 2 FMAs per pair on
                         // one layer's epilogue, and the output that the alpha multiplies by inv_s loses no bits to bf16
-                        if constexpr ((pr & 1) == 0) w8hold = *(reinterpret_cast<const f32x4*>(pp.template slot<CP + 1>() + kTail) + (8 * T + 2 * (pr >> 1) + h));
-                        sdf_dot = fmaf(g0, w8hold[2 * (pr & 1)], fmaf(g1, w8hold[2 * (pr & 1) + 1], sdf_dot));
+                        if constexpr ((pr & 1) == 0) w8hold = *(reinterpret_cast<const f32x4*>(pp.template slot<CP + 1>() + kTail) + (8 * T + quad_of(pr >> 1, lane)));
+                        sdf_dot[ph_of_pair(pr)] = fmaf(g0, w8hold[2 * (pr & 1)], fmaf(g1, w8hold[2 * (pr & 1) + 1], sdf_dot[ph_of_pair(pr)]));
                     }
                     unsigned pk = pack_bf16x2(g0, g1);
                     asm volatile("" : "+v"(pk));
@@ -570,7 +667,7 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
                             asm volatile("" : "+v"(w));      // materialise here: otherwise the chain sinks to the tile's end
                             sq_prev[pr >> 1] = w;
                             if constexpr (TS && (pr & 3) == 3)          // H plane piece k = pr >> 2 = this k-step's whole B fragment
-                                plane_store16(Hs + L.l * PS + prow + T * 1024 + 512 * (pr >> 2), cur);
+                                plane_store16(Hs + L.l * PS + piece(T, pr >> 2), cur);
                             if constexpr (pr == 7) SS.template put<PG::s_tile0(L.l) + T>(sq_prev);
                         }
                     }
@@ -592,10 +689,10 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
                                 o[1] = fhold1;
                                 o[2] = pack_bf16x2(acc_prev[4 * q], acc_prev[4 * q + 1]);
                                 o[3] = pack_bf16x2(acc_prev[4 * q + 2], acc_prev[4 * q + 3]);
-                                if constexpr (FEAT) plane_store16(feat + prow + T * 1024 + 512 * (q >> 1), o);
+                                if constexpr (FEAT) plane_store16(feat + piece(T, q >> 1), o);
                                 if constexpr (COL) F.r[T * 2 + (q >> 1)] = __builtin_bit_cast(bf16x8, o);      // (the piece IS the B fragment)
                             }
-                            const f32x4 w = *(reinterpret_cast<const f32x4*>(pp.template slot<CP + 1>() + kTail) + (8 * T + 2 * q + h));
+                            const f32x4 w = *(reinterpret_cast<const f32x4*>(pp.template slot<CP + 1>() + kTail) + (8 * T + quad_of(q, lane)));
                             if constexpr (q == 0) sq_v7 = SS.template get<PG::s_tile0(7) + T>();
                             const unsigned sw = sq_v7[q];
                             const float v0 = w[0] * inv_scale * ubyte_f32(sw, 0), v1 = w[1] * inv_scale * ubyte_f32(sw, 1);
@@ -617,7 +714,7 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
                                     ov[1] = vhold1;
                                     ov[2] = pack_bf16x2(v0 * kVSave, v1 * kVSave);
                                     ov[3] = pack_bf16x2(v2 * kVSave, v3 * kVSave);
-                                    plane_store16(Vs + 7 * PS + prow + T * 1024 + 512 * (q >> 1), ov);
+                                    plane_store16(Vs + 7 * PS + piece(T, q >> 1), ov);
                                 }
                             }
                         }
@@ -652,7 +749,7 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
                             o[1] = vhold1;
                             o[2] = hold0;
                             o[3] = pv;
-                            plane_store16(Vs + L.l * PS + prow + T * 1024 + 512 * (pr >> 2), o);
+                            plane_store16(Vs + L.l * PS + piece(T, pr >> 2), o);
                         }
                     }
                 });
@@ -663,9 +760,10 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
                     constexpr int pr = PB + decltype(i_c)::value;
                     float a0 = acc_prev[2 * pr], a1 = acc_prev[2 * pr + 1];
                     if constexpr (L.kind == COL0) {
-                        if constexpr ((pr & 1) == 0) w8hold = *(reinterpret_cast<const f32x4*>(pp.template slot<CP + 1>() + kTail) + (8 * T + 2 * (pr >> 1) + h));
-                        a0 = fmaf(w8hold[2 * (pr & 1)], nz, a0);
-                        a1 = fmaf(w8hold[2 * (pr & 1) + 1], nz, a1);
+                        if constexpr ((pr & 1) == 0) w8hold = *(reinterpret_cast<const f32x4*>(pp.template slot<CP + 1>() + kTail) + (8 * T + quad_of(pr >> 1, lane)));
+                        const float nzp = kS16 ? nz2[ph_of_pair(pr)] : nz;
+                        a0 = fmaf(w8hold[2 * (pr & 1)], nzp, a0);
+                        a1 = fmaf(w8hold[2 * (pr & 1) + 1], nzp, a1);
                     }
                     unsigned pk = pack_bf16x2(relu0(a0), relu0(a1));
                     asm volatile("" : "+v"(pk));
@@ -673,13 +771,24 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
                     cur[pr & 3] = pk;
                     D.r[T * 2 + (pr >> 2)] = __builtin_bit_cast(bf16x8, cur);
                     if constexpr (MODE == 3 && (pr & 3) == 3)          // the saved plane piece k = pr >> 2 = this k-step's whole B fragment (as the H planes)
-                        plane_store16(reinterpret_cast<ST*>(ex.col_h) + L.l * PS + prow + T * 1024 + 512 * (pr >> 2), cur);
+                        plane_store16(reinterpret_cast<ST*>(ex.col_h) + L.l * PS + piece(T, pr >> 2), cur);
                 });
             } else if constexpr (L.kind == COLOUT) {
                 // rows 0..2 of the output tile = registers 0..2 of the h = 0 lanes (fields.py:166-171)
                 if constexpr (PB == 0) {
+                    if constexpr (kS16) {
+                        // rows 0..2 = registers 0..2 of feature half 0 of the q4 = 0 lanes, per point half: home lane c takes its point's from
+                        // lane c & 15 (itself for c < 16)
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) col[j] = ex.squeeze_out ? sigmoidf_(acc_prev[j]) : relu0(acc_prev[j]);
+                        for (int j = 0; j < 3; ++j) {
+                            const float lo = acc_prev[j], hi = __shfl(acc_prev[8 + j], lane & 15);
+                            const float x = (lane & 16) ? hi : lo;
+                            col[j] = ex.squeeze_out ? sigmoidf_(x) : relu0(x);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) col[j] = ex.squeeze_out ? sigmoidf_(acc_prev[j]) : relu0(acc_prev[j]);
+                    }
                 }
             }
         }
@@ -711,24 +820,36 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
             u32x4 sq_next;
             if constexpr (sweep_tile) sq_next = SS.template get<PG::s_tile0(L.l) + T>();
             const auto& Xin = L.kind == COL0 ? F : ((LI & 1) ? Y : X);
-            const f32x16 acc_cur = chunk_step<MODE, SAVE, NSLOT, DEPTH, C>(pp, Xin, [&](auto g_c, auto) VDN_INL {
+            const AccT acc_cur = chunk_step<MODE, SAVE, NSLOT, DEPTH, C>(pp, Xin, [&](auto g_c, auto) VDN_INL {
                 constexpr int gi = decltype(g_c)::value;
                 epilogue(std::integral_constant<int, CP>{}, std::integral_constant<int, pair_begin(gi, GA)>{},
                          std::integral_constant<int, pair_begin(gi + 1, GA)>{});
             });
             if constexpr (L.kind == SWEEP_SKIP && T >= 7) UPE[T - 7] = acc_cur;
-            if constexpr (L.kind == SWEEP_PE) UPE[T] = acc_cur;
+            if constexpr (L.kind == SWEEP_PE) {
+                // shape 1: ONE crossing to the home lanes, on u_4[PE part] + u_0 (the encoding's adjoint is linear)
+                if constexpr (kS16) UPE[T].add(acc_cur);
+                else UPE[T] = acc_cur;
+            }
             if constexpr (L.kind == LAST && T == L.nt - 1) {
                 // sdf = W8[0,:] . h8 + b8[0]: the f32 dot of layer 7's epilogue (g8 = 100 log2(e) h8), the bias from this
                 // chunk's bias block (row 0); the MFMA's own bf16 value of the row is not used
                 const float b0 = *reinterpret_cast<const float*>(pp.template slot<C>() + L.kt * 2048);
-                const float dot = sdf_dot + __shfl_xor(sdf_dot, 32);
+                float dot;
+                if constexpr (kS16) {       // the four row quads of a point; home lane c + 32 h is a tile lane of point half (c >> 4)
+                    float d0 = sdf_dot[0], d1 = sdf_dot[1];
+                    d0 += __shfl_xor(d0, 16); d1 += __shfl_xor(d1, 16);
+                    d0 += __shfl_xor(d0, 32); d1 += __shfl_xor(d1, 32);
+                    dot = (lane & 16) ? d1 : d0;
+                } else {
+                    dot = sdf_dot[0] + __shfl_xor(sdf_dot[0], 32);
+                }
                 sdf_keep = fmaf(dot, 1.0f / kC1, b0) * inv_scale;
                 if (ok && h == 0) a.sdf[sdf_idx] = sdf_keep;
             }
             acc_prev = acc_cur;
             if constexpr (sweep_tile) sq_prev = sq_next;
-            if constexpr ((L.kind == SWEEP_SKIP && T == 8) || (L.kind == SWEEP_PE && T == 1)) pe_backward(L.kind == SWEEP_SKIP);
+            if constexpr ((!kS16 && L.kind == SWEEP_SKIP && T == 8) || (L.kind == SWEEP_PE && T == 1)) pe_backward(kS16 || L.kind == SWEEP_SKIP);
             if constexpr (COL && L.kind == SWEEP_PE && T == 1) {
                 // the normal is complete: the colour head's small input tile [points (3), PE4(view) (27), normal x, y] (fields.py:154;
                 // k order of the "c2" stream), z component kept in f32
@@ -742,6 +863,14 @@ __global__ __launch_bounds__(kWaves * 64, MODE == 0 ? 2 : 1) void sdf_fwd2_kerne
                 small[31] = n[1] * a.scale;
                 nz = n[2] * a.scale;
                 F.set(8, vals_tile<32>(small, h, 0));
+                if constexpr (kS16) {
+                    to_tile_lanes(&F.r[16], std::integral_constant<int, 2>{});
+                    reinterpret_cast<float*>(xch)[c] = nz;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    nz2[0] = reinterpret_cast<const float*>(xch)[c16];
+                    nz2[1] = reinterpret_cast<const float*>(xch)[16 + c16];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
                 if constexpr (MODE == 3) {
                     // the colour head's 33 small inputs as rendernet_fwd_kernel saves them ([rows, 64]: the weight-gradient GEMM's operand).
                     // Uncounted vector-memory operations only make a counted wait return later (as the U_pe stores above)
