@@ -403,6 +403,25 @@ class Leg:
                                "points_per_s": eng.P / tk_c2["median"],
                                "achieved": c2f / tk_c2["median"] / 1e12, "frac": c2f / tk_c2["median"] / pk}}
 
+    def sdf_roofline_in_step(self, in_situ_steps=40):
+        """N > 1: the north-star kernel timed only where the job runs it - HIP events around the launch inside consecutive training
+        steps of THIS leg as scheduled (every rank steps: the steps hold collectives); no isolated launches, no second leg."""
+        in_situ_steps = max(1, int(round(in_situ_steps / float(len(self.batches))))) * len(self.batches)
+        situ = self.sdf_in_situ(in_situ_steps)
+        if self.rank != 0:
+            return None
+        dtype = "f32" if self.precision == "fp32" else "bf16"
+        pk = PEAK[dtype]
+        tf = _profile_file("traffic_sdf_fwd_%s_train.json" % self.precision)
+        tr = json.load(open(tf)).get("hbm_bytes_per_launch") if tf is not None else None
+        return {"bound": "mfma", "kernel": "fused PE + SDF MLP + gradient sweep, training-mode launch of the timed step over its foreground work "
+                                           "list, HIP events around the launch inside %d consecutive steps of rank 0" % in_situ_steps,
+                "achieved": situ["flops"] / (situ["kernel_ms"] * 1e-3) / 1e12, "peak": pk / 1e12, "unit": "TFLOP/s",
+                "frac": situ["flops"] / (situ["kernel_ms"] * 1e-3) / pk,
+                "traffic": tr * situ["points"] / float(self.trainer.engine.P) if tr is not None else None,
+                "kernel_ms": situ["kernel_ms"], "points": situ["points"],
+                "schedule": "default two-stream schedule of the data-parallel step (the schedule of ms_per_step), rank 0", "in_situ": situ}
+
     def dw_roofline(self):
         eng = self.trainer.engine
         dtype = "f32" if self.precision == "fp32" else "bf16"
@@ -484,6 +503,51 @@ def runner_flow(args, dev, precision, steps, warmup=5, wdepth=False):
             "dtype": "f32" if precision == "fp32" else "bf16"}
 
 
+def precision_gap(head, dev, n_batches=4):
+    """bf16 against fp32 on the SAME rays, weights and jitter: the headline leg's networks as its timed steps left them, copied into
+    a second renderer on the exact-fp32 kernels; render() without grad on `n_batches` of the leg's resident batches, the jitter
+    injected (t_rand / t_rand_out) so that both draw the same samples. Per output: max |bf16 - fp32| / max |fp32| and
+    mean |bf16 - fp32| / mean |fp32| over all rays of all batches; gradient_error is one scalar per batch (its relative error)."""
+    from vdn_train import factory
+    r16 = head.rend
+    r32 = factory.build_renderer(wdepth=head.wdepth, device=dev, states=None, precision="fp32")
+    with torch.no_grad():
+        for name in ("nerf", "sdf_network", "deviation_network", "color_network", "depth_network"):
+            src, dst = getattr(r16, name), getattr(r32, name)
+            if src is not None:
+                dst.load_state_dict({k: v.detach().clone() for k, v in src.state_dict().items()})
+    gen = torch.Generator(device="cpu").manual_seed(1234)
+    bg = torch.ones(1, 3, device=dev)
+    keys = ("color_fine", "weight_sum", "gradients", "weights") + (("render_feats",) if head.wdepth else ())
+    num_max, den_max, num_sum, den_sum = ({k: 0.0 for k in keys} for _ in range(4))
+    eik = []
+    with torch.no_grad():
+        for i in range(n_batches):
+            o, d, near, far = head.batches[i % len(head.batches)][:4]
+            t1 = torch.rand(o.shape[0], 1, generator=gen).to(dev)
+            t2 = torch.rand(o.shape[0], r16.n_outside, generator=gen).to(dev)
+            a = r16.render(o, d, near, far, background_rgb=bg, cos_anneal_ratio=0.5, t_rand=t1, t_rand_out=t2)
+            b = r32.render(o, d, near, far, background_rgb=bg, cos_anneal_ratio=0.5, t_rand=t1, t_rand_out=t2)
+            for k in keys:
+                x, y = a[k].double(), b[k].double()
+                num_max[k] = max(num_max[k], float((x - y).abs().max()))
+                den_max[k] = max(den_max[k], float(y.abs().max()))
+                num_sum[k] += float((x - y).abs().sum())
+                den_sum[k] += float(y.abs().sum())
+            ea, eb = float(a["gradient_error"]), float(b["gradient_error"])
+            eik.append(abs(ea - eb) / max(abs(eb), 1e-30))
+    inv_s = float(torch.exp(r16.deviation_network.variance.detach() * 10.0).item())
+    out = {"what": "bf16 kernels against the fp32 parity kernels on the same %d x %d rays, weights (the headline leg's, after its timed "
+                   "steps) and jitter: max |diff| / max |fp32| and mean |diff| / mean |fp32| per render() output" % (n_batches, head.B),
+           "inv_s": inv_s, "gradient_error_rel_err_max": float(max(eik)), "gradient_error_rel_err_mean": float(np.mean(eik))}
+    for k in keys:
+        out[k + "_max_rel_err"] = num_max[k] / max(den_max[k], 1e-30)
+        out[k + "_mean_rel_err"] = num_sum[k] / max(den_sum[k], 1e-30)
+    del r32
+    torch.cuda.empty_cache()
+    return out
+
+
 def real_cameras():
     """A camera rig the reference SHIPS: the 33 learned poses and the focal coefficient of pretrained-models/pixiu/
     womsk_learn_white_colmap/pnf_300000.pth, as the reference's own LearnPose / LearnIntrin return them (tests/golden/pnf_rays.npz,
@@ -559,6 +623,11 @@ def main():
                                               "the gradient slices are summed IN that stream (the bracket is the collective itself: "
                                               "grad_sdf on the critical path, grad_nerf / grad_heads on the side stream); fg_count and "
                                               "eikonal overlap other work and the bracket is only the stream's wait for them")
+    if world > 1:
+        # N > 1 is the scaling measurement: the headline leg, the exposed all-reduce time and the north-star kernel inside the
+        # job's own steps - no further legs (each would be another Trainer and minutes of box time on every rank), no per-rank
+        # micro-benchmarks. Everything else is reported at N = 1.
+        args.headline_only = True
     if not args.headline_only:
         # The same K steps with every sample evaluated, as the reference does: the default path skips samples that enter the loss
         # only through exact zeros ("Work lists") - identical results, reported side by side for transparency.
@@ -601,7 +670,9 @@ def main():
                 head.fence()
                 extras["forward_only_rays_per_s_batch_%d" % (4 * args.batch)] = world * 4 * args.batch * (nf // 2) / (time.time() - t1)
     roof = roof_dw = None
-    if not args.no_roofline:
+    if not args.no_roofline and world > 1:
+        roof = head.sdf_roofline_in_step()
+    elif not args.no_roofline:
         # the north-star kernel in situ on the one-stream schedule (what the committed rocprofv3 kernel trace shows): a second
         # leg with the same seed, batches and step count (same work lists), built with the side stream and the overlap off
         env1 = {"VDN_SIDE_STREAM": "0", "VDN_OVERLAP": "0"}
@@ -653,6 +724,8 @@ def main():
                                      "bf16": runner_flow(args, dev, "bf16", K), "fp32": runner_flow(args, dev, "fp32", max(4, K // 4)),
                                      "bf16_wdepth": runner_flow(args, dev, "bf16", K, wdepth=True)}
             torch.cuda.empty_cache()
+        if args.precision == "bf16" and world == 1:
+            extras["bf16_vs_fp32"] = precision_gap(head, dev)
         rc = real_cameras()
         if rc is not None and args.crop is None:
             leg = Leg(args, dev, world, rank, args.precision, wdepth, nb, cams=rc[0], focal=rc[1])
@@ -707,17 +780,52 @@ def main():
             "roofline_in_step_two_streams": (dict({k: roof["in_step_two_streams"][k] for k in ("frac", "kernel_ms", "points", "steps")},
                                                   schedule="default two-stream schedule = the schedule of ms_per_step: the background network's "
                                                            "kernels share the chip with the launch", ms_per_step=res["ms_per_step"])
-                                             if roof is not None else None),
+                                             if (roof is not None and "in_step_two_streams" in roof) else None),
         }
         line.update(extras)
+        if roof is not None:
+            # flat copies of the nested figures (a reader that keeps only the scalars of `roofline` still sees them)
+            for k in ("inference_launch", "training_launch_full_rows", "c2_forward", "in_step_two_streams"):
+                if isinstance(roof.get(k), dict) and "frac" in roof[k]:
+                    roof[k + "_frac"] = roof[k]["frac"]
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.batch, 0, wdepth, full=args.cpu_baseline_full)
         else:
             line["cpu_baseline"] = None
+        # the figures of the other legs once more, short and LAST: whoever keeps only the end of this (long) line still has them
+        g = lambda d, *ks: (g(d.get(ks[0]), *ks[1:]) if len(ks) > 1 else d.get(ks[0])) if isinstance(d, dict) else None
+        rnd = lambda x: None if x is None else (round(x, 1) if abs(x) >= 100 else float("%.4g" % x))
+        summary = {"value_rays_per_s": rnd(res["value"]), "ms_per_step": rnd(res["ms_per_step"]),
+                   "roofline_frac_in_step_one_stream": rnd(g(roof, "frac")), "roofline_frac_in_step_two_streams": rnd(g(roof, "in_step_two_streams", "frac")),
+                   "roofline_frac_inference_launch": rnd(g(roof, "inference_launch", "frac")),
+                   "roofline_frac_training_launch_full_rows": rnd(g(roof, "training_launch_full_rows", "frac")),
+                   "roofline_frac_c2_forward_one_launch": rnd(g(roof, "c2_forward", "frac")),
+                   "dw_gemm_hbm_frac": rnd(g(roof_dw, "frac")),
+                   "runner_flow_bf16_rays_per_s": rnd(g(extras, "runner_flow", "bf16", "rays_per_s")),
+                   "runner_flow_bf16_ms_per_step": rnd(g(extras, "runner_flow", "bf16", "ms_per_step")),
+                   "runner_flow_fp32_rays_per_s": rnd(g(extras, "runner_flow", "fp32", "rays_per_s")),
+                   "runner_flow_bf16_wdepth_rays_per_s": rnd(g(extras, "runner_flow", "bf16_wdepth", "rays_per_s")),
+                   "wdepth_rays_per_s": rnd(g(extras, "wdepth", "value")), "object_centric_rays_per_s": rnd(g(extras, "object_centric", "value")),
+                   "all_samples_rays_per_s": rnd(g(extras, "all_samples_evaluated", "value")),
+                   "real_cameras_rays_per_s": rnd(g(extras, "real_cameras", "value")),
+                   "fp32_parity_path_rays_per_s": rnd(g(extras, "parity_path", "value")),
+                   "forward_only_rays_per_s": rnd(g(extras, "forward_only_rays_per_s")),
+                   "bf16_vs_fp32_color_max_rel_err": rnd(g(extras, "bf16_vs_fp32", "color_fine_max_rel_err")),
+                   "bf16_vs_fp32_color_mean_rel_err": rnd(g(extras, "bf16_vs_fp32", "color_fine_mean_rel_err")),
+                   "bf16_vs_fp32_weight_sum_max_rel_err": rnd(g(extras, "bf16_vs_fp32", "weight_sum_max_rel_err")),
+                   "bf16_vs_fp32_gradient_error_rel_err_max": rnd(g(extras, "bf16_vs_fp32", "gradient_error_rel_err_max")),
+                   "allreduce_exposed_ms": ({k: rnd(v["mean_ms"]) for k, v in extras["allreduce_exposed_ms"].items() if isinstance(v, dict)}
+                                            if "allreduce_exposed_ms" in extras else None),
+                   "cpu_baseline_rays_per_s": rnd(g(line, "cpu_baseline", "value"))}
+        line["summary"] = {k: v for k, v in summary.items() if v is not None}
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist
-        dist.barrier()                 # rank 0 is still timing single kernels / printing: leave together
+        from vdn_train import dp
+        dist.barrier()                 # rank 0 is still printing: leave together
+        if os.environ.get("VDN_BENCH_REPORT_GROUPS"):       # tests: how many communicators this rank made beyond the world group
+            print("bench.py rank %d: process groups created by vdn_train.dp: %d" % (rank, dp.groups_created), file=sys.stderr, flush=True)
+        dp.shutdown()
         dist.destroy_process_group()
 
 

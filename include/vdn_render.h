@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VDN_ABI_VERSION 27
+#define VDN_ABI_VERSION 28
 
 int vdn_abi_version(void);
 
@@ -744,6 +744,31 @@ typedef struct {
 } VdnMeshArgs;
 int vdn_mesh_count(const VdnMeshArgs* args_host, void* stream);
 int vdn_mesh_emit(const VdnMeshArgs* args_host, void* stream);
+
+/* ---- iso-surface of the lattice as mcubes.marching_cubes(u, threshold) numbers it (renderer.py:36) -------------------------
+ * Marching cubes on the classic 256-case tables with PyMCubes' sequential bookkeeping (mcubes/src/marchingcubes.h of
+ * PyMCubes 0.1.2, the version the reference's README pins; restated in oracle/marching_cubes.py - the package itself is absent
+ * here): cells visited x-major with z innermost, corner "set" when (double)u <= isovalue, one float64 vertex per cut lattice
+ * edge created by the first visited cell containing it (in-cell order: edges 6, 5, 10, then 0, 1, 2, 3, 4, 7, 8, 9, 11 where no
+ * earlier cell exists), interpolated from the edge's first corner to its second, triangles in table order. Two passes around two
+ * exclusive prefix sums over the cells (cell = (x*(R-1) + y)*(R-1) + z) that the caller makes:
+ *   vdn_mesh_mc_count: cube_case[cell], n_verts[cell] = vertices the cell creates, n_tris[cell];
+ *   vdn_mesh_mc_emit:  vertices[vert_offsets[cell] ..][xyz] (lattice index coordinates) and triangles[tri_offsets[cell] ..][3]
+ *                      (vertex numbers) - the arrays the sequential library returns, element for element. u is [R][R][R] fp32. */
+typedef struct {
+    const float* u;
+    double isovalue;
+    int32_t R;
+    uint8_t* cube_case;            /* [(R-1)^3]   written by the count pass, read by the emit pass */
+    int32_t* n_verts;              /* [(R-1)^3]   (count pass) */
+    int32_t* n_tris;               /* [(R-1)^3]   (count pass) */
+    const int64_t* vert_offsets;   /* [(R-1)^3] exclusive prefix sum of n_verts   (emit pass) */
+    const int64_t* tri_offsets;    /* [(R-1)^3] exclusive prefix sum of n_tris    (emit pass) */
+    double* vertices;              /* [V][3] */
+    int64_t* triangles;            /* [F][3] */
+} VdnMeshMcArgs;
+int vdn_mesh_mc_count(const VdnMeshMcArgs* args_host, void* stream);
+int vdn_mesh_mc_emit(const VdnMeshMcArgs* args_host, void* stream);
 
 #ifdef __cplusplus
 }

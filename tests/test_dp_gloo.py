@@ -52,6 +52,9 @@ def _worker(rank, port, q, wdepth):
         os.environ["VDN_DP_INSTREAM"] = "0"                 # every sum through begin / finish on the backend's stream)
     coll = dp.Collectives(WORLD)                            # the Trainer's own collectives object (vdn_train/trainer.py:97)
     assert coll.enabled and coll.side_group is not coll.group
+    # a second Trainer of the same process (bench.py builds one per leg) shares the side communicator: one new_group per process
+    coll2 = dp.Collectives(WORLD)
+    assert coll2.side_group is coll.side_group and dp.groups_created == 1
     coll.finish(coll.begin([nd]), tag="eikonal")            # in place: global (num, den)
     eik = (out["eik_num"] + (nd[0] - local_num)) / (nd[1] + 1e-5)     # gradient flows through the local numerator only
     loss = (out["color_fine"] - b[6]).abs().sum() / (B_PER_RANK + 1e-5) / WORLD + 0.1 * eik / WORLD * WORLD
@@ -76,6 +79,8 @@ def _worker(rank, port, q, wdepth):
     coll.sum_now([flat[se:]], side=True, tag="grad_heads")
     if rank == 0:
         q.put((flat.numpy(), float(eik)))
+    dp.shutdown()                                           # the side communicator goes before the world group
+    assert dp._shared_side_group is None
     dist.destroy_process_group()
 
 

@@ -259,7 +259,7 @@ def test_two_ranks_keep_identical_parameters_over_overlapped_steps(fused):
     assert np.linalg.norm(dp - ref) < 1e-4 * np.linalg.norm(ref), np.linalg.norm(dp - ref) / np.linalg.norm(ref)
 
 
-def _bench(cmd, env=None):
+def _bench(cmd, env=None, with_stderr=False):
     import json
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -267,7 +267,7 @@ def _bench(cmd, env=None):
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
-    return json.loads(lines[0])
+    return (json.loads(lines[0]), out.stderr) if with_stderr else json.loads(lines[0])
 
 
 def test_bench_two_rank_control_flow():
@@ -276,15 +276,22 @@ def test_bench_two_rank_control_flow():
     single JSON line of rank 0. And the plain `python bench.py --gpus 2` form, which must spawn the ranks itself."""
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, VDN_DIST_BACKEND="gloo")
-    tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--headline-only"]
+    env = dict(os.environ, VDN_DIST_BACKEND="gloo", VDN_BENCH_REPORT_GROUPS="1")
+    # the driver's own flags: at N > 1 bench.py runs the headline leg, the exposed all-reduce time and the in-step roofline - nothing else
+    tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
     for cmd in ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                  "--master-port", "29541"] + tail, [sys.executable] + tail):
         env.pop("WORLD_SIZE", None)
-        d = _bench(cmd, env)
+        d, err = _bench(cmd, env, with_stderr=True)
         assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
         assert d["config"]["parallelism"] == "dp2" and d["roofline"]["frac"] > 0 and d["cpu_baseline"] is None
         assert d["trials"]["regions"] >= 5 and d["trials"]["steps_per_region"] == 3
+        # one leg: no fp32 / wdepth / object-centric / runner legs at N > 1, and the collectives' exposed time is in the line
+        assert not {"parity_path", "wdepth", "object_centric", "runner_flow", "all_samples_evaluated", "real_cameras"} & set(d)
+        assert set(d["allreduce_exposed_ms"]) >= {"grad_sdf", "grad_nerf", "grad_heads"}
+        # every rank made at most ONE communicator beyond the world group (vdn_train/dp.py: the shared side group), and destroyed it
+        made = [int(l.rsplit(":", 1)[1]) for l in err.splitlines() if "process groups created by vdn_train.dp" in l]
+        assert len(made) == 2 and max(made) <= 1, made
     # --gpus that does not match the launcher's world size must not print a line for the wrong GPU count
     import subprocess
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=300,

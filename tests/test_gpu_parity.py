@@ -740,6 +740,76 @@ def test_marching_tets_surface_properties(dev, shape, chi):
         assert abs(area - 4 * np.pi * 0.49) < 0.01 * 4 * np.pi * 0.49
 
 
+@pytest.mark.parametrize("field", ["blob", "noise", "cut_by_the_box", "flat_ties", "torus"])
+def test_marching_cubes_kernel_equals_the_pymcubes_restatement(dev, field):
+    """vdn_mesh_mc_count / vdn_mesh_mc_emit against oracle/marching_cubes.py (the published algorithm of the PyMCubes the reference
+    calls at renderer.py:36): the SAME vertex array and the SAME triangle array - counts, order, float64 bits. Fields: a smooth blob
+    (the stages.npz kind of level set), white noise (all 256 cases, every ambiguous face), a surface that leaves the lattice through
+    all six faces (the cells that create vertices on shared boundary edges), values that tie with the level and with each other
+    (`<=` side of the case test, the f1 == f2 midpoint), and a torus."""
+    from oracle import marching_cubes as omc
+    from vdn_hip import mesh
+    rng = np.random.default_rng(11)
+    R = 14
+    gx = np.linspace(-1, 1, R)
+    X, Y, Z = np.meshgrid(gx, gx, gx, indexing="ij")
+    iso = 0.03
+    if field == "blob":
+        u = 0.55 - np.sqrt(X * X + 0.8 * Y * Y + 1.3 * Z * Z) + 0.15 * np.sin(3 * X) * np.cos(2 * Y) + 0.02 * rng.standard_normal(X.shape)
+    elif field == "noise":
+        u, iso = rng.standard_normal(X.shape), 0.0
+    elif field == "cut_by_the_box":
+        u = 1.25 - np.sqrt(X * X + Y * Y + Z * Z) + 0.1 * np.sin(5 * X + 1) * np.sin(4 * Y) * np.cos(3 * Z)
+    elif field == "flat_ties":
+        u, iso = np.round(2.0 * (0.7 - np.sqrt(X * X + Y * Y + Z * Z))) / 2.0, 0.0          # multiples of 0.5: many values equal the level
+    else:
+        u, iso = 0.25 - np.sqrt((np.sqrt(X * X + Y * Y) - 0.6) ** 2 + Z * Z), 0.0
+    u = u.astype(np.float32)
+    Vo, Fo = omc.marching_cubes(u, iso)
+    V, F = mesh.marching_cubes(torch.tensor(u, device=dev), iso)
+    assert V.dtype == torch.float64 and F.dtype == torch.int64
+    V, F = V.cpu().numpy(), F.cpu().numpy()
+    assert V.shape == Vo.shape and F.shape == Fo.shape and len(Fo) > 50, (V.shape, Vo.shape, F.shape, Fo.shape)
+    assert np.array_equal(F, Fo)
+    assert np.array_equal(V, Vo)            # float64, bit for bit: one division per vertex, evaluated as the library writes it
+
+
+def test_marching_cubes_surface_properties_at_full_size(dev):
+    """The reference's default lattice (resolution 64 blocks; here 128^3): closed, consistently oriented, Euler characteristic of the
+    shape, vertices on the level set, one vertex per cut lattice edge."""
+    from vdn_hip import mesh
+    R = 128
+    g1 = torch.linspace(-1, 1, R, device=dev)
+    X, Y, Z = torch.meshgrid(g1, g1, g1, indexing="ij")
+    sdf = torch.sqrt((torch.sqrt(X * X + Y * Y) - 0.6) ** 2 + Z * Z) - 0.22
+    V, F = mesh.marching_cubes(-sdf, 0.0)
+    V, F = V.cpu().numpy(), F.cpu().numpy()
+    dmax, uses, euler = _mesh_stats(V, F)
+    assert dmax == 1 and uses == {2} and euler == 0
+    assert len(np.unique(V, axis=0)) == len(V)
+    P = V * (2.0 / (R - 1)) - 1.0
+    d = np.sqrt((np.sqrt(P[:, 0] ** 2 + P[:, 1] ** 2) - 0.6) ** 2 + P[:, 2] ** 2) - 0.22
+    assert np.abs(d).max() < 3e-4
+
+
+def test_extract_geometry_matches_the_restatement_on_the_networks_lattice(env, dev):
+    """NeuSRenderer.extract_geometry (renderer.py:441-446 -> 33-41) end to end on the SDF network: the lattice u = -sdf the kernels
+    fill, triangulated on the device, equals the restatement applied to that same lattice - vertex and face counts, arrays bit for
+    bit after the reference's own world-coordinate transform."""
+    from oracle import marching_cubes as omc
+    from dpt_models import renderer as rmod
+    rend, _, _ = env(3, True, 0.3)
+    lo, hi, res = torch.tensor([-1.0, -1.0, -1.0]), torch.tensor([1.0, 1.0, 1.0]), 24
+    V, F = rend.extract_geometry(lo, hi, resolution=res, threshold=0.0)
+    u = rmod.extract_fields(lo, hi, res, lambda pts: -rend.sdf_network.sdf(pts))
+    Vo, Fo = omc.marching_cubes(u, 0.0)
+    Vo = Vo / (res - 1.0) * 2.0 + (-1.0)                                    # renderer.py:39
+    assert V.shape == Vo.shape and F.shape == Fo.shape and len(F) > 100
+    assert np.array_equal(F, Fo) and np.array_equal(V, Vo)
+    Vt, Ft = rend.extract_geometry(lo, hi, resolution=res, threshold=0.0, method="tets")      # the tetrahedra stay available
+    assert len(Ft) > len(F)
+
+
 def test_extract_geometry_without_pymcubes(env, dev):
     rend, _, _ = env(3, True, 0.3)
     V, F = rend.extract_geometry(torch.tensor([-1.0, -1.0, -1.0]), torch.tensor([1.0, 1.0, 1.0]), resolution=40, threshold=0.0)

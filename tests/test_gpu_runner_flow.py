@@ -262,6 +262,45 @@ def test_engines_of_alternating_batch_sizes_stay_alive():
     assert sorted(k[0] for k in rend.__dict__["_engines"]) == [11, 20, 64]
 
 
+def test_outputs_of_render_under_grad_allow_inplace_ops():
+    """render() under grad hands out plain tensors (they were views of one arena, and autograd refuses in-place ops
+    on the views of a multi-output node): color_fine.clamp_() and weight_sum.clip_() work, backward() still reaches every
+    parameter, and gradients equal those of the out-of-place forms. A saved output (`weights`) modified before backward() is
+    still caught by autograd's version check."""
+    from vdn_train import synth, factory
+    dev = torch.device("cuda:0")
+    rend = factory.build_renderer(device=dev, states=synth.make_all_states(3, variance=0.4), precision="fp32")
+    cams = synth.make_cameras(3)
+    tt = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32, device=dev)
+    B = 24
+    o, d = synth.random_pixel_batch(3, 0, 1, B, cams=cams)
+    near, far = synth.near_far_from_sphere(o, d)
+    t1, t2 = synth.jitter(3, 0, B)
+    params = rend._all_parameters()
+
+    def grads(inplace):
+        for p in params:
+            p.grad = None
+        out = rend.render(tt(o), tt(d), tt(near), tt(far), background_rgb=torch.ones(1, 3, device=dev), cos_anneal_ratio=1.0,
+                          t_rand=tt(t1), t_rand_out=tt(t2))
+        c, ws = out["color_fine"], out["weight_sum"]
+        assert not c._is_view() and not ws._is_view() and not out["gradients"]._is_view()
+        if inplace:
+            c.mul_(0.5).clamp_(0.05, 0.45)
+            ws.clip_(1e-3, 1.0 - 1e-3)
+        else:
+            c, ws = (c * 0.5).clamp(0.05, 0.45), ws.clip(1e-3, 1.0 - 1e-3)
+        (c.sum() + ws.sum() + out["gradient_error"]).backward()
+        return [p.grad.clone() for p in params]
+    ga, gb = grads(True), grads(False)
+    assert all(torch.equal(a, b) for a, b in zip(ga, gb))
+    assert sum(float(g.abs().sum()) for g in ga) > 0
+    out = rend.render(tt(o), tt(d), tt(near), tt(far), background_rgb=torch.ones(1, 3, device=dev), cos_anneal_ratio=1.0)
+    out["weights"].mul_(2.0)                    # saved for the node's backward: must not pass silently
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        out["color_fine"].sum().backward()
+
+
 @pytest.mark.parametrize("precision", ["bf16", "fp32"])
 @pytest.mark.parametrize("kind", ["all_listed", "none_listed", "single_ray"])
 def test_render_under_grad_with_an_empty_list_or_an_empty_complement(kind, precision):

@@ -26,6 +26,9 @@ ap.add_argument("--out", default=None)
 ap.add_argument("--grid", type=int, default=64)
 ap.add_argument("--seed", type=int, default=0, help="initial weights (torch.manual_seed) and pixel stream")
 ap.add_argument("--quiet", action="store_true", help="only the summary line")
+ap.add_argument("--rig", choices=["synthetic", "real"], default="synthetic", help="real: the 33 learned cameras + focal of a scene the "
+                "reference ships (pretrained-models/pixiu/womsk_learn_white_colmap/pnf_300000.pth via tests/golden/pnf_rays.npz), "
+                "pixels over the full frame; the analytic target scene is the same")
 args = ap.parse_args()
 steps, prec = args.steps, args.precision
 dev = torch.device("cuda:0")
@@ -39,16 +42,22 @@ other = None
 if args.cross:
     oprec = "fp32" if prec == "bf16" else "bf16"
     other = factory.build_renderer(device=dev, precision=oprec)
-cams = synth.make_cameras(seed)
+cams, FOCAL, NCAM = synth.make_cameras(seed), synth.FOCAL, 40
 g = lambda x: torch.tensor(x).to(dev)
 ALBEDO = 0.5
 CROP = 420            # train on the central window where the object covers most pixels (object-centric capture)
 HELD = [3, 7, 13, 18, 23, 27, 33, 38][:args.views]          # never trained on
+if args.rig == "real":
+    pn = np.load(os.path.join(ROOT, "tests", "golden", "pnf_rays.npz"), allow_pickle=False)
+    tag = "pixiu.womsk_learn_white_colmap"
+    cams, FOCAL = pn[tag + "__c2w"].astype(np.float64), float(pn[tag + "__fx"]) ** 2 * 800.0      # poses.py:80-84: focal = fx^2 * W
+    NCAM, CROP = len(cams), None
+    HELD = [3, 7, 11, 15, 19, 23, 27, 31][:args.views]
 G = args.grid
 vx, vy = np.meshgrid(np.linspace(190, 610, G), np.linspace(190, 610, G))
 val = []
 for v in HELD:
-    vo, vd = synth.pixel_rays(cams[v], vx.reshape(-1), vy.reshape(-1))
+    vo, vd = synth.pixel_rays(cams[v], vx.reshape(-1), vy.reshape(-1), focal=FOCAL)
     vn, vf = synth.near_far_from_sphere(vo, vd)
     val.append([g(vo), g(vd), g(vn), g(vf), g(synth.target_colors(vo, vd, ALBEDO))])
 white = torch.ones(1, 3, device=dev)
@@ -78,12 +87,12 @@ def sync_other():
 log = []
 out_f = open(args.out, "w") if args.out else None
 t0 = time.time()
-order = (synth.uniform(seed, "trainperm", (steps,)) * 40).astype(np.int64) % 40
-free = [i for i in range(40) if i not in HELD]
+order = (synth.uniform(seed, "trainperm", (steps,)) * NCAM).astype(np.int64) % NCAM
+free = [i for i in range(NCAM) if i not in HELD]
 every = max(steps // args.checkpoints, 1)
 for it in range(steps):
     img = free[int(order[it]) % len(free)]
-    o, d = synth.random_pixel_batch(seed, it, img, B, cams=cams, crop=CROP)
+    o, d = synth.random_pixel_batch(seed, it, img, B, cams=cams, crop=CROP, focal=FOCAL)
     near, far = synth.near_far_from_sphere(o, d)
     sc = tr.train_step(g(o), g(d), g(near), g(far), g(synth.target_colors(o, d, ALBEDO)))
     if (it + 1) % every == 0 or it == 0 or it == steps - 1:
@@ -106,7 +115,7 @@ for it in range(steps):
             out_f.write(line + "\n")
             out_f.flush()
 last = [r["val_psnr_mean"] for r in log[-3:]]
-summary = {"precision": prec, "steps": steps, "seed": args.seed, "views": HELD, "final_val_psnr_mean": log[-1]["val_psnr_mean"], "final_val_psnr_sd": log[-1]["val_psnr_sd"],
+summary = {"precision": prec, "rig": args.rig, "steps": steps, "seed": args.seed, "views": HELD, "final_val_psnr_mean": log[-1]["val_psnr_mean"], "final_val_psnr_sd": log[-1]["val_psnr_sd"],
            "mean_of_last_3_checkpoints": float(np.mean(last)), "final_train_psnr": log[-1]["train_psnr"], "wall_s": time.time() - t0}
 print(json.dumps(summary))
 if out_f:

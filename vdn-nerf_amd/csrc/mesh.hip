@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include "vdn_render.h"
+#include "mc_tables.h"
 
 namespace vdn {
 
@@ -121,6 +122,117 @@ __global__ void mesh_emit_kernel(VdnMeshArgs a) {
     }
 }
 
+// ---- marching cubes with PyMCubes' vertex and triangle numbering (vdn_mesh_mc_*: include/vdn_render.h) ------------------------
+// The library the reference calls (renderer.py:36) walks the cells sequentially, x-major with z innermost, gives every cut lattice
+// edge ONE vertex - created by the first visited cell that contains the edge - and numbers vertices in creation order. In parallel
+// form: the count pass stores each cell's case, the number of vertices it creates and its triangle count; the caller's exclusive
+// prefix sums over cells in visiting order ARE the sequential numbering; the emit pass writes each cell's vertices at its offset in
+// the library's in-cell creation order and resolves a triangle corner on edge e through the cell that owns e: offset[owner] + the
+// rank of e among the vertices the owner creates.
+__device__ __constant__ unsigned char kMcCorner[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
+__device__ __constant__ unsigned char kMcEdge[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6}, {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+// in-cell creation order (marchingcubes.h: 0x040, 0x020, 0x400, then the shared edges where no earlier cell exists)
+__device__ __constant__ unsigned char kMcOrder[12] = {6, 5, 10, 0, 1, 2, 3, 4, 7, 8, 9, 11};
+
+// does cell (i, j, k) create the vertex of its edge e (i.e. is it the first visited cell that contains that lattice edge)?
+__device__ inline bool mc_creates(int e, int i, int j, int k) {
+    switch (e) {
+        case 6: case 5: case 10: return true;
+        case 0: return j == 0 && k == 0;
+        case 1: case 2: return k == 0;
+        case 3: return i == 0 && k == 0;
+        case 4: case 9: return j == 0;
+        case 7: case 11: return i == 0;
+        default: return i == 0 && j == 0;      // 8
+    }
+}
+__device__ inline int mc_edge_mask(int cube) {
+    int m = 0;
+#pragma unroll
+    for (int e = 0; e < 12; ++e)
+        if (((cube >> kMcEdge[e][0]) ^ (cube >> kMcEdge[e][1])) & 1) m |= 1 << e;
+    return m;
+}
+__device__ inline int mc_case(const VdnMeshMcArgs& a, int i, int j, int k, double* v) {
+    int cube = 0;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const float f = a.u[((long)(i + kMcCorner[m][0]) * a.R + (j + kMcCorner[m][1])) * a.R + (k + kMcCorner[m][2])];
+        if (v != nullptr) v[m] = (double)f;
+        if ((double)f <= a.isovalue) cube |= 1 << m;          // marchingcubes.h: `if(v[m] <= isovalue) cubeindex |= 1<<m`, in double
+    }
+    return cube;
+}
+
+__global__ void mesh_mc_count_kernel(VdnMeshMcArgs a) {
+    const long n = a.R - 1;
+    const long cell = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= n * n * n) return;
+    const int k = (int)(cell % n), j = (int)((cell / n) % n), i = (int)(cell / (n * n));
+    const int cube = mc_case(a, i, j, k, nullptr);
+    const int edges = mc_edge_mask(cube);
+    int nv = 0, nt = 0;
+#pragma unroll
+    for (int e = 0; e < 12; ++e)
+        if (((edges >> e) & 1) && mc_creates(e, i, j, k)) ++nv;
+    for (int t = 0; t < 16 && kMcTri[cube][t] >= 0; t += 3) ++nt;
+    a.cube_case[cell] = (unsigned char)cube;
+    a.n_verts[cell] = nv;
+    a.n_tris[cell] = nt;
+}
+
+__global__ void mesh_mc_emit_kernel(VdnMeshMcArgs a) {
+    const long n = a.R - 1;
+    const long cell = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= n * n * n) return;
+    const int cube = a.cube_case[cell];
+    const int edges = mc_edge_mask(cube);
+    if (edges == 0) return;
+    const int k = (int)(cell % n), j = (int)((cell / n) % n), i = (int)(cell / (n * n));
+    double v[8];
+    mc_case(a, i, j, k, v);
+    // this cell's own vertices, in the library's creation order; interpolated FROM corner a TO corner b of the edge, in double:
+    // (x_b - x_a) * (isovalue - f_a) / (f_b - f_a) + x_a, the midpoint when f_a == f_b  (mc_isovalue_interpolation)
+    long vo = a.vert_offsets[cell];
+    for (int o = 0; o < 12; ++o) {
+        const int e = kMcOrder[o];
+        if (!((edges >> e) & 1) || !mc_creates(e, i, j, k)) continue;
+        const int ca = kMcEdge[e][0], cb = kMcEdge[e][1];
+        double p[3] = {(double)(i + kMcCorner[ca][0]), (double)(j + kMcCorner[ca][1]), (double)(k + kMcCorner[ca][2])};
+        const int ax = kMcCorner[ca][0] != kMcCorner[cb][0] ? 0 : (kMcCorner[ca][1] != kMcCorner[cb][1] ? 1 : 2);
+        const double x1 = p[ax], x2 = (double)((ax == 0 ? i : (ax == 1 ? j : k)) + kMcCorner[cb][ax]);
+        const double f1 = v[ca], f2 = v[cb];
+        p[ax] = f2 == f1 ? (x2 + x1) / 2.0 : (x2 - x1) * (a.isovalue - f1) / (f2 - f1) + x1;
+        a.vertices[vo * 3 + 0] = p[0]; a.vertices[vo * 3 + 1] = p[1]; a.vertices[vo * 3 + 2] = p[2];
+        ++vo;
+    }
+    // triangles: the vertex of edge e lives with the first visited cell that contains the lattice edge
+    long to = a.tri_offsets[cell];
+    for (int t = 0; t < 16 && kMcTri[cube][t] >= 0; ++t) {
+        const int e = kMcTri[cube][t];
+        const int ca = kMcEdge[e][0], cb = kMcEdge[e][1];
+        const int ax = kMcCorner[ca][0] != kMcCorner[cb][0] ? 0 : (kMcCorner[ca][1] != kMcCorner[cb][1] ? 1 : 2);
+        // lattice position of the edge's lower end
+        const int lx = i + min(kMcCorner[ca][0], kMcCorner[cb][0]), ly = j + min(kMcCorner[ca][1], kMcCorner[cb][1]), lz = k + min(kMcCorner[ca][2], kMcCorner[cb][2]);
+        // owner: along the edge's axis the cell index is fixed; across it, the lower neighbour where one exists
+        const int oi = ax == 0 ? lx : max(lx - 1, 0), oj = ax == 1 ? ly : max(ly - 1, 0), ok = ax == 2 ? lz : max(lz - 1, 0);
+        const int dx = lx - oi, dy = ly - oj, dz = lz - ok;
+        // the owner's number for that edge
+        int oe;
+        if (ax == 0) oe = dy == 0 ? (dz == 0 ? 0 : 4) : (dz == 0 ? 2 : 6);
+        else if (ax == 1) oe = dx == 0 ? (dz == 0 ? 3 : 7) : (dz == 0 ? 1 : 5);
+        else oe = dx == 0 ? (dy == 0 ? 8 : 11) : (dy == 0 ? 9 : 10);
+        const long ocell = ((long)oi * n + oj) * n + ok;
+        const int oedges = mc_edge_mask(a.cube_case[ocell]);
+        int rank = 0;
+        for (int o = 0; o < 12 && kMcOrder[o] != oe; ++o) {
+            const int e2 = kMcOrder[o];
+            if (((oedges >> e2) & 1) && mc_creates(e2, oi, oj, ok)) ++rank;
+        }
+        a.triangles[to * 3 + t] = a.vert_offsets[ocell] + rank;
+    }
+}
+
 }  // namespace vdn
 
 static int mesh_check(const VdnMeshArgs* a) {
@@ -132,6 +244,21 @@ extern "C" int vdn_mesh_count(const VdnMeshArgs* a, void* stream) {
     if (mesh_check(a) != 0 || a->counts == nullptr) return -1;
     const long n = (long)(a->R - 1) * (a->R - 1) * (a->R - 1);
     hipLaunchKernelGGL(vdn::mesh_count_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int vdn_mesh_mc_count(const VdnMeshMcArgs* a, void* stream) {
+    if (a == nullptr || a->u == nullptr || a->R < 2 || a->cube_case == nullptr || a->n_verts == nullptr || a->n_tris == nullptr) return -1;
+    const long n = (long)(a->R - 1) * (a->R - 1) * (a->R - 1);
+    hipLaunchKernelGGL(vdn::mesh_mc_count_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int vdn_mesh_mc_emit(const VdnMeshMcArgs* a, void* stream) {
+    if (a == nullptr || a->u == nullptr || a->R < 2 || a->cube_case == nullptr || a->vert_offsets == nullptr || a->tri_offsets == nullptr ||
+        a->vertices == nullptr || a->triangles == nullptr) return -1;
+    const long n = (long)(a->R - 1) * (a->R - 1) * (a->R - 1);
+    hipLaunchKernelGGL(vdn::mesh_mc_emit_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
     return (int)hipGetLastError();
 }
 

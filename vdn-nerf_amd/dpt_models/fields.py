@@ -371,13 +371,14 @@ class NeRF(_HipNet):
             ent = self.__dict__.setdefault("_scratch", {}).get(key)
             if ent is None:
                 self.__dict__["_scratch"].clear()            # (one shape at a time: a new batch size replaces the old buffer)
-                ent = self.__dict__["_scratch"][key] = [torch.zeros(P * (4 + nf), dtype=torch.float32, device=dev), img._key]
-            elif ent[1] != img._key:
+                ent = self.__dict__["_scratch"][key] = [torch.zeros(P * (4 + nf), dtype=torch.float32, device=dev), img.builds]
+            elif ent[1] != img.builds:
                 # the parameters changed since the buffer was last zeroed (an optimizer step, a checkpoint reload): rows off the
                 # list may hold outputs of the OLD weights - non-finite ones if that state had diverged, and 0 * NaN would poison
                 # every later render. One fill per parameter change, none in a render loop
+                # (img.builds, not the parameters' version tuple: the Trainer's fused Adam does not move torch's version counters)
                 ent[0].zero_()
-                ent[1] = img._key
+                ent[1] = img.builds
             buf = ent[0]
         else:
             buf = (torch.empty if active is None else torch.zeros)(P * (4 + nf), dtype=torch.float32, device=dev)

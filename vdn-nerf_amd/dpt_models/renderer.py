@@ -45,13 +45,18 @@ def extract_fields(bound_min, bound_max, resolution, query_func, device=None):
     return extract_fields_device(bound_min, bound_max, resolution, query_func, device).cpu().numpy()
 
 
-def extract_geometry(bound_min, bound_max, resolution, threshold, query_func):
+def extract_geometry(bound_min, bound_max, resolution, threshold, query_func, method=None):
     """renderer.py:33-41 -> (vertices [V,3] float64 in world coordinates, triangles [F,3]). The reference triangulates with
-    the third-party PyMCubes; here the iso-surface is extracted on the device by marching tetrahedra (vdn_hip.mesh): the
-    same level set as a closed, consistently oriented, welded mesh, with a different (finer) triangulation."""
+    `mcubes.marching_cubes(u, threshold)` (third-party PyMCubes): vdn_hip.mesh.marching_cubes extracts the same mesh on the
+    device - the classic 256-case tables with the library's sequential vertex / triangle numbering, float64 vertices (restated
+    from its published source in oracle/marching_cubes.py; the package itself is absent here). `method="tets"` (or
+    VDN_MESH_METHOD=tets): rounds 3-5's marching tetrahedra - the same level set, a finer, different triangulation."""
     from vdn_hip import mesh
+    method = method or os.environ.get("VDN_MESH_METHOD", "cubes")
+    if method not in ("cubes", "tets"):
+        raise ValueError("method must be 'cubes' or 'tets', got %r" % (method,))
     u = extract_fields_device(bound_min, bound_max, resolution, query_func)
-    vertices, triangles = mesh.marching_tets(u, threshold)
+    vertices, triangles = mesh.marching_cubes(u, threshold) if method == "cubes" else mesh.marching_tets(u, threshold)
     b_max_np = np.asarray([float(v) for v in bound_max])
     b_min_np = np.asarray([float(v) for v in bound_min])
     vertices = vertices.cpu().numpy().astype(np.float64) / (resolution - 1.0) * (b_max_np - b_min_np)[None, :] + b_min_np[None, :]
@@ -116,13 +121,19 @@ class _RenderCoreFn(torch.autograd.Function):
         feats = c["feat_out"] if "feat_out" in c else color.new_zeros(0)
         # cdf_fine and gradients stay attached as in the reference (renderer.py:426-439; its own loss never uses them)
         cdf, normals = c["cdf"], c["normals"].view(engine.B, engine.N, 3)
-        aux = (c["inside"], c["bg_mid"] if engine.r.n_outside > 0 else c["mid_z"], c["eik"][1:3])
+        aux = tuple(t.detach() for t in (c["inside"], c["bg_mid"] if engine.r.n_outside > 0 else c["mid_z"], c["eik"][1:3]))
         ctx.mark_non_differentiable(*aux)
         # s_val = 1 / inv_s for every ray (renderer.py:324, 420: a function of the variance alone) and the two reductions of
         # `weights` (renderer.py:309, 431) are outputs of this node as well: their adjoints are folded in by backward() below
         # instead of nine small torch launches per forward
-        ctx.save_for_backward(weights, rays_o, rays_d, z, z_out)
-        return (color, feats, weights, eik, cdf, normals, c["s_val"], c["wsum"], c["wmax"]) + aux
+        # The outputs are as_strided views of ONE cloned arena (one copy launch instead of twelve). Handed out as views, autograd
+        # would mark them "views of a multi-output function" and refuse any in-place op on them (color_fine.clamp_() ...; ADVICE
+        # round 5): detach() makes each a plain tensor on the same storage - in-place ops are allowed again, and a saved output
+        # that is modified before backward() is still caught by the version counter. (What remains of the sharing: a retained
+        # output keeps the whole ~2 MB arena of its batch alive - INTEGRATION.md.)
+        outs = tuple(t.detach() for t in (color, feats, weights, eik, cdf, normals, c["s_val"], c["wsum"], c["wmax"]))
+        ctx.save_for_backward(outs[2], rays_o, rays_d, z, z_out)
+        return outs + aux
 
     @staticmethod
     def backward(ctx, g_color, g_feats, g_weights, g_eik, g_cdf, g_normals, g_sval, g_wsum, g_wmax, *unused):
@@ -164,7 +175,21 @@ class _RenderCoreFn(torch.autograd.Function):
 
 class NeuSRenderer:
     def __init__(self, nerf, sdf_network, deviation_network, color_network, depth_network, n_samples, n_importance,
-                 n_outside, up_sample_steps, perturb):
+                 n_outside, up_sample_steps, perturb, precision=None):
+        """Reference signature (renderer.py:78-88) plus ONE optional keyword the reference does not have:
+        precision = "fp32" | "bf16" | None - the kernels every network of this renderer runs on. "fp32": exact-f32 MFMA kernels, the
+        path the 1e-4 parity tests hold on (the default). "bf16": bf16-operand / fp32-accumulate kernels, the throughput path
+        (tests/test_gpu_bf16.py states its bounds). None: the environment variable VDN_PRECISION, read once here (default fp32) -
+        so an UNCHANGED dpt_runner.py runs on the bf16 kernels with `VDN_PRECISION=bf16 python dpt_runner.py ...`, or with the line
+        `precision = bf16` in the conf's `model.neus_renderer` block (the runner splats that block into this constructor)."""
+        if precision is None:
+            precision = os.environ.get("VDN_PRECISION", "").strip().lower() or None
+        if precision is not None:
+            if precision not in ("fp32", "bf16"):
+                raise ValueError("precision must be 'fp32' or 'bf16', got %r" % (precision,))
+            for m in (nerf, sdf_network, color_network, depth_network):
+                if m is not None:
+                    m.precision = precision
         self.nerf = nerf
         self.sdf_network = sdf_network
         self.deviation_network = deviation_network
@@ -184,6 +209,20 @@ class NeuSRenderer:
             # kernels implement the shipped pairing (womsk_white_wdepth: both on)
             raise ValueError("a depth_network needs a background NeRF with gen_depth_feats=True (the shipped wdepth configuration)")
         self._const_cache = {}
+
+    @property
+    def precision(self):
+        """The kernels' precision when all networks agree, else "mixed". Assigning sets every network (one line instead of four)."""
+        ps = {m.precision for m in (self.nerf, self.sdf_network, self.color_network, self.depth_network) if m is not None}
+        return ps.pop() if len(ps) == 1 else "mixed"
+
+    @precision.setter
+    def precision(self, value):
+        if value not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16', got %r" % (value,))
+        for m in (self.nerf, self.sdf_network, self.color_network, self.depth_network):
+            if m is not None:
+                m.precision = value
 
     # constant vectors whose rounding must be torch.linspace's (renderer.py:335,340,352-354; 53)
     def _consts(self, dev):
@@ -577,7 +616,10 @@ class NeuSRenderer:
             # parameters go at once.
             for k in [k for k in engines if k[1:] != pkey]:
                 del engines[k]
-            while len(engines) >= 3:
+            # VDN_RENDER_ENGINES=1..3 (default 3) bounds how many stay alive: on a smaller or shared device one engine per renderer
+            # is the round-4 memory footprint, at the price of rebuilding when the batch size changes
+            keep = min(3, max(1, int(os.environ.get("VDN_RENDER_ENGINES", "3") or 3)))
+            while len(engines) >= keep:
                 del engines[next(iter(engines))]             # (dicts keep insertion order: the least recently used one)
             eng = TrainEngine(self, B, dev)
         engines[key] = eng                                   # (re-inserted: most recently used)
@@ -607,9 +649,10 @@ class NeuSRenderer:
     def extract_fields(self, bound_min, bound_max, resolution):
         return extract_fields(bound_min, bound_max, resolution, lambda pts: -self.sdf_network.sdf(pts))
 
-    def extract_geometry(self, bound_min, bound_max, resolution, threshold=0.0):
+    def extract_geometry(self, bound_min, bound_max, resolution, threshold=0.0, method=None):
+        """renderer.py:441-446. `method` (not a reference argument): "cubes" (default, PyMCubes' mesh) or "tets"."""
         return extract_geometry(bound_min, bound_max, resolution=resolution, threshold=threshold,
-                                query_func=lambda pts: -self.sdf_network.sdf(pts))
+                                query_func=lambda pts: -self.sdf_network.sdf(pts), method=method)
 
 
 class RenderPlan:

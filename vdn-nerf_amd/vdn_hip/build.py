@@ -75,6 +75,45 @@ def _compile(src, force, hm):
     return src, time.time() - t, r.stderr
 
 
+def scan_m0_writers(lib_path=None):
+    """Post-link gate (every library variant: VDN_BUILD_VARIANT too). csrc/vdn_common.h glds16_imm*: a wave's LDS-DMA pieces of one
+    chunk share ONE write of M0 (the LDS destination base), made by the first piece's statement and read by the others up to a
+    chunk step later; the later statements cannot declare that dependency to the compiler. It holds as long as nothing else
+    writes M0 in between: every instruction with M0 as destination, in every kernel that issues LDS-DMA, must be the head of one
+    of the DMA statements (`s_mov_b32 / s_add_u32 m0` - `s_nop 0` - `global_load_lds_dwordx4`). A foreign writer (a compiler
+    upgrade that starts using M0, a new build flag) would land weights in the wrong LDS slot silently - so the build fails
+    instead. -> (kernels scanned, M0 writes seen); raises RuntimeError on a violation; (0, 0) when llvm-objdump is missing."""
+    import re
+    import shutil
+    import tempfile
+    lib_path = lib_path or LIB
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        return 0, 0
+    kernels = writes = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        shutil.copy(lib_path, os.path.join(tmp, "lib.so"))
+        subprocess.run([objdump, "--offloading", os.path.join(tmp, "lib.so")], check=True, capture_output=True, cwd=tmp)
+        for f in sorted(os.listdir(tmp)):
+            if "amdgcn" not in f:
+                continue
+            dis = subprocess.run([objdump, "-d", os.path.join(tmp, f)], check=True, capture_output=True, text=True).stdout
+            for fn in re.split(r"\n(?=[0-9a-f]{16} <)", dis):          # functions, at the symbol labels
+                if "global_load_lds_dwordx4" not in fn:
+                    continue
+                kernels += 1
+                name = fn.split("\n", 1)[0]
+                lines = [ln.split("//")[0].strip() for ln in fn.splitlines()[1:] if ln.strip()]
+                for i, ln in enumerate(lines):
+                    parts = ln.replace(",", " ").split()
+                    if len(parts) >= 2 and parts[1] == "m0" and not parts[0].startswith(("s_cmp", "s_bitcmp")):     # M0 as the destination
+                        writes += 1
+                        if parts[0] not in ("s_mov_b32", "s_add_u32") or not (
+                                i + 2 < len(lines) and lines[i + 1].startswith("s_nop") and lines[i + 2].startswith("global_load_lds_dwordx4")):
+                            raise RuntimeError("%s: M0 is written outside an LDS-DMA statement in %s: %r" % (os.path.basename(lib_path), name, lines[i:i + 3]))
+    return kernels, writes
+
+
 def build(force=False, jobs=None, verbose=True):
     os.makedirs(OBJDIR, exist_ok=True)
     srcs = _sources()
@@ -93,8 +132,13 @@ def build(force=False, jobs=None, verbose=True):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr[-4000:])
+        try:
+            k, w = scan_m0_writers(LIB)
+        except RuntimeError:
+            os.replace(LIB, LIB + ".rejected")          # never leave a library that failed the gate where lib.load() finds it
+            raise
         if verbose:
-            print("[vdn_hip.build] linked", LIB, flush=True)
+            print("[vdn_hip.build] linked %s (M0 gate: %d LDS-DMA kernels, %d M0 writes, all inside DMA statements)" % (LIB, k, w), flush=True)
     return LIB
 
 

@@ -107,6 +107,10 @@ class NetImages:
         self.matrices = matrices
         self.streams = streams
         self._key = None
+        # counts every (re)build and every invalidation of the images: what "the weights changed" means to consumers that cache
+        # something derived from them (fields.py: the NeRF scratch buffer). torch's version counters are not enough - the Trainer's
+        # fused Adam writes parameters through raw pointers and refresh_together() then stores the SAME version tuple again.
+        self.builds = 0
         names = list(matrices)
         self.names = names
         sizes = [matrices[n][1].numel() for n in names]
@@ -193,6 +197,7 @@ class NetImages:
     def invalidate(self):
         """Parameters were written outside torch's version tracking (fused Adam through raw pointers)."""
         self._key = None
+        self.builds += 1
 
     def _params(self):
         return [t for n in self.names for t in self.matrices[n] if t is not None]
@@ -219,6 +224,7 @@ class NetImages:
         lib.call("vdn_weightnorm_materialize", lib.ptr(self.wn_table), self._n_wn, self.max_rows, stream)
         lib.call("vdn_build_images", lib.ptr(self.chunk_table), self._n_ch, stream)
         self._key = key
+        self.builds += 1
         return True
 
 
@@ -249,6 +255,7 @@ def refresh_together(images, stream, cache):
     lib.call("vdn_build_images", lib.ptr(cache["ch"]), cache["n_ch"], stream)
     for im in images:
         im._key = tuple(t._version for t in im._params())
+        im.builds += 1
 
 
 # ---------------------------------------------------------------------------------------------

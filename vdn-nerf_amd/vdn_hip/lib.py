@@ -16,7 +16,7 @@ HEADER = os.path.join(os.path.dirname(PKG), "include", "vdn_render.h")
 # (VDN_LIB: another build of the same library, for A/B timing of compile-time switches inside one gpurun call; development only)
 LIB_PATH = os.environ.get("VDN_LIB") or os.path.join(HERE, "libvdn_render.so")
 
-_SCALARS = {"int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "int": ctypes.c_int}
+_SCALARS = {"int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "int": ctypes.c_int, "double": ctypes.c_double}
 
 
 def _strip_comments(text):

@@ -19,6 +19,34 @@ import torch
 import torch.distributed as dist
 
 
+# The second communicator (same ranks as the world) is made ONCE per process and shared by every Trainer on the world group
+# (round 6: bench.py builds a Trainer per leg - six RCCL communicators per rank, none destroyed, was the round-5 state).
+# dist.new_group is collective over the world, so the first data-parallel Trainer must be constructed by every rank - as before.
+_shared_side_group = None
+groups_created = 0          # process groups this module has created (tests/test_gpu_dp.py asserts <= 1 per process)
+
+
+def shared_side_group():
+    """The process-wide side communicator over all world ranks: created at the first call (collective: every rank calls it in the
+    same order), reused afterwards."""
+    global _shared_side_group, groups_created
+    if _shared_side_group is None:
+        _shared_side_group = dist.new_group(ranks=None)
+        groups_created += 1
+    return _shared_side_group
+
+
+def shutdown():
+    """Destroy the side communicator (before dist.destroy_process_group(), or when no Trainer of this process needs it again)."""
+    global _shared_side_group
+    if _shared_side_group is not None and dist.is_initialized():
+        try:
+            dist.destroy_process_group(_shared_side_group)
+        except Exception:       # the world group went first: nothing left to destroy
+            pass
+    _shared_side_group = None
+
+
 class Collectives:
     """The collectives of one Trainer, issued asynchronously on whatever torch stream is current at the call.
 
@@ -44,11 +72,12 @@ class Collectives:
         # background slice (side stream), the SDF slice (critical path: the next sampler waits for it), the heads' slice (side
         # stream), the next step's 8-byte eikonal sums (critical path). In one group the critical ones would queue behind the
         # side-stream slices and their GEMMs; the side-stream slices therefore get a communicator of their own (same ranks).
-        # Created by every rank in the same order (dist.new_group is collective). VDN_DP_SIDE_GROUP=0: one group for all.
+        # Created by every rank in the same order (dist.new_group is collective), once per process (shared_side_group above).
+        # VDN_DP_SIDE_GROUP=0: one group for all.
         self.side_group = group if side_group is None else side_group
         whole_world = group is None or (dist.is_initialized() and group is dist.group.WORLD)
         if self.enabled and side_group is None and whole_world and os.environ.get("VDN_DP_SIDE_GROUP", "1") != "0":
-            self.side_group = dist.new_group(ranks=None)
+            self.side_group = shared_side_group()
         # The gradient slices are summed IN the stream that made them (sum_now: torch.distributed's blocking form enqueues the
         # RCCL kernel on the current stream - no hop to the backend's stream and back, i.e. two marker packets and two queue
         # switches less per slice, on chains that wait for the sum at once anyway). The two small sums that DO overlap other

@@ -52,6 +52,6 @@ def build_renderer(wdepth=False, device="cuda", states=None, precision="fp32", c
         if m is not None:
             m.precision = precision          # "fp32" (parity) or "bf16" (throughput)
     mods = [m.to(device) for m in (nerf, sdf, var, col)] + ([vdn.to(device)] if wdepth else [None])
-    kw = dict(CONF["neus_renderer"])
+    kw = dict(CONF["neus_renderer"], precision=precision)     # (explicit: the VDN_PRECISION environment default does not apply here)
     kw.update(renderer_overrides)
     return NeuSRenderer(*mods, **kw)
