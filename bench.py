@@ -510,6 +510,7 @@ def precision_gap(head, dev, n_batches=4):
     mean |bf16 - fp32| / mean |fp32| over all rays of all batches; gradient_error is one scalar per batch (its relative error)."""
     from vdn_train import factory
     r16 = head.rend
+    head.trainer.join()                 # (the heads' / background network's parameters are updated on the Trainer's side stream)
     r32 = factory.build_renderer(wdepth=head.wdepth, device=dev, states=None, precision="fp32")
     with torch.no_grad():
         for name in ("nerf", "sdf_network", "deviation_network", "color_network", "depth_network"):
@@ -619,6 +620,11 @@ def main():
         head.trainer.coll.timing = True
         head.region(W + K, K)
         head.trainer.coll.timing = False
+        # communicators this job made beyond the world group, max over ranks (vdn_train/dp.py: ONE shared side group per process)
+        from vdn_train import dp as _dp
+        made = torch.tensor([_dp.groups_created], device=dev, dtype=torch.int32)
+        torch.distributed.all_reduce(made, op=torch.distributed.ReduceOp.MAX)
+        extras["dp_process_groups_created_max_over_ranks"] = int(made.item())
         extras["allreduce_exposed_ms"] = dict(head.trainer.coll.exposed_ms(), note="per call, bracketed by HIP events on the issuing stream: "
                                               "the gradient slices are summed IN that stream (the bracket is the collective itself: "
                                               "grad_sdf on the critical path, grad_nerf / grad_heads on the side stream); fg_count and "
@@ -823,8 +829,6 @@ def main():
         import torch.distributed as dist
         from vdn_train import dp
         dist.barrier()                 # rank 0 is still printing: leave together
-        if os.environ.get("VDN_BENCH_REPORT_GROUPS"):       # tests: how many communicators this rank made beyond the world group
-            print("bench.py rank %d: process groups created by vdn_train.dp: %d" % (rank, dp.groups_created), file=sys.stderr, flush=True)
         dp.shutdown()
         dist.destroy_process_group()
 

@@ -285,6 +285,9 @@ typedef struct {
     float* s_val;              /* [B] 1/inv_s */
     float* eik_partial;        /* [B,2] workspace */
     float* eik_out;            /* [3]: gradient_error, numerator, denominator */
+    const float* cos_anneal_dev; /* [1] device scalar or NULL. Non-NULL: the kernels read cos_anneal_ratio from it (the by-value field is
+                                  * ignored) - a launch captured once in a HIP graph then follows the runner's annealing schedule
+                                  * (dpt_runner.py:304-308) without a re-capture (ABI 28) */
 } VdnCompositeArgs;
 int vdn_alpha_composite_fwd(const VdnCompositeArgs* args_host, void* stream);
 /* d_feats = sum_i w_i * feature_i (renderer.py:306-308) alone, from the `weights` / `inside_sphere` a compositor launch has
@@ -561,6 +564,7 @@ typedef struct {
     /* optional scratch for the feature channels, [B*(2T+N)] floats: with it the per-sample feature dot products and the outer
      * products d_feat / d_bg_feat run as two streaming launches around the per-ray kernel (which has only 2 waves per CU) */
     float* feat_scratch;
+    const float* cos_anneal_dev; /* [1] device scalar or NULL: as VdnCompositeArgs.cos_anneal_dev */
 } VdnCompositeBwdArgs;
 int vdn_alpha_composite_bwd(const VdnCompositeBwdArgs* args_host, void* stream);
 

@@ -262,6 +262,91 @@ def test_engines_of_alternating_batch_sizes_stay_alive():
     assert sorted(k[0] for k in rend.__dict__["_engines"]) == [11, 20, 64]
 
 
+@pytest.mark.parametrize("precision,wdepth", [("bf16", False), ("fp32", False), ("bf16", True)])
+def test_graph_replayed_steps_equal_eager_steps(precision, wdepth, monkeypatch):
+    """render() under grad from its second call on is a HIP-graph replay (dpt_models/renderer.py::_TrainPlan: sampler + forward,
+    and the backward per adjoint pattern). Five optimizer steps with a changing cos_anneal_ratio, a changing background colour
+    and injected jitter: every output of every step and every parameter after the last step are BIT-identical to the same steps
+    with VDN_RENDER_GRAPHS=0 - and the replayed steps really were replays."""
+    from vdn_train import synth, factory
+    dev = torch.device("cuda:0")
+    cams = synth.make_cameras(5)
+    tt = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32, device=dev)
+    B = 40
+
+    def run(graphs):
+        monkeypatch.setenv("VDN_RENDER_GRAPHS", "1" if graphs else "0")
+        rend = factory.build_renderer(wdepth=wdepth, device=dev, states=synth.make_all_states(5, wdepth=wdepth, variance=0.45), precision=precision)
+        params = rend._all_parameters()
+        opt = torch.optim.Adam(params, lr=1e-3)
+        outs = []
+        for it in range(5):
+            o, d = synth.random_pixel_batch(5, it, it % 3, B, cams=cams)
+            near, far = synth.near_far_from_sphere(o, d)
+            t1, t2 = synth.jitter(5, it, B)
+            bg = torch.full((1, 3), 1.0 - 0.1 * it, device=dev)
+            out = rend.render(tt(o), tt(d), tt(near), tt(far), background_rgb=bg, cos_anneal_ratio=0.2 * it,
+                              t_rand=tt(t1), t_rand_out=tt(t2))
+            mask = torch.ones(B, 1, device=dev)
+            loss = (out["color_fine"] - tt(synth.target_colors(o, d))).abs().sum() / B + 0.1 * out["gradient_error"] \
+                + 0.0 * F.binary_cross_entropy(out["weight_sum"].clip(1e-3, 1.0 - 1e-3), mask)
+            if wdepth:
+                loss = loss + 0.5 * out["render_feats"].abs().sum() / B
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            outs.append({k: v.detach().clone() for k, v in out.items() if torch.is_tensor(v)})
+        eng = next(iter(rend.__dict__["_engines"].values()))
+        plans = eng.__dict__.get("_plans", {})
+        return outs, [p.detach().clone() for p in params], plans
+
+    ga, pa, plans = run(True)
+    assert len(plans) == 1 and len(next(iter(plans.values())).bwd) == 1       # one forward graph, one backward graph (one adjoint pattern)
+    gb, pb, none = run(False)
+    assert not none
+    for it, (a, b) in enumerate(zip(ga, gb)):
+        assert a.keys() == b.keys()
+        for k in a:
+            assert torch.equal(a[k], b[k]), (it, k, float((a[k] - b[k]).abs().max()))
+    assert all(torch.equal(x, y) for x, y in zip(pa, pb))
+
+
+def test_graph_plan_draws_fresh_jitter_and_follows_forward_only_loops():
+    """Without injected jitter the plan's sampler draws inside the graph: consecutive replays on the same rays differ (perturb = 1)
+    and are equal with perturb_overwrite = 0; render() under grad without a backward in between (the runner's image loops,
+    dpt_runner.py:439-445) replays as well; a loss that reads `gradients` falls back to the eager re-run of the forward."""
+    from vdn_train import synth, factory
+    dev = torch.device("cuda:0")
+    rend = factory.build_renderer(device=dev, states=synth.make_all_states(6, variance=0.4), precision="bf16")
+    cams = synth.make_cameras(6)
+    tt = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32, device=dev)
+    B = 48
+    o, d = synth.random_pixel_batch(6, 0, 1, B, cams=cams)
+    near, far = synth.near_far_from_sphere(o, d)
+    args = (tt(o), tt(d), tt(near), tt(far))
+    bg = torch.ones(1, 3, device=dev)
+    cols = [rend.render(*args, background_rgb=bg, cos_anneal_ratio=1.0)["color_fine"].detach().clone() for _ in range(4)]
+    assert not torch.equal(cols[2], cols[3]) and float((cols[2] - cols[3]).abs().max()) < 0.2
+    fix = [rend.render(*args, background_rgb=bg, cos_anneal_ratio=1.0, perturb_overwrite=0)["color_fine"].detach().clone() for _ in range(3)]
+    assert torch.equal(fix[0], fix[1]) and torch.equal(fix[1], fix[2])          # eager, then two replays
+    eng = next(iter(rend.__dict__["_engines"].values()))
+    assert len(eng.__dict__["_plans"]) == 2
+    # a loss on `gradients`: the adjoint reaches the samples the work list skipped - eager forward over every sample, eager backward
+    out = rend.render(*args, background_rgb=bg, cos_anneal_ratio=1.0, perturb_overwrite=0)
+    (out["gradients"].square().sum() + out["color_fine"].sum()).backward()
+    g1 = [p.grad.clone() for p in rend._all_parameters()]
+    os_env = __import__("os").environ
+    os_env["VDN_RENDER_GRAPHS"] = "0"
+    try:
+        for p in rend._all_parameters():
+            p.grad = None
+        out = rend.render(*args, background_rgb=bg, cos_anneal_ratio=1.0, perturb_overwrite=0)
+        (out["gradients"].square().sum() + out["color_fine"].sum()).backward()
+    finally:
+        del os_env["VDN_RENDER_GRAPHS"]
+    assert all(torch.equal(a, p.grad) for a, p in zip(g1, rend._all_parameters()))
+
+
 def test_outputs_of_render_under_grad_allow_inplace_ops():
     """render() under grad hands out plain tensors (they were views of one arena, and autograd refuses in-place ops
     on the views of a multi-output node): color_fine.clamp_() and weight_sum.clip_() work, backward() still reaches every

@@ -24,6 +24,9 @@ timed(T.TrainEngine, "outputs_clone", "outputs_clone")
 timed(R.NeuSRenderer, "_sample", "_sample")
 timed(R.NeuSRenderer, "_render_train", "_render_train")
 timed(R.NeuSRenderer, "render", "render")
+timed(R._TrainPlan, "stage", "plan.stage")
+timed(R._TrainPlan, "replay_forward", "plan.replay_forward")
+timed(R._TrainPlan, "replay_backward", "plan.replay_backward")
 dev = torch.device("cuda:0")
 seed, B = 0, 512
 rend = factory.build_renderer(wdepth=False, device=dev, states=synth.make_all_states(seed), precision=sys.argv[1] if len(sys.argv) > 1 else "bf16")

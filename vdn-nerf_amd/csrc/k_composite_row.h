@@ -48,7 +48,7 @@ VDN_DEV RowOut composite_row(const CompositeArgs& a, int r, int lane, const Src&
     }
     float inv_s = expf(a.variance[0] * 10.0f);                     // fields.py:364
     inv_s = fminf(fmaxf(inv_s, 1e-6f), 1e6f);                      // renderer.py:262
-    const float car = a.cos_anneal_ratio;
+    const float car = a.cos_anneal_dev != nullptr ? a.cos_anneal_dev[0] : a.cos_anneal_ratio;      // (device scalar: graph-captured launches)
 
     float alpha[kEPL], f[kEPL], Tr[kEPL], wgt[kEPL], col[kEPL][3], ins[kEPL];
     double eik_num = 0.0, eik_den = 0.0;

@@ -105,7 +105,7 @@ VDN_DEV void composite_bwd_row(const CompositeBwdArgs& a, int r, int wave, int l
     const float inv_s_raw = expf(var * 10.0f);
     const float inv_s = fminf(fmaxf(inv_s_raw, 1e-6f), 1e6f);
     const bool s_unclipped = inv_s_raw >= 1e-6f && inv_s_raw <= 1e6f;
-    const float car = a.cos_anneal_ratio;
+    const float car = a.cos_anneal_dev != nullptr ? a.cos_anneal_dev[0] : a.cos_anneal_ratio;      // (device scalar: graph-captured launches)
     const float g_eik = ov.on ? ov.g_eik : (a.g_eik != nullptr ? a.g_eik[0] : 0.0f);
     const float eik_den = ov.on ? ov.eik_den : a.eik[2] + 1e-5f;
     float bgc[3] = {0.0f, 0.0f, 0.0f};

@@ -113,26 +113,31 @@ class _RenderCoreFn(torch.autograd.Function):
         # everywhere: a loss on `gradients` or `cdf_fine` (the reference's own loss uses neither, dpt_runner.py:215-243).
         ctx.skipped = not ctx.ray_grads and os.environ.get("VDN_RENDER_FG_COMPACT", "1") != "0"
         ctx.fwd_args = (bgc, car)
-        w = engine.forward(rays_o, rays_d, z, z_out, bgc, car, ray_grads=ctx.ray_grads, skip_far=ctx.skipped, rest_normals=ctx.skipped)
+        # a _TrainPlan (below): sampler + this forward were captured once as a HIP graph on the plan's fixed input buffers
+        # (rays_o ... z_out ARE those buffers); one replay instead of ~20 launches issued from Python
+        ctx.plan = plan = engine.__dict__.pop("_plan_call", None)
+        if plan is not None:
+            plan.replay_forward(engine)
+        else:
+            engine.forward(rays_o, rays_d, z, z_out, bgc, car, ray_grads=ctx.ray_grads, skip_far=ctx.skipped, rest_normals=ctx.skipped)
         ctx.skipped = ctx.skipped and engine._fg_compact
         ctx.engine, ctx.generation, ctx.n_params = engine, engine.generation, len(params)
         c = engine.outputs_clone()                # one copy: the engine's buffers are rewritten by the next forward
         color, weights, eik = c["color"], c["weights"], c["eik"][0]
         feats = c["feat_out"] if "feat_out" in c else color.new_zeros(0)
         # cdf_fine and gradients stay attached as in the reference (renderer.py:426-439; its own loss never uses them)
-        cdf, normals = c["cdf"], c["normals"].view(engine.B, engine.N, 3)
-        aux = tuple(t.detach() for t in (c["inside"], c["bg_mid"] if engine.r.n_outside > 0 else c["mid_z"], c["eik"][1:3]))
+        cdf, normals = c["cdf"], c["normals"].view(engine.B, engine.N, 3).detach()       # (detach: a tensor of its own, not a view)
+        aux = (c["inside"], c["bg_mid"] if engine.r.n_outside > 0 else c["mid_z"], c["eik"][1:3].detach())
         ctx.mark_non_differentiable(*aux)
         # s_val = 1 / inv_s for every ray (renderer.py:324, 420: a function of the variance alone) and the two reductions of
         # `weights` (renderer.py:309, 431) are outputs of this node as well: their adjoints are folded in by backward() below
         # instead of nine small torch launches per forward
-        # The outputs are as_strided views of ONE cloned arena (one copy launch instead of twelve). Handed out as views, autograd
-        # would mark them "views of a multi-output function" and refuse any in-place op on them (color_fine.clamp_() ...; ADVICE
-        # round 5): detach() makes each a plain tensor on the same storage - in-place ops are allowed again, and a saved output
-        # that is modified before backward() is still caught by the version counter. (What remains of the sharing: a retained
-        # output keeps the whole ~2 MB arena of its batch alive - INTEGRATION.md.)
-        outs = tuple(t.detach() for t in (color, feats, weights, eik, cdf, normals, c["s_val"], c["wsum"], c["wmax"]))
-        ctx.save_for_backward(outs[2], rays_o, rays_d, z, z_out)
+        # The outputs share ONE cloned arena (one copy launch instead of twelve) as tensors of their own (TrainEngine.outputs_clone:
+        # not views, separate version counters): in-place ops on them are allowed (color_fine.clamp_() ...), and a
+        # saved output that is modified before backward() is still caught. (What remains of the sharing: a retained output keeps
+        # the whole ~2 MB arena of its batch alive - INTEGRATION.md.)
+        outs = (color, feats, weights, eik.detach(), cdf, normals, c["s_val"], c["wsum"], c["wmax"])
+        ctx.save_for_backward(weights, rays_o, rays_d, z, z_out)
         return outs + aux
 
     @staticmethod
@@ -151,10 +156,14 @@ class _RenderCoreFn(torch.autograd.Function):
         if g_wmax is not None:                    # weight_max = weights.max(-1, keepdim=True)[0]: to the (first) arg max
             hot = torch.zeros_like(weights).scatter_(1, weights.argmax(dim=-1, keepdim=True), g_wmax)
             g_weights = hot if g_weights is None else g_weights + hot
-        if g_weights is not None:
-            g_weights = g_weights.contiguous()
         g_feats = g_feats if (g_feats is not None and g_feats.numel() > 0) else None
-        eng.backward(g_color, g_feats, g_weights, g_eik, g_cdf=g_cdf, g_gradients=g_normals)
+        plan = ctx.plan
+        if plan is not None and g_cdf is None and g_normals is None and not ctx.ray_grads and plan.replay_backward(eng, g_color, g_feats, g_weights, g_eik):
+            pass                                  # (the captured launch sequence of eng.backward on staged adjoints)
+        else:
+            if g_weights is not None:
+                g_weights = g_weights.contiguous()
+            eng.backward(g_color, g_feats, g_weights, g_eik, g_cdf=g_cdf, g_gradients=g_normals)
         flat = eng.param_grads(clone=True)        # clones: the engine's buffers are reused by the next step
         assert len(flat) == ctx.n_params
         if g_sval is not None:
@@ -171,6 +180,94 @@ class _RenderCoreFn(torch.autograd.Function):
                     w["d_z_out"].clone() if "d_z_out" in w else None)
             rays = tuple(g if need else None for g, need in zip(rays, ctx.needs_input_grad[1:5]))
         return (None,) + rays + (None, None) + tuple(flat)
+
+
+# environment switches that select launches inside the captured region: a plan is valid for one setting of them
+_PLAN_ENV = ("VDN_RENDER_FG_COMPACT", "VDN_FG_COMPACT", "VDN_BG_COMPACT", "VDN_FUSED_PREP", "VDN_TRAIN_COLOR_FUSED", "VDN_SDF_TAIL",
+             "VDN_SDF_TAIL_ROW0", "VDN_SDF_TAIL_MAX", "VDN_BWD_SPLIT_DW", "VDN_SDF_BWD_SPLIT", "VDN_FUSE_ROUNDS", "VDN_FUSE_SDF_ROUNDS")
+# engine attributes forward() leaves for backward(): a replayed forward restores them as the capture left them
+_PLAN_STATE = ("_ctx", "_fg_compact", "_bg_compact", "_composite_bwd_done", "_bwd_train", "_pending", "_ray_grads", "_color_fused",
+               "_car_dev", "_fwd_rays", "_fused_keep")
+
+
+class _TrainPlan:
+    """render() under grad of one batch size as HIP graphs (round 6; what RenderPlan is for the inference path). An unchanged
+    dpt_runner.py spends more host time per step than the device needs: ~0.5 ms of Python in render() and ~0.25 ms in
+    this package's share of loss.backward(), most of it ~45 ctypes launches whose argument blocks are refilled field by field.
+    The plan captures, once per (renderer, batch size, configuration):
+      * forward: the sampler (renderer.py:334-386, its jitter drawn by a generator call INSIDE the graph) + TrainEngine.forward on
+        fixed input buffers; the annealing ratio comes from a device scalar (VdnCompositeArgs.cos_anneal_dev), so the runner's
+        schedule (dpt_runner.py:304-308) needs no re-capture;
+      * backward, per pattern of present adjoints: TrainEngine.backward on staged adjoints, side-stream work included
+        (fork / join events become graph dependencies).
+    A step is then: one multi-tensor copy of the inputs, one replay, one copy of the outputs' arena; in backward one copy per
+    adjoint, one replay, one multi-tensor copy of the gradients. Row counts of the work lists are device-side and every grid is
+    sized for the full batch, so the graphs are independent of the data. Built by NeuSRenderer at the SECOND call with a key (the
+    first ran eagerly: lazy workspaces, kernel attributes and weight images exist); `VDN_RENDER_GRAPHS=0` turns it off."""
+
+    def __init__(self, rend, eng, has_bg, perturb, inject):
+        B, dev, O = eng.B, eng.dev, rend.n_outside
+        f = lambda *sh: torch.zeros(*sh, dtype=torch.float32, device=dev)
+        self.rays_o, self.rays_d, self.near, self.far = f(B, 3), f(B, 3), f(B), f(B)
+        self.rays_d[:, 2] = 1.0
+        self.far.fill_(1.0)
+        self.bgc = f(3) if has_bg else None
+        self.car, self._car_host = f(1), 0.0
+        self.t_rand, self.t_rand_out = (f(B, 1), f(B, O) if O > 0 else None) if inject else (None, None)
+        self.perturb = perturb
+        self._dst = [self.rays_o, self.rays_d, self.near, self.far] + ([self.bgc] if has_bg else []) + \
+                    ([self.t_rand] + ([self.t_rand_out] if O > 0 else []) if inject else [])
+        self.bwd = {}
+        skip = os.environ.get("VDN_RENDER_FG_COMPACT", "1") != "0"
+        g = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(g):
+            z, z_out = rend._sample(self.rays_o, self.rays_d, self.near, self.far, perturb, self.t_rand, self.t_rand_out, None)
+            z = z.contiguous()
+            eng.forward(self.rays_o, self.rays_d, z, z_out, self.bgc, 0.0, skip_far=skip, rest_normals=skip, cos_anneal_dev=self.car)
+        self.fwd, self.z, self.z_out = g, z, z_out
+        self.state = {k: eng.__dict__.get(k) for k in _PLAN_STATE}
+
+    def stage(self, rays_o, rays_d, near, far, background_rgb, car, t_rand, t_rand_out):
+        src = [rays_o, rays_d, near, far]
+        if self.bgc is not None:
+            src.append(background_rgb.detach().reshape(-1))
+        if self.t_rand is not None:
+            src.append(t_rand.detach().reshape(self.t_rand.shape))
+            if self.t_rand_out is not None:
+                src.append(t_rand_out.detach().reshape(self.t_rand_out.shape))
+        torch._foreach_copy_(self._dst, src)
+        car = float(car)
+        if car != self._car_host:
+            self.car.fill_(car)
+            self._car_host = car
+
+    def replay_forward(self, eng):
+        self.fwd.replay()
+        eng.__dict__.update(self.state)
+        eng._ctx = self.state["_ctx"][:3] + (self._car_host,) + self.state["_ctx"][4:]
+        eng.generation = getattr(eng, "generation", 0) + 1
+
+    def replay_backward(self, eng, g_color, g_feats, g_weights, g_eik):
+        """-> False when this call has to run eagerly (the engine has not run a backward yet)."""
+        pat = (g_color is not None, g_feats is not None, g_weights is not None, g_eik is not None)
+        ent = self.bwd.get(pat)
+        if ent is None:
+            if not getattr(eng, "_bwd_warm", False):
+                return False
+            B, dev = eng.B, eng.dev
+            f = lambda *sh: torch.zeros(*sh, dtype=torch.float32, device=dev)
+            bufs = (f(B, 3) if pat[0] else None, f(B, 96) if pat[1] else None, f(B, eng.T) if pat[2] else None, f(1) if pat[3] else None)
+            g = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(g):
+                eng.backward(bufs[0], bufs[1], bufs[2], bufs[3])
+            eng.__dict__.update(self.state)
+            ent = self.bwd[pat] = (g, bufs)
+        g, bufs = ent
+        for dst, src in zip(bufs, (g_color, g_feats, g_weights, g_eik)):
+            if dst is not None:
+                dst.copy_(src.reshape(dst.shape) if src.numel() == dst.numel() else src)       # (g_weights may be an expanded view)
+        g.replay()
+        return True
 
 
 class NeuSRenderer:
@@ -395,6 +492,13 @@ class NeuSRenderer:
             # each network of the engine) skip their own staleness test (a walk over the parameters' versions and addresses)
             _images.trust(ims)
             try:
+                if attached is None and z_vals_inject is None:
+                    # the second and later calls of a configuration: sampler + forward as one HIP-graph replay (_TrainPlan)
+                    eng = self._engine_for(B, dev, params)
+                    plan = self._plan_for(eng, background_rgb, perturb, t_rand, t_rand_out)
+                    if plan is not None:
+                        plan.stage(rays_o, rays_d, near, far, background_rgb, cos_anneal_ratio, t_rand, t_rand_out)
+                        return self._render_train(plan.rays_o, plan.rays_d, plan.z, plan.z_out, plan.bgc, cos_anneal_ratio, params, plan=plan, eng=eng)
                 z, z_out = self._sample(rays_o, rays_d, near, far, perturb, t_rand, t_rand_out, z_vals_inject, defer_last_merge=defer)
                 if attached is not None:
                     rays_o, rays_d, z, z_out = self._attach_rays(attached, near, far, z, z_out)
@@ -601,12 +705,10 @@ class NeuSRenderer:
             z_out_att = z_out + (far - far.detach()) * c
         return rays_o.contiguous(), rays_d.contiguous(), z_att, z_out_att
 
-    def _render_train(self, rays_o, rays_d, z, z_out, background_rgb, cos_anneal_ratio, params):
-        """Training path: same outputs, differentiable wrt every network parameter (dpt_runner.py:253)."""
+    def _engine_for(self, B, dev, params):
         from vdn_hip.train import TrainEngine
-        B, dev = rays_o.shape[0], rays_o.device
         engines = self.__dict__.setdefault("_engines", {})
-        pkey = (dev, tuple(p.data_ptr() for p in params))
+        pkey = (dev, tuple(p.data_ptr() for p in params), self.precision)
         key = (B,) + pkey
         eng = engines.pop(key, None)
         if eng is None:
@@ -623,6 +725,38 @@ class NeuSRenderer:
                 del engines[next(iter(engines))]             # (dicts keep insertion order: the least recently used one)
             eng = TrainEngine(self, B, dev)
         engines[key] = eng                                   # (re-inserted: most recently used)
+        return eng
+
+    def _plan_for(self, eng, background_rgb, perturb, t_rand, t_rand_out):
+        """The _TrainPlan of this call's configuration, or None (first call with the configuration, graphs off, jitter injected
+        only in part, a capture already in progress)."""
+        if os.environ.get("VDN_RENDER_GRAPHS", "1") == "0" or torch.cuda.is_current_stream_capturing():
+            return None
+        O = self.n_outside
+        inject = t_rand is not None or t_rand_out is not None
+        if inject and (t_rand is None or (O > 0 and t_rand_out is None) or perturb <= 0):
+            return None
+        key = (background_rgb is not None, float(perturb), inject, tuple(os.environ.get(k) for k in _PLAN_ENV))
+        plans = eng.__dict__.setdefault("_plans", {})
+        plan = plans.get(key)
+        if plan is None:
+            seen = eng.__dict__.setdefault("_plan_seen", {})
+            seen[key] = seen.get(key, 0) + 1
+            if seen[key] < 2:
+                return None                                  # the first call of a configuration runs eagerly (and warms everything up)
+            while len(plans) >= 4:
+                del plans[next(iter(plans))]
+            plan = plans[key] = _TrainPlan(self, eng, key[0], float(perturb), inject)
+        return plan
+
+    def _render_train(self, rays_o, rays_d, z, z_out, background_rgb, cos_anneal_ratio, params, plan=None, eng=None):
+        """Training path: same outputs, differentiable wrt every network parameter (dpt_runner.py:253).
+        plan: a _TrainPlan whose input buffers hold this call's rays (rays_o ... z_out are then the plan's own tensors)."""
+        B, dev = rays_o.shape[0], rays_o.device
+        if eng is None:
+            eng = self._engine_for(B, dev, params)
+        if plan is not None:
+            eng._plan_call = plan
         bgc = None
         if background_rgb is not None:
             bgc = background_rgb.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous()

@@ -431,7 +431,7 @@ class TrainEngine:
         return w
 
     def forward(self, rays_o, rays_d, z, z_out, background_rgb, cos_anneal_ratio, skip_far=False, ray_grads=False, pending_merge=None,
-                after_sdf=None, fuse_loss=None, before_heads=None, rest_normals=False):
+                after_sdf=None, fuse_loss=None, before_heads=None, rest_normals=False, cos_anneal_dev=None):
         """Differentiable part of render() at detached z [B,N] (+ z_out [B,O]); returns the output tensors.
         skip_far (the Trainer's hot loop): inside samples beyond the relaxed sphere (|p| >= 1.2: inside_sphere = 0 and
         relax_inside_sphere = 0, renderer.py:284-286) enter the loss only through exact zeros, so the SDF / colour / VDN
@@ -444,12 +444,15 @@ class TrainEngine:
         colour term's gradient and the compositor's adjoint run as ONE launch (vdn_composite_train); backward() then starts at
         the heads. With the VDN head and the dict's gt_feats / g_feats / depth_weight: vdn_composite_fwd_train here and
         vdn_composite_bwd_train in backward() (the loss gradients are made inside them). Needs skip_far (the eikonal denominator
-        is the foreground list's length)."""
+        is the foreground list's length).
+        cos_anneal_dev: a [1] device tensor the compositor (and its adjoint in backward()) reads cos_anneal_ratio from instead of the
+        by-value argument (VdnCompositeArgs.cos_anneal_dev): launches captured in a HIP graph follow a changing ratio."""
         r, w, B, N, T = self.r, self.w, self.B, self.N, self.T
         st = _stream()
         if ray_grads and skip_far:
             raise ValueError("ray gradients need every inside sample evaluated (skip_far=False)")
         self._ray_grads = bool(ray_grads)
+        self._car_dev = cos_anneal_dev
         self._fwd_rays = (rays_o, rays_d)
         if ray_grads:
             self._ray_workspaces()
@@ -815,6 +818,8 @@ class TrainEngine:
         if background_rgb is not None:
             c.background_rgb = background_rgb.data_ptr()
         c.cos_anneal_ratio = float(cos_anneal_ratio)
+        if getattr(self, "_car_dev", None) is not None:
+            c.cos_anneal_dev = self._car_dev.data_ptr()
         c.B, c.N, c.T = self.B, self.N, self.T
         return c
 
@@ -863,6 +868,7 @@ class TrainEngine:
         heads_event=False when it will hand side_weight_grads / rest_weight_grads an `after` event recorded later on this stream
         (which then also covers the heads' backward)."""
         r, w, st = self.r, self.w, _stream()
+        self._bwd_warm = True           # (render()'s graph plans capture a backward only after one ran eagerly: lazy one-time set-up is done)
         rays_o, rays_d, background_rgb, car, z = self._ctx
         keep = [t.contiguous() if t is not None else None for t in (g_color, g_feat, g_weights, g_eik, g_cdf, g_gradients)]
         g_color, g_feat, g_weights, g_eik, g_cdf, g_gradients = keep
@@ -997,7 +1003,12 @@ class TrainEngine:
         a = self._out_arena.clone()
         if self.__dict__.get("_out_strided") is None:
             self._out_strided = [(k, tuple(sh), tuple(torch.empty(sh, device="meta").stride()), o) for k, (o, sh) in self._out_slots.items()]
-        return {k: a.as_strided(sh, st, o) for k, sh, st, o in self._out_strided}
+        # Tensor.set_ on the copy's storage, not as_strided / detach: each output is then a tensor of its own - not a view (autograd
+        # refuses in-place ops on the views a multi-output node returns: ADVICE round 5) and with its OWN version counter (views and
+        # detach() aliases share their base's: an in-place op on one output would read as a modification of every other one that
+        # somebody saved for backward)
+        st, base = a.untyped_storage(), a.storage_offset()
+        return {k: torch.empty(0, dtype=torch.float32, device=a.device).set_(st, base + o, sh, sd) for k, sh, sd, o in self._out_strided}
 
     def param_grads(self, clone=True):
         """Per-parameter gradients in renderer._all_parameters() order."""
