@@ -244,3 +244,31 @@ def test_nothing_but_the_dma_statements_writes_m0_in_the_weight_stream_kernels()
         pytest.skip("no llvm-objdump")
     kernels, writes = build.scan_m0_writers(build.LIB)
     assert kernels >= 20 and writes >= 1000
+
+
+def test_the_16x16x32_arm_of_the_fused_sdf_kernel_still_builds(tmp_path):
+    """csrc/k_sdf_fwd2.h carries a second MFMA shape behind -DVDN_SDF2_S16=1 (built for the round-6 A/B, level in wall
+    time, not shipped). It lives in the development harness only, so nothing else would notice if an edit broke it: compile the
+    sdf-only mode of it (the quickest instantiation) and check that the object holds the shape it claims - and the product library
+    the other one."""
+    import os
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if shutil.which("hipcc") is None or not os.path.exists(os.path.join(llvm, "llvm-objdump")):
+        pytest.skip("no hipcc / llvm-objdump")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    obj = tmp_path / "s16.o"
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
+           "-I", os.path.join(root, "include"), "-I", os.path.join(root, "vdn-nerf_amd", "csrc"),
+           "-DVARIANT_ID=1", "-DVTAG=t16", "-DVM=0", "-DVS=0", "-DVN=4", "-DVD=3", "-DVDN_SDF2_S16=1",
+           "-c", os.path.join(root, "tools", "dev", "sdf2_variant.hip"), "-o", str(obj)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", str(obj)], check=True, capture_output=True, cwd=tmp_path)
+    code = [f for f in os.listdir(tmp_path) if "amdgcn" in f]
+    assert code
+    dis = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", str(tmp_path / code[0])], check=True, capture_output=True, text=True).stdout
+    n16, n32 = dis.count("v_mfma_f32_16x16x32_bf16"), dis.count("v_mfma_f32_32x32x16_bf16")
+    assert n16 >= 1000 and n32 == 0, (n16, n32)
+    assert "scratch_" not in dis                      # no register spills in the arm
