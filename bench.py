@@ -37,7 +37,7 @@ import torch
 # algorithmic FLOPs (2 per MAC, GEMM work only) - SURVEY.md 8d
 F_SDF, F_SDF1, F_GRAD, F_COL, F_VDN, F_NERF, F_NERF_DPT = 1049088, 918016, 918016, 542720, 590336, 1208320, 1232896
 PEAK = {"f32": 157.3e12, "bf16": 2.5e15}     # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
-PROFILE_ROUND = "r05"      # profiles/<round>_traffic_*.json: the PMC traffic figures quoted in `roofline.traffic`
+PROFILE_ROUND = "r06"      # profiles/<round>_traffic_*.json: the PMC traffic figures quoted in `roofline.traffic`
 
 
 def _profile_file(suffix):
