@@ -262,7 +262,12 @@ int main(int argc, char** argv) {
                 }
             }
         }
-        printf("check %-44s sdf abs err %.3e", name, e_sdf);
+        // FNV-1a over the raw output bits: variants that differ only in scheduling (ring depth, barrier cadence) must agree to the bit
+        unsigned long long hsh = 1469598103934665603ull;
+        auto eat = [&](const void* q, size_t n) { const unsigned char* c = (const unsigned char*)q; for (size_t i = 0; i < n; ++i) { hsh ^= c[i]; hsh *= 1099511628211ull; } };
+        eat(o_sdf.data(), (size_t)P * 4);
+        if (full) { eat(o_n.data(), (size_t)P * 12); eat(o_f.data(), (size_t)P * 512); }
+        printf("check %-44s bits %016llx  sdf abs err %.3e", name, hsh, e_sdf);
         if (full) printf("  normal abs err %.3e (max |n| %.2f, min cosine %.6f)  feature abs err %.3e (max %.2f)", e_n, m_n, cosmin, e_f, m_f);
         printf("\n");
     };

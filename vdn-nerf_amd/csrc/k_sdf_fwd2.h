@@ -44,6 +44,15 @@ namespace sdf2 {
 #define VDN_SDF2_S16 0   // MFMA shape of the chunk steps: 0 = v_mfma_f32_32x32x16_bf16, 1 = v_mfma_f32_16x16x32_bf16 (same 32-point x 32-feature tile per wave)
 #endif
 constexpr bool kS16 = VDN_SDF2_S16 != 0;
+#ifndef VDN_SDF2_B2
+// Barrier cadence of instantiations whose ring has DEPTH + 2 slots (the others re-synchronise every chunk step): 1 = TWO chunks
+// certified per workgroup barrier, i.e. one barrier every second chunk step; 2 (default, round 6) = that in front of the sweep only;
+// 0 = every step. Same arithmetic, same bits; see chunk_step. Development harness, 65 536-point inference launch, variants
+// interleaved in one process (profiles/r06_sdf2_barrier_cadence_ab.log): 130 980 cycles per 128-point pass -> 128 268 (1: hidden step
+// 1 268 -> 1 193, but the sweep's 682 -> 730) -> 125 084 (2: 1 193 / 678), at an unchanged clock; launch 146.3 -> 141.8 us. Two builds
+// of the library on one box, alternating processes (profiles/r06_sdf2_barrier_cadence_library_ab.log): 148.2 -> 145.9 us (-1.5 %).
+#define VDN_SDF2_B2 2
+#endif
 constexpr int kStride = 20480;          // BF16::stride(9)
 constexpr int kTail = 9 * 2048 + 1024;  // row 0 of W8 (f32 x 256) in every chunk's tail (vdn_hip/images.py: SDF_TAIL_OFF)
 constexpr int kWaves = 4;
@@ -167,6 +176,15 @@ constexpr bool dma_burst(int c) { return tile_stores<MODE, SAVE>(c - 1) > 0; }
 // s_waitcnt vmcnt(N) that retires this wave's DMA of chunk c+1 in step c (before its barrier). Younger than that DMA
 // (issued during step c+1-DEPTH) are the DMAs of chunks c+2 .. c+DEPTH-1, the stores of steps c+2-DEPTH .. c-1, and - when
 // step c+1-DEPTH issued its DMA as a burst ahead of its stores - that step's stores too.
+// Two chunks per barrier (B2; a ring of >= DEPTH + 2 slots): the even step c certifies chunks c+1 AND c+2. This wave's DMA of chunk
+// c+2 was issued during step c-1; younger than it are only that step's stores when it issued its DMA as a burst ahead of them
+// (a step without stores spreads the pieces and issues nothing behind them), and nothing of step c (the wait sits in front of its
+// first epilogue slice).
+template <int MODE, bool SAVE>
+constexpr int wait_count_b2(int c) {
+    const int n = tile_stores<MODE, SAVE>(c - 2);       // step c-1 runs the epilogue of chunk c-2
+    return n < 63 ? n : 63;
+}
 template <int MODE, bool SAVE, int DEPTH>
 constexpr int wait_count(int c) {
     using PG = Prog<MODE>;
@@ -286,9 +304,16 @@ VDN_DEV AccT chunk_step(PipeT& pp, const ActT& X, Group&& group) {
             acc.template mfma<s>(fr[s], X);
 #endif
         });
-        if constexpr (gi == 0 && HAS_NEXT) {
+        // B2: with two spare ring slots the workgroup re-synchronises every SECOND step - the even step certifies chunks C+1 and C+2
+        // (the latter's DMA is one step old: an L2-warm piece lands in 250 - 400 cycles of the ~1 300 a step takes); the slot a step's
+        // DMA overwrites, that of chunk C-2, was last read in step C-2, which every wave had left at the latest barrier (C or C-1)
+        // (VDN_SDF2_B2 = 2: only for the chunks in front of the sweep - behind them one barrier per step again, with the spare slot idle;
+        // the change-over needs nothing: a step of the second kind certifies chunk C+1 by the ordinary count, whether or not the
+        // even step before it already did)
+        constexpr bool B2 = VDN_SDF2_B2 != 0 && NSLOT >= DEPTH + 2 && (VDN_SDF2_B2 != 2 || C < PG::first_chunk(PG::NL < 9 ? PG::NL : 9));
+        if constexpr (gi == 0 && HAS_NEXT && (!B2 || C % 2 == 0)) {
             __builtin_amdgcn_sched_barrier(0);      // the step's first MFMAs are in the pipe while the wave waits
-            wait_vmcnt<wait_count<MODE, SAVE, DEPTH>(C)>();
+            wait_vmcnt<B2 ? wait_count_b2<MODE, SAVE>(C) : wait_count<MODE, SAVE, DEPTH>(C)>();
 #if !(VDN_SDF2_ABL & 8)
             __builtin_amdgcn_s_barrier();
 #endif

@@ -22,7 +22,9 @@ extern "C" int vdn_sdf_mlp_fwd_bf16(int mode, const VdnSdfArgs* args, void* stre
         if (args->V == nullptr) return -3;
         return vdn::sdf2::launch<1, true, 4, 3>(args, stream);
     }
-    return vdn::sdf2::launch<1, false, 4, 3>(args, stream);
+    // (the inference launch: a 5-slot ring = one workgroup barrier per TWO chunk steps in front of the sweep, k_sdf_fwd2.h VDN_SDF2_B2;
+    // the training launch gains nothing from it - its steps wait on their plane stores - and keeps the 4-slot ring)
+    return vdn::sdf2::launch<1, false, 5, 3>(args, stream);
 }
 
 // One up-sampling round behind its SDF pass (renderer.py:201 + 372-386) in one launch: vdn_sdf_mlp_fwd_bf16(mode 0) on the new

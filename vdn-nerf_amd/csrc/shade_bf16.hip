@@ -20,6 +20,8 @@ extern "C" int vdn_shade_fused_bf16(const VdnSdfArgs* sa, const void* color_blob
     ex.ticket = ticket;
     ex.squeeze_out = squeeze_out;
     ex.cm = *cm;
+    // (the 4-slot ring: with a fifth slot - one barrier per two chunk steps, k_sdf_fwd2.h VDN_SDF2_B2 - 12 more softplus' tiles move
+    // from LDS into registers, and this mode, which also holds the colour head's input fragments, then spills: 512 VGPRs + 3)
     if (sa->feat != nullptr) return vdn::sdf2::launch<2, true, 4, 3>(sa, stream, nullptr, &ex);
     return vdn::sdf2::launch<2, false, 4, 3>(sa, stream, nullptr, &ex);
 }
