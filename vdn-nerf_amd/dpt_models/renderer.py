@@ -251,15 +251,22 @@ class _TrainPlan:
         """-> False when this call has to run eagerly (the engine has not run a backward yet)."""
         pat = (g_color is not None, g_feats is not None, g_weights is not None, g_eik is not None)
         ent = self.bwd.get(pat)
-        if ent is None:
-            if not getattr(eng, "_bwd_warm", False):
+        if ent is None or ent is False:
+            if not getattr(eng, "_bwd_warm", False) or ent is False:
                 return False
             B, dev = eng.B, eng.dev
             f = lambda *sh: torch.zeros(*sh, dtype=torch.float32, device=dev)
             bufs = (f(B, 3) if pat[0] else None, f(B, 96) if pat[1] else None, f(B, eng.T) if pat[2] else None, f(1) if pat[3] else None)
             g = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(g):
-                eng.backward(bufs[0], bufs[1], bufs[2], bufs[3])
+            try:
+                with torch.no_grad(), torch.cuda.graph(g):
+                    eng.backward(bufs[0], bufs[1], bufs[2], bufs[3])
+            except Exception as e:                           # (as for the forward: report once, this pattern stays eager)
+                import warnings
+                self.bwd[pat] = False
+                eng.__dict__.update(self.state)
+                warnings.warn("NeuSRenderer: capturing the backward of render() as a HIP graph failed (%s: %s); eager launches" % (type(e).__name__, e))
+                return False
             eng.__dict__.update(self.state)
             ent = self.bwd[pat] = (g, bufs)
         g, bufs = ent
@@ -744,9 +751,18 @@ class NeuSRenderer:
             seen[key] = seen.get(key, 0) + 1
             if seen[key] < 2:
                 return None                                  # the first call of a configuration runs eagerly (and warms everything up)
+            if seen[key] < 0:
+                return None                                  # (a capture of this configuration failed before: eager from then on)
             while len(plans) >= 4:
                 del plans[next(iter(plans))]
-            plan = plans[key] = _TrainPlan(self, eng, key[0], float(perturb), inject)
+            try:
+                plan = plans[key] = _TrainPlan(self, eng, key[0], float(perturb), inject)
+            except Exception as e:                           # never let the optimisation break a render(): report once, stay eager
+                import warnings
+                seen[key] = -(1 << 30)
+                warnings.warn("NeuSRenderer: capturing render() as a HIP graph failed (%s: %s); this configuration keeps the eager "
+                              "launches (VDN_RENDER_GRAPHS=0 silences the attempt)" % (type(e).__name__, e))
+                return None
         return plan
 
     def _render_train(self, rays_o, rays_d, z, z_out, background_rgb, cos_anneal_ratio, params, plan=None, eng=None):
