@@ -11,6 +11,7 @@ the cell size is exactly 1 and vertices come out in lattice index coordinates, f
 algorithm as restated here, NOT to an output of the library ("parity unpinned" against the binary; DESIGN.md says the same).
 The points of the restatement that decide the output bit for bit:
 
+  * the level is rounded to a C float on its way in (`_mcubes.pyx`: `float isovalue`), then compared and interpolated as a double;
   * cells are visited x-major, z innermost (`for i < nx-1: for j < ny-1: for k < nz-1`);
   * corner m of a cell is "set" when `v[m] <= isovalue` (Bourke's corner numbering: 0..3 the z face counter-clockwise from
     (x, y, z): (0,0,0) (1,0,0) (1,1,0) (0,1,0); 4..7 the same at z + 1);
@@ -325,7 +326,9 @@ def marching_cubes(u, isovalue):
     sequential library produces them."""
     u = np.asarray(u)
     nx, ny, nz = u.shape
-    iso = float(isovalue)
+    # `_mcubes.pyx` declares the array entry point as `marching_cubes(np.ndarray volume, float isovalue)`: the level passes through a C
+    # float before the C++ code takes it as a double (no effect on the reference's default threshold 0.0, dpt_runner.py: mcube_threshold)
+    iso = float(np.float32(isovalue))
     verts, tris = [], []
     owner = {}                      # (lattice node a, lattice node b) of a cut edge -> vertex number
     for i in range(nx - 1):

@@ -53,7 +53,8 @@ def marching_cubes(u, threshold=0.0):
     case = torch.empty(n, dtype=torch.uint8, device=dev)
     nv, nt = torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev)
     a = lib.VdnMeshMcArgs()
-    a.u, a.isovalue, a.R = u.data_ptr(), float(threshold), R
+    # (the library's array entry point takes the level as a C float - `_mcubes.pyx`: `float isovalue` - before its C++ code widens it)
+    a.u, a.isovalue, a.R = u.data_ptr(), float(torch.tensor(float(threshold), dtype=torch.float32).item()), R
     a.cube_case, a.n_verts, a.n_tris = case.data_ptr(), nv.data_ptr(), nt.data_ptr()
     lib.call("vdn_mesh_mc_count", a, st)
     iv, it = torch.cumsum(nv, 0, dtype=torch.int64), torch.cumsum(nt, 0, dtype=torch.int64)
