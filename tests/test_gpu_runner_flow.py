@@ -347,6 +347,38 @@ def test_graph_plan_draws_fresh_jitter_and_follows_forward_only_loops():
     assert all(torch.equal(a, p.grad) for a, p in zip(g1, rend._all_parameters()))
 
 
+def test_a_failed_graph_capture_falls_back_to_the_eager_launches(monkeypatch):
+    """The graph plan is an optimisation: if capturing it fails, render() warns once for that configuration and keeps issuing the
+    launches itself - same results."""
+    import warnings
+    from dpt_models import renderer as R
+    from vdn_train import synth, factory
+    dev = torch.device("cuda:0")
+    rend = factory.build_renderer(device=dev, states=synth.make_all_states(8, variance=0.4), precision="bf16")
+    cams = synth.make_cameras(8)
+    tt = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32, device=dev)
+    B = 32
+    o, d = synth.random_pixel_batch(8, 0, 1, B, cams=cams)
+    near, far = synth.near_far_from_sphere(o, d)
+    args = (tt(o), tt(d), tt(near), tt(far))
+    bg = torch.ones(1, 3, device=dev)
+
+    def boom(self, *a, **k):
+        raise RuntimeError("capture refused (test)")
+    monkeypatch.setattr(R._TrainPlan, "__init__", boom)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        cols = []
+        for _ in range(4):
+            out = rend.render(*args, background_rgb=bg, cos_anneal_ratio=1.0, perturb_overwrite=0)
+            out["color_fine"].sum().backward()
+            cols.append(out["color_fine"].detach().clone())
+    assert sum("capturing render() as a HIP graph failed" in str(x.message) for x in w) == 1
+    assert all(torch.equal(cols[0], c) for c in cols[1:])
+    eng = next(iter(rend.__dict__["_engines"].values()))
+    assert not eng.__dict__.get("_plans")
+
+
 def test_outputs_of_render_under_grad_allow_inplace_ops():
     """render() under grad hands out plain tensors (they were views of one arena, and autograd refuses in-place ops
     on the views of a multi-output node): color_fine.clamp_() and weight_sum.clip_() work, backward() still reaches every
