@@ -802,7 +802,9 @@ def main():
         g = lambda d, *ks: (g(d.get(ks[0]), *ks[1:]) if len(ks) > 1 else d.get(ks[0])) if isinstance(d, dict) else None
         rnd = lambda x: None if x is None else (round(x, 1) if abs(x) >= 100 else float("%.4g" % x))
         summary = {"value_rays_per_s": rnd(res["value"]), "ms_per_step": rnd(res["ms_per_step"]),
-                   "roofline_frac_in_step_one_stream": rnd(g(roof, "frac")), "roofline_frac_in_step_two_streams": rnd(g(roof, "in_step_two_streams", "frac")),
+                   # (`roofline.frac` is timed on the one-stream schedule at N = 1, inside the job's own two-stream steps at N > 1)
+                   ("roofline_frac_in_step_one_stream" if world == 1 else "roofline_frac_in_step_two_streams"): rnd(g(roof, "frac")),
+                   **({"roofline_frac_in_step_two_streams": rnd(g(roof, "in_step_two_streams", "frac"))} if world == 1 else {}),
                    "roofline_frac_inference_launch": rnd(g(roof, "inference_launch", "frac")),
                    "roofline_frac_training_launch_full_rows": rnd(g(roof, "training_launch_full_rows", "frac")),
                    "roofline_frac_c2_forward_one_launch": rnd(g(roof, "c2_forward", "frac")),
